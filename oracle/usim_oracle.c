@@ -1,0 +1,1132 @@
+/*
+ * usim_oracle.c -- CPU ORACLE for the batched Ultrasound simulator.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C, scalar, one-environment-at-a-time restatement of the reference hot path
+ * (SURVEY.md section 8a): robosuite MujocoEnv.step -> OSC_POSE controller -> MuJoCo mj_step
+ * (forward dynamics + soft constraints) -> Ultrasound sensors / reward / post-action / termination,
+ * plus reset.  Every function cites the reference file:line it follows; where the arithmetic lives
+ * in an un-vendored dependency (MuJoCo 2.0, robosuite fork, klampt, roboticstoolbox) the published
+ * algorithm is restated and marked [RESTATED] with the reference call-site that depends on it.
+ *
+ * PARITY UNPINNED at the MuJoCo boundary (see usim_oracle.h).  Pinned parts: env-level formulas from
+ * /root/reference/src/my_environments/ultrasound.py and src/utils/quaternion.py, checked in
+ * tests/test_oracle_*.py against tests/golden/reference_pins.npz.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * It is written independently of the HIP kernels (different algorithms where a choice exists:
+ * mass matrix by unit-acceleration RNE instead of CRBA, lattice solve by Cholesky instead of a
+ * precomputed inverse, generic body-tree FK instead of the unrolled Panda chain) so that agreement
+ * between the two is evidence about logic, not about shared code.
+ *
+ * Physical model (documented deviations from the 283-DoF MuJoCo model are listed in DESIGN.md):
+ *   arm     7 revolute DoF, RNE/CRBA dynamics, joint damping 0.1 (implicit in Euler), torque clip
+ *   torso   static base (optionally the prescribed 4.7 mm drop), 99 top-face elements = 1-DoF sliders
+ *           of mass 0.01 kg held by MuJoCo-style soft equality rows (joint "fix" rows + neighbour
+ *           "tendon" rows with solrefsmooth = (-stiffness,-damping)), solved exactly in primal form
+ *   contact probe capsule vs element capsules, condim 3 elliptic cone, soft (solref .02/1, solimp
+ *           .9/.95/.001/.5/2), projected Gauss-Seidel on the dual over contact rows only
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+#ifndef REAL
+#define REAL double
+#endif
+typedef REAL real;
+
+#include "usim_oracle.h"
+
+#define NJ 7
+#define PI 3.14159265358979323846
+
+/* ------------------------------------------------------------------------------------------------
+ * constants of the task (ultrasound.py:143-187) and of the models
+ * ---------------------------------------------------------------------------------------------- */
+static const double GOAL_QUAT_XYZW[4] = {-0.69192486, 0.72186726, -0.00514253, -0.01100909}; /* ultrasound.py:174 */
+#define GOAL_VELOCITY 0.04            /* ultrasound.py:175 */
+#define GOAL_FORCE 5.0                /* ultrasound.py:176 */
+#define GOAL_DFORCE 0.0               /* ultrasound.py:177 */
+#define POS_ERR_MUL 90.0              /* ultrasound.py:160 */
+#define ORI_ERR_MUL 0.2               /* ultrasound.py:161 */
+#define VEL_ERR_MUL 45.0              /* ultrasound.py:162 */
+#define FORCE_ERR_MUL 0.7             /* ultrasound.py:163 */
+#define DFORCE_ERR_MUL 0.01           /* ultrasound.py:164 */
+#define POS_REW_MUL 5.0               /* ultrasound.py:167 */
+#define ORI_REW_MUL 1.0               /* ultrasound.py:168 */
+#define VEL_REW_MUL 1.0               /* ultrasound.py:169 */
+#define FORCE_REW_MUL 3.0             /* ultrasound.py:170 */
+#define DFORCE_REW_MUL 2.0            /* ultrasound.py:171 */
+#define POS_ERR_THRESH 1.0            /* ultrasound.py:180 */
+#define ORI_ERR_THRESH 0.10           /* ultrasound.py:181 */
+#define FORCE_EMA_ALPHA 0.1           /* ultrasound.py:153 */
+#define NOISE_SIGMA 0.010             /* ultrasound.py:150 */
+#define TOP_TORSO_OFFSET 0.039        /* ultrasound.py:184 (box torso) */
+#define X_RANGE 0.15                  /* ultrasound.py:185 */
+#define Y_RANGE 0.09                  /* ultrasound.py:186 (box torso) */
+#define GRID_PTS 50                   /* ultrasound.py:187 */
+#define QLIM_TOL 0.1                  /* robosuite check_q_limits tolerance [RESTATED], ultrasound.py:651 */
+
+/* world placement */
+static const double BASE_WORLD[3] = {-0.56, 0.0, 0.913};   /* ultrasound.py:279-280, Panda on RethinkMount [RESTATED] */
+static const double TORSO_WORLD[3] = {0.0, 0.0, 0.8572};   /* ultrasound.py:146,304-314, soft_box.xml:14 (0.8+0.005+0.0522) */
+#define TORSO_DROP 0.0047             /* spawn gap above the table: 0.8572-0.0525-0.8 */
+#define GRAV 9.81
+
+/* Panda (robosuite asset, un-vendored) -- the build's own model definition */
+static const double LINK_POS[NJ][3] = {
+    {0, 0, 0.333}, {0, 0, 0}, {0, -0.316, 0}, {0.0825, 0, 0}, {-0.0825, 0.384, 0}, {0, 0, 0}, {0.088, 0, 0}};
+static const double LINK_QUAT_WXYZ[NJ][4] = {
+    {1, 0, 0, 0}, {0.7071067811865476, -0.7071067811865476, 0, 0}, {0.7071067811865476, 0.7071067811865476, 0, 0},
+    {0.7071067811865476, 0.7071067811865476, 0, 0}, {0.7071067811865476, -0.7071067811865476, 0, 0},
+    {0.7071067811865476, 0.7071067811865476, 0, 0}, {0.7071067811865476, 0.7071067811865476, 0, 0}};
+static const double LINK_MASS[NJ] = {3, 3, 2, 2, 2, 1.5, 0.5};
+static const double LINK_COM[NJ][3] = {
+    {0, 0, -0.07}, {0, -0.1, 0}, {0.04, 0, -0.05}, {-0.04, 0.05, 0}, {0, 0, -0.15}, {0.06, 0, 0}, {0, 0, 0.08}};
+static const double LINK_INERTIA[NJ] = {0.3, 0.3, 0.2, 0.2, 0.2, 0.1, 0.05};  /* isotropic diaginertia */
+static const double Q_MIN[NJ] = {-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973};
+static const double Q_MAX[NJ] = {2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973};
+static const double TAU_MAX[NJ] = {80, 80, 80, 80, 12, 12, 12};
+#define JOINT_DAMPING 0.1
+static const double INIT_QPOS[NJ] = {0.0, PI / 16.0, 0.0, -PI / 2.0 - PI / 3.0, 0.0, PI - 0.2, PI / 4.0};
+/* hand body on link7, then the probe body (ultrasound_probe_gripper.xml:6) */
+static const double HAND_POS[3] = {0, 0, 0.107};
+#define HAND_YAW (-PI / 4.0)
+#define HAND_MASS 0.5
+#define HAND_INERTIA 0.05
+static const double PROBE_POS[3] = {-0.004, -0.063, 0.128};   /* ultrasound_probe_gripper.xml:6 */
+#define PROBE_MASS 1.0                                         /* ultrasound_probe_gripper.xml:8 */
+/* The probe mesh is missing from the reference snapshot (.MISSING_LARGE_BLOBS:1): stand-in geometry */
+static const double PROBE_COM[3] = {0.0013, 0.021, -0.043};
+static const double PROBE_INERTIA[3] = {1.6e-3, 1.6e-3, 2.0e-4};
+#define PROBE_RADIUS 0.030
+#define PROBE_HALFLEN 0.020
+/* capsule axis = probe-frame y, centre one radius behind the tip (tip == grip_site) */
+
+/* soft torso lattice (soft_box.xml:9-10) */
+#define LAT_NX 9
+#define LAT_NY 4
+#define LAT_NZ 11
+#define LAT_SPACING 0.035
+#define ELEM_RADIUS 0.0075
+#define ELEM_HALFLEN 0.025
+#define ELEM_MASS 0.01
+#define N_SHELL 270
+#define N_TOP 99
+/* MuJoCo default constraint parameters [RESTATED from MuJoCo docs "Solver parameters"] */
+#define SOLREF_TC 0.02
+#define SOLREF_DR 1.0
+#define SOLIMP_D0 0.9
+#define SOLIMP_DMAX 0.95
+#define SOLIMP_WIDTH 0.001
+#define IMPRATIO 20.0                 /* robosuite base.xml option impratio=20 cone=elliptic [RESTATED] */
+/* systematic offset of the reference's DH-Panda IK seen in the decoded reset observations */
+static const double INIT_POS_BIAS[3] = {0.0028, 0.0008, 0.0066};
+
+/* ------------------------------------------------------------------------------------------------
+ * small helpers
+ * ---------------------------------------------------------------------------------------------- */
+static inline void v3set(real* a, real x, real y, real z) { a[0] = x; a[1] = y; a[2] = z; }
+static inline void v3cpy(real* a, const real* b) { a[0] = b[0]; a[1] = b[1]; a[2] = b[2]; }
+static inline void v3add(real* o, const real* a, const real* b) { o[0] = a[0] + b[0]; o[1] = a[1] + b[1]; o[2] = a[2] + b[2]; }
+static inline void v3sub(real* o, const real* a, const real* b) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2]; }
+static inline void v3addscl(real* o, const real* a, const real* b, real s) { o[0] = a[0] + s * b[0]; o[1] = a[1] + s * b[1]; o[2] = a[2] + s * b[2]; }
+static inline real v3dot(const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void v3cross(real* o, const real* a, const real* b) {
+    real x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static inline real v3norm(const real* a) { return (real)sqrt((double)v3dot(a, a)); }
+/* 3x3 row-major */
+static inline void m3mulv(real* o, const real* m, const real* v) {
+    real x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2], z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static inline void m3tmulv(real* o, const real* m, const real* v) {
+    real x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2], y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2], z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static void m3mul(real* o, const real* a, const real* b) {
+    real t[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) t[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+    memcpy(o, t, sizeof t);
+}
+static void quat_wxyz_to_mat(real* m, const double* q) {
+    double w = q[0], x = q[1], y = q[2], z = q[3];
+    double n = sqrt(w * w + x * x + y * y + z * z); w /= n; x /= n; y /= n; z /= n;
+    m[0] = (real)(1 - 2 * (y * y + z * z)); m[1] = (real)(2 * (x * y - w * z)); m[2] = (real)(2 * (x * z + w * y));
+    m[3] = (real)(2 * (x * y + w * z)); m[4] = (real)(1 - 2 * (x * x + z * z)); m[5] = (real)(2 * (y * z - w * x));
+    m[6] = (real)(2 * (x * z - w * y)); m[7] = (real)(2 * (y * z + w * x)); m[8] = (real)(1 - 2 * (x * x + y * y));
+}
+/* Cholesky of an n x n SPD matrix (row-major, lower factor written in place); returns 0 on success */
+static int chol(real* a, int n) {
+    for (int j = 0; j < n; j++) {
+        real d = a[j * n + j];
+        for (int k = 0; k < j; k++) d -= a[j * n + k] * a[j * n + k];
+        if (!(d > 0)) return -1;
+        d = (real)sqrt((double)d);
+        a[j * n + j] = d;
+        for (int i = j + 1; i < n; i++) {
+            real s = a[i * n + j];
+            for (int k = 0; k < j; k++) s -= a[i * n + k] * a[j * n + k];
+            a[i * n + j] = s / d;
+        }
+    }
+    return 0;
+}
+static void chol_solve(const real* l, int n, real* b) {
+    for (int i = 0; i < n; i++) { real s = b[i]; for (int k = 0; k < i; k++) s -= l[i * n + k] * b[k]; b[i] = s / l[i * n + i]; }
+    for (int i = n - 1; i >= 0; i--) { real s = b[i]; for (int k = i + 1; k < n; k++) s -= l[k * n + i] * b[k]; b[i] = s / l[i * n + i]; }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * counter-based RNG: Philox4x32-10 (Salmon et al. 2011), identical integer stream on CPU and GPU
+ * ---------------------------------------------------------------------------------------------- */
+static void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+static inline double u01(uint32_t u) { return (double)(u >> 8) * (1.0 / 16777216.0); }          /* [0,1) on a 2^-24 grid */
+static inline double u01_open(uint32_t u) { return (double)((u >> 8) + 1) * (1.0 / 16777216.0); } /* (0,1] */
+static inline uint32_t urange(uint32_t u, uint32_t n) { return (uint32_t)(((uint64_t)u * n) >> 32); }
+
+/* ------------------------------------------------------------------------------------------------
+ * model
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    /* robot tree in base-centred world axes */
+    real link_pos[NJ][3], link_rot[NJ][9];
+    real mass[NJ], com[NJ][3], inertia[NJ][9];      /* link-frame COM and inertia about COM (link 7 = composite with hand+probe) */
+    real site_pos7[3], site_rot7[9];                /* eef site (grip_site == ft_frame) in link-7 frame */
+    real hand_pos7[3];                              /* right_hand body origin in link-7 frame */
+    real probe_com7[3], probe_inertia7[9];          /* probe body alone (torque sensor), link-7 frame */
+    real cap_c_site[3], cap_axis_site[3];           /* probe capsule centre/axis in site frame */
+    real torso_c[3];                                /* torso centre at spawn, base-centred */
+    real goal_rot[9];                               /* rotmat of goal_quat */
+    /* lattice */
+    int n_el;                                       /* dynamic elements */
+    int el_shell_id[N_TOP];                         /* shell id of dynamic element k */
+    real el_pos[N_TOP][3], el_axis[N_TOP][3];       /* nominal surface point (rel. torso centre) and slide axis */
+    int el_nnbr[N_TOP], el_nbr[N_TOP][4];           /* neighbours: index into dynamic list or -1 = pinned */
+    real* lat_L;                                    /* Cholesky factor of the lattice normal matrix (n_el x n_el) */
+    real* lat_Linv;                                 /* explicit inverse (for contact Delassus entries) */
+    real w_fix, w_ten;
+    real invw_contact;                              /* regulariser scale for contact rows */
+    int n_shell_edges;
+} Model;
+
+typedef struct {
+    real q[NJ], qd[NJ], q0[NJ];
+    real traj_start[3], traj_end[3], u0;            /* world coordinates */
+    real vbar, fzbar, fzprev, dfz;
+    real kt_stiff, kt_damp, mu;                     /* per-env torso stiffness/damping, contact friction */
+    int t, has_touched, episode;
+    real ep_return;
+    real s[N_TOP], sd[N_TOP];
+    int ncon, con_el[USO_MAXC];
+    int status;
+} Env;
+
+typedef struct {
+    uso_config cfg;
+    Model m;
+    int n, adim;
+    Env* env;
+} Sim;
+
+static int shell_id_of(int ix, int iy, int iz) {
+    /* creation order of shell elements: ix outer, iy, iz inner, interior skipped */
+    int id = 0;
+    for (int a = 0; a < LAT_NX; a++) for (int b = 0; b < LAT_NY; b++) for (int c = 0; c < LAT_NZ; c++) {
+        int shell = (a == 0 || a == LAT_NX - 1 || b == 0 || b == LAT_NY - 1 || c == 0 || c == LAT_NZ - 1);
+        if (!shell) continue;
+        if (a == ix && b == iy && c == iz) return id;
+        id++;
+    }
+    return -1;
+}
+static int is_shell(int a, int b, int c) {
+    if (a < 0 || a >= LAT_NX || b < 0 || b >= LAT_NY || c < 0 || c >= LAT_NZ) return 0;
+    return (a == 0 || a == LAT_NX - 1 || b == 0 || b == LAT_NY - 1 || c == 0 || c == LAT_NZ - 1);
+}
+
+/* inertia of body B (mass mb, com cb, inertia Ib about its com) added into composite A, all in one frame */
+static void merge_inertia(double* ma, double ca[3], double Ia[9], double mb, const double cb[3], const double Ib[9]) {
+    double m = *ma + mb, c[3];
+    for (int i = 0; i < 3; i++) c[i] = (*ma * ca[i] + mb * cb[i]) / m;
+    double I[9];
+    for (int i = 0; i < 9; i++) I[i] = Ia[i] + Ib[i];
+    const double* cs[2] = {ca, cb}; double ms[2] = {*ma, mb};
+    for (int k = 0; k < 2; k++) {
+        double d[3] = {cs[k][0] - c[0], cs[k][1] - c[1], cs[k][2] - c[2]};
+        double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) I[3 * i + j] += ms[k] * ((i == j ? dd : 0.0) - d[i] * d[j]);
+    }
+    *ma = m; for (int i = 0; i < 3; i++) ca[i] = c[i]; for (int i = 0; i < 9; i++) Ia[i] = I[i];
+}
+
+/* forward declarations */
+static void fk_all(const Model* m, const real* q, real o[NJ][3], real R[NJ][9]);
+static void rne(const Model* m, const real* q, const real* qd, const real* qdd, real grav, real* tau,
+                real* w7, real* al7, real* a7, real o[NJ][3], real R[NJ][9]);
+
+static void build_model(Sim* S) {
+    Model* m = &S->m;
+    memset(m, 0, sizeof *m);
+    for (int i = 0; i < NJ; i++) {
+        for (int k = 0; k < 3; k++) { m->link_pos[i][k] = (real)LINK_POS[i][k]; m->com[i][k] = (real)LINK_COM[i][k]; }
+        quat_wxyz_to_mat(m->link_rot[i], LINK_QUAT_WXYZ[i]);
+        m->mass[i] = (real)LINK_MASS[i];
+        for (int k = 0; k < 9; k++) m->inertia[i][k] = 0;
+        m->inertia[i][0] = m->inertia[i][4] = m->inertia[i][8] = (real)LINK_INERTIA[i];
+    }
+    /* hand rotation about z by HAND_YAW (robosuite right_hand quat 0.924 0 0 -0.383) */
+    double ch = cos(HAND_YAW), sh = sin(HAND_YAW);
+    double Rh[9] = {ch, -sh, 0, sh, ch, 0, 0, 0, 1};
+    double site7[3];
+    for (int i = 0; i < 3; i++) site7[i] = HAND_POS[i] + Rh[3 * i] * PROBE_POS[0] + Rh[3 * i + 1] * PROBE_POS[1] + Rh[3 * i + 2] * PROBE_POS[2];
+    for (int i = 0; i < 3; i++) { m->site_pos7[i] = (real)site7[i]; m->hand_pos7[i] = (real)HAND_POS[i]; }
+    for (int i = 0; i < 9; i++) m->site_rot7[i] = (real)Rh[i];
+    /* probe COM and inertia in link-7 frame */
+    double pc7[3], Ip7[9];
+    for (int i = 0; i < 3; i++) pc7[i] = site7[i] + Rh[3 * i] * PROBE_COM[0] + Rh[3 * i + 1] * PROBE_COM[1] + Rh[3 * i + 2] * PROBE_COM[2];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double s = 0; for (int k = 0; k < 3; k++) s += Rh[3 * i + k] * PROBE_INERTIA[k] * Rh[3 * j + k];
+        Ip7[3 * i + j] = s;
+    }
+    for (int i = 0; i < 3; i++) m->probe_com7[i] = (real)pc7[i];
+    for (int i = 0; i < 9; i++) m->probe_inertia7[i] = (real)Ip7[i];
+    /* link 7 composite = link7 + hand + probe (no joints between them) */
+    double mc = LINK_MASS[6], cc[3] = {LINK_COM[6][0], LINK_COM[6][1], LINK_COM[6][2]};
+    double Ic[9] = {LINK_INERTIA[6], 0, 0, 0, LINK_INERTIA[6], 0, 0, 0, LINK_INERTIA[6]};
+    double Ih[9] = {HAND_INERTIA, 0, 0, 0, HAND_INERTIA, 0, 0, 0, HAND_INERTIA};
+    merge_inertia(&mc, cc, Ic, HAND_MASS, HAND_POS, Ih);
+    merge_inertia(&mc, cc, Ic, PROBE_MASS, pc7, Ip7);
+    m->mass[6] = (real)mc;
+    for (int i = 0; i < 3; i++) m->com[6][i] = (real)cc[i];
+    for (int i = 0; i < 9; i++) m->inertia[6][i] = (real)Ic[i];
+    /* probe collision capsule in the site frame */
+    v3set(m->cap_c_site, 0, 0, (real)(-S->cfg.probe_radius));
+    v3set(m->cap_axis_site, 0, 1, 0);
+    for (int i = 0; i < 3; i++) m->torso_c[i] = (real)(TORSO_WORLD[i] - BASE_WORLD[i]);
+    double gq[4] = {GOAL_QUAT_XYZW[3], GOAL_QUAT_XYZW[0], GOAL_QUAT_XYZW[1], GOAL_QUAT_XYZW[2]};
+    quat_wxyz_to_mat(m->goal_rot, gq);
+
+    /* ---- lattice: composite box count 9x4x11, shell only (soft_box.xml:9) ---- */
+    /* parent quat (0.5,0.5,-0.5,-0.5) (ultrasound.py:430): world x = -local z, y = -local x, z = local y */
+    const double Rt[9] = {0, 0, -1, -1, 0, 0, 0, 1, 0};
+    int top_of[LAT_NX][LAT_NZ];
+    int k = 0, nedge = 0;
+    for (int a = 0; a < LAT_NX; a++) for (int b = 0; b < LAT_NY; b++) for (int c = 0; c < LAT_NZ; c++) {
+        if (!is_shell(a, b, c)) continue;
+        /* count shell edges once (+ direction only) */
+        if (is_shell(a + 1, b, c)) nedge++;
+        if (is_shell(a, b + 1, c)) nedge++;
+        if (is_shell(a, b, c + 1)) nedge++;
+        if (b == LAT_NY - 1) { top_of[a][c] = k; k++; }
+    }
+    m->n_shell_edges = nedge;
+    m->n_el = (S->cfg.torso == USO_TORSO_TOP) ? N_TOP : 0;
+    for (int a = 0; a < LAT_NX; a++) for (int c = 0; c < LAT_NZ; c++) {
+        int e = top_of[a][c], b = LAT_NY - 1;
+        double loc[3] = {(a - 0.5 * (LAT_NX - 1)) * LAT_SPACING, (b - 0.5 * (LAT_NY - 1)) * LAT_SPACING, (c - 0.5 * (LAT_NZ - 1)) * LAT_SPACING};
+        double nl = sqrt(loc[0] * loc[0] + loc[1] * loc[1] + loc[2] * loc[2]);
+        for (int i = 0; i < 3; i++) {
+            double p = Rt[3 * i] * loc[0] + Rt[3 * i + 1] * loc[1] + Rt[3 * i + 2] * loc[2];
+            m->el_pos[e][i] = (real)p;
+            m->el_axis[e][i] = (real)(p / nl);      /* slide joint axis points radially from the centre [RESTATED] */
+        }
+        m->el_shell_id[e] = shell_id_of(a, b, c);
+        int nn = 0;
+        const int da[4] = {-1, 1, 0, 0}, dc[4] = {0, 0, -1, 1};
+        for (int d = 0; d < 4; d++) {
+            int a2 = a + da[d], c2 = c + dc[d];
+            if (a2 >= 0 && a2 < LAT_NX && c2 >= 0 && c2 < LAT_NZ) m->el_nbr[e][nn++] = top_of[a2][c2];
+        }
+        /* side-face neighbours (iy = 2) exist under every boundary node of the top face: pinned in TOP mode */
+        int npinned = 0;
+        if (is_shell(a, b - 1, c)) npinned = 1;
+        for (int p = 0; p < npinned; p++) m->el_nbr[e][nn++] = -1;
+        m->el_nnbr[e] = nn;
+    }
+    /* soft-equality weights: R = (1-d)/d * A_ii with d = dmax (constant; DESIGN.md deviation),
+     * A_ii = 1/m (joint row) or 2/m (tendon row) => weights relative to m: d/(1-d) and d/(2(1-d)) */
+    m->w_fix = (real)(SOLIMP_DMAX / (1.0 - SOLIMP_DMAX));
+    m->w_ten = (real)(0.5 * SOLIMP_DMAX / (1.0 - SOLIMP_DMAX));
+    if (m->n_el) {
+        int n = m->n_el;
+        m->lat_L = (real*)calloc((size_t)n * n, sizeof(real));
+        m->lat_Linv = (real*)calloc((size_t)n * n, sizeof(real));
+        for (int e = 0; e < n; e++) {
+            m->lat_L[e * n + e] = 1 + m->w_fix + m->w_ten * m->el_nnbr[e];
+            for (int d = 0; d < m->el_nnbr[e]; d++) if (m->el_nbr[e][d] >= 0) m->lat_L[e * n + m->el_nbr[e][d]] = -m->w_ten;
+        }
+        if (chol(m->lat_L, n)) { fprintf(stderr, "usim_oracle: lattice matrix not SPD\n"); abort(); }
+        real* col = (real*)malloc(sizeof(real) * n);
+        for (int j = 0; j < n; j++) {
+            for (int i = 0; i < n; i++) col[i] = (i == j);
+            chol_solve(m->lat_L, n, col);
+            for (int i = 0; i < n; i++) m->lat_Linv[i * n + j] = col[i];
+        }
+        free(col);
+    }
+    /* contact regulariser scale: translational inverse weights of the two bodies [RESTATED: MuJoCo
+     * body_invweight0], probe at init_qpos, element = (1/m + 2/M_torso)/3 */
+    {
+        real q[NJ], z[NJ] = {0}, o[NJ][3], R[NJ][9], Mm[NJ * NJ], col[NJ], t0[NJ];
+        for (int i = 0; i < NJ; i++) q[i] = (real)INIT_QPOS[i];
+        rne(m, q, z, z, 0, t0, 0, 0, 0, o, R);
+        for (int j = 0; j < NJ; j++) {
+            real e[NJ] = {0}; e[j] = 1;
+            rne(m, q, z, e, 0, col, 0, 0, 0, o, R);
+            for (int i = 0; i < NJ; i++) Mm[i * NJ + j] = col[i];
+        }
+        chol(Mm, NJ);
+        real x[3], tmp[3]; m3mulv(tmp, R[6], m->site_pos7); v3add(x, o[6], tmp);
+        double tr = 0;
+        for (int ax = 0; ax < 3; ax++) {
+            real jt[NJ];
+            for (int i = 0; i < NJ; i++) { real zi[3] = {R[i][2], R[i][5], R[i][8]}, r[3], c[3]; v3sub(r, x, o[i]); v3cross(c, zi, r); jt[i] = c[ax]; }
+            real y[NJ]; memcpy(y, jt, sizeof y); chol_solve(Mm, NJ, y);
+            for (int i = 0; i < NJ; i++) tr += (double)(jt[i] * y[i]);
+        }
+        double invw_elem = (1.0 / ELEM_MASS + 2.0 / (N_SHELL * ELEM_MASS)) / 3.0;
+        m->invw_contact = (real)(tr / 3.0 + invw_elem);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * kinematics and dynamics of the arm  [RESTATED: MuJoCo mj_kinematics / mj_rne / mj_crb semantics]
+ * ---------------------------------------------------------------------------------------------- */
+static void fk_all(const Model* m, const real* q, real o[NJ][3], real R[NJ][9]) {
+    real po[3] = {0, 0, 0}, pR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int i = 0; i < NJ; i++) {
+        real t[3], Rf[9];
+        m3mulv(t, pR, m->link_pos[i]); v3add(o[i], po, t);
+        m3mul(Rf, pR, m->link_rot[i]);
+        real c = (real)cos((double)q[i]), s = (real)sin((double)q[i]);
+        real Rz[9] = {c, -s, 0, s, c, 0, 0, 0, 1};
+        m3mul(R[i], Rf, Rz);
+        v3cpy(po, o[i]); memcpy(pR, R[i], sizeof pR);
+    }
+}
+
+/* Recursive Newton-Euler.  tau = ID(q, qd, qdd) with gravity `grav` along -z.  Optionally returns the
+ * angular velocity, angular acceleration and origin acceleration (incl. the +g pseudo-acceleration)
+ * of link 7. */
+static void rne(const Model* m, const real* q, const real* qd, const real* qdd, real grav, real* tau,
+                real* w7, real* al7, real* a7, real o[NJ][3], real R[NJ][9]) {
+    fk_all(m, q, o, R);
+    real w[NJ][3], al[NJ][3], a[NJ][3], F[NJ][3], N[NJ][3], c[NJ][3];
+    real wp[3] = {0, 0, 0}, alp[3] = {0, 0, 0}, ap[3] = {0, 0, grav}, op[3] = {0, 0, 0};
+    for (int i = 0; i < NJ; i++) {
+        real z[3] = {R[i][2], R[i][5], R[i][8]}, r[3], t1[3], t2[3];
+        v3sub(r, o[i], op);
+        /* origin acceleration carried from the parent */
+        v3cross(t1, alp, r); v3cross(t2, wp, r); v3cross(t2, wp, t2);
+        for (int k = 0; k < 3; k++) a[i][k] = ap[k] + t1[k] + t2[k];
+        v3cross(t1, wp, z);
+        for (int k = 0; k < 3; k++) { w[i][k] = wp[k] + z[k] * qd[i]; al[i][k] = alp[k] + z[k] * qdd[i] + t1[k] * qd[i]; }
+        /* COM */
+        real rc[3]; m3mulv(rc, R[i], m->com[i]); v3add(c[i], o[i], rc);
+        real ac[3];
+        v3cross(t1, al[i], rc); v3cross(t2, w[i], rc); v3cross(t2, w[i], t2);
+        for (int k = 0; k < 3; k++) ac[k] = a[i][k] + t1[k] + t2[k];
+        for (int k = 0; k < 3; k++) F[i][k] = m->mass[i] * ac[k];
+        /* N = I al + w x I w, I = R I_link R^T */
+        real Iw[9], tmp[9], Rt[9] = {R[i][0], R[i][3], R[i][6], R[i][1], R[i][4], R[i][7], R[i][2], R[i][5], R[i][8]};
+        m3mul(tmp, R[i], m->inertia[i]); m3mul(Iw, tmp, Rt);
+        real Ial[3], Iww[3];
+        m3mulv(Ial, Iw, al[i]); m3mulv(Iww, Iw, w[i]); v3cross(t1, w[i], Iww);
+        for (int k = 0; k < 3; k++) N[i][k] = Ial[k] + t1[k];
+        v3cpy(wp, w[i]); v3cpy(alp, al[i]); v3cpy(ap, a[i]); v3cpy(op, o[i]);
+    }
+    real f[3] = {0, 0, 0}, n[3] = {0, 0, 0};  /* force / moment (about o[i]) transmitted through joint i */
+    for (int i = NJ - 1; i >= 0; i--) {
+        real t1[3], rc[3];
+        if (i < NJ - 1) { real r[3]; v3sub(r, o[i + 1], o[i]); v3cross(t1, r, f); v3add(n, n, t1); }
+        v3sub(rc, c[i], o[i]); v3cross(t1, rc, F[i]);
+        for (int k = 0; k < 3; k++) { n[k] += N[i][k] + t1[k]; f[k] += F[i][k]; }
+        real z[3] = {R[i][2], R[i][5], R[i][8]};
+        tau[i] = v3dot(z, n);
+    }
+    if (w7) v3cpy(w7, w[NJ - 1]);
+    if (al7) v3cpy(al7, al[NJ - 1]);
+    if (a7) v3cpy(a7, a[NJ - 1]);
+}
+
+typedef struct {
+    real o[NJ][3], R[NJ][9];
+    real x[3], Rs[9];           /* eef site pose (base-centred world axes) */
+    real hand[3];               /* right_hand body origin */
+    real J[6][NJ];              /* site Jacobian: rows 0-2 linear, 3-5 angular */
+    real M[NJ * NJ], Lm[NJ * NJ];   /* mass matrix and its Cholesky factor */
+    real bias[NJ];              /* qfrc_bias */
+    real w7[3];                 /* angular velocity of link 7 */
+} KinDyn;
+
+static void kin_dyn(const Model* m, const real* q, const real* qd, KinDyn* k) {
+    real z7[NJ] = {0};
+    rne(m, q, qd, z7, (real)GRAV, k->bias, k->w7, 0, 0, k->o, k->R);
+    /* mass matrix column j = ID(q, 0, e_j) without gravity (independent of the GPU's CRBA) */
+    real col[NJ], o[NJ][3], R[NJ][9];
+    for (int j = 0; j < NJ; j++) {
+        real e[NJ] = {0}; e[j] = 1;
+        rne(m, q, z7, e, 0, col, 0, 0, 0, o, R);
+        for (int i = 0; i < NJ; i++) k->M[i * NJ + j] = col[i];
+    }
+    for (int i = 0; i < NJ; i++) for (int j = 0; j < i; j++) { real s = (real)0.5 * (k->M[i * NJ + j] + k->M[j * NJ + i]); k->M[i * NJ + j] = k->M[j * NJ + i] = s; }
+    memcpy(k->Lm, k->M, sizeof k->M);
+    chol(k->Lm, NJ);
+    real t[3];
+    m3mulv(t, k->R[6], m->site_pos7); v3add(k->x, k->o[6], t);
+    m3mul(k->Rs, k->R[6], m->site_rot7);
+    m3mulv(t, k->R[6], m->hand_pos7); v3add(k->hand, k->o[6], t);
+    for (int i = 0; i < NJ; i++) {
+        real z[3] = {k->R[i][2], k->R[i][5], k->R[i][8]}, r[3], c[3];
+        v3sub(r, k->x, k->o[i]); v3cross(c, z, r);
+        for (int a = 0; a < 3; a++) { k->J[a][i] = c[a]; k->J[3 + a][i] = z[a]; }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * OSC_POSE controller  [RESTATED: robosuite controllers/osc.py run_controller + opspace_matrices +
+ * nullspace_torques; config rl_config.yaml:33-51; fork modes inferred per SURVEY.md C.3]
+ * ---------------------------------------------------------------------------------------------- */
+static int inv_spd(real* a, int n) {   /* in-place inverse of an SPD matrix (np.linalg.pinv on a regular matrix) */
+    real l[36], col[6], out[36];
+    memcpy(l, a, sizeof(real) * n * n);
+    if (chol(l, n)) return -1;
+    for (int j = 0; j < n; j++) { for (int i = 0; i < n; i++) col[i] = (i == j); chol_solve(l, n, col); for (int i = 0; i < n; i++) out[i * n + j] = col[i]; }
+    memcpy(a, out, sizeof(real) * n * n);
+    return 0;
+}
+
+static void osc_torque(const Sim* S, const KinDyn* k, const real* q, const real* qd, const real* q0,
+                       const real* goal_pos, const real* goal_rot, const real* kp, const real* kd, real* tau) {
+    /* site velocity */
+    real v[6];
+    for (int a = 0; a < 6; a++) { real s = 0; for (int i = 0; i < NJ; i++) s += k->J[a][i] * qd[i]; v[a] = s; }
+    /* orientation error 0.5*(sum_i rc_i x rd_i) over matrix columns */
+    real eo[3] = {0, 0, 0};
+    for (int c = 0; c < 3; c++) {
+        real rc[3] = {k->Rs[c], k->Rs[3 + c], k->Rs[6 + c]}, rd[3] = {goal_rot[c], goal_rot[3 + c], goal_rot[6 + c]}, x[3];
+        v3cross(x, rc, rd); for (int a = 0; a < 3; a++) eo[a] += (real)0.5 * x[a];
+    }
+    real F[3], T[3];
+    for (int a = 0; a < 3; a++) { F[a] = (goal_pos[a] - k->x[a]) * kp[a] - v[a] * kd[a]; T[a] = eo[a] * kp[3 + a] - v[3 + a] * kd[3 + a]; }
+    /* M^-1 J^T (7x6) */
+    real MiJt[NJ][6];
+    for (int a = 0; a < 6; a++) { real col[NJ]; for (int i = 0; i < NJ; i++) col[i] = k->J[a][i]; chol_solve(k->Lm, NJ, col); for (int i = 0; i < NJ; i++) MiJt[i][a] = col[i]; }
+    real lam_full[36], lam_pos[9], lam_ori[9];
+    for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) { real s = 0; for (int i = 0; i < NJ; i++) s += k->J[a][i] * MiJt[i][b]; lam_full[a * 6 + b] = s; }
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) { lam_pos[a * 3 + b] = lam_full[a * 6 + b]; lam_ori[a * 3 + b] = lam_full[(3 + a) * 6 + 3 + b]; }
+    inv_spd(lam_full, 6); inv_spd(lam_pos, 3); inv_spd(lam_ori, 3);
+    real wr[6];
+    (void)S;
+    m3mulv(wr, lam_pos, F); m3mulv(wr + 3, lam_ori, T);       /* uncouple_pos_ori: True (rl_config.yaml:48) */
+    for (int i = 0; i < NJ; i++) { real s = k->bias[i]; for (int a = 0; a < 6; a++) s += k->J[a][i] * wr[a]; tau[i] = s; }
+    /* nullspace: tau += N^T M (10 (q0-q) - 2 sqrt(10) qd),  N = I - Jbar J, Jbar = M^-1 J^T lam_full */
+    real pt[NJ], ptm[NJ];
+    real jkv = (real)(2.0 * sqrt(10.0));
+    for (int i = 0; i < NJ; i++) pt[i] = (real)10.0 * (q0[i] - q[i]) - jkv * qd[i];
+    for (int i = 0; i < NJ; i++) { real s = 0; for (int j = 0; j < NJ; j++) s += k->M[i * NJ + j] * pt[j]; ptm[i] = s; }
+    /* N^T y = y - J^T Jbar^T y */
+    real jb[6], lj[6];
+    for (int a = 0; a < 6; a++) { real s = 0; for (int i = 0; i < NJ; i++) s += MiJt[i][a] * ptm[i]; jb[a] = s; }   /* (M^-1 J^T)^T y */
+    for (int a = 0; a < 6; a++) { real s = 0; for (int b = 0; b < 6; b++) s += lam_full[b * 6 + a] * jb[b]; lj[a] = s; } /* lam^T (..) */
+    for (int i = 0; i < NJ; i++) { real s = ptm[i]; for (int a = 0; a < 6; a++) s -= k->J[a][i] * lj[a]; tau[i] += s; }
+    for (int i = 0; i < NJ; i++) { real lim = (real)TAU_MAX[i]; if (tau[i] > lim) tau[i] = lim; if (tau[i] < -lim) tau[i] = -lim; }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * constrained forward dynamics  [RESTATED: MuJoCo mj_fwdAcceleration + mj_fwdConstraint semantics,
+ * SURVEY.md C.4; soft-constraint formulas from MuJoCo docs "Solver parameters"]
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    real qacc[NJ];
+    real ael[N_TOP];
+    int ncon, con_el[USO_MAXC];
+    real con_dist[USO_MAXC];
+    real fc[3];                 /* cfrc_ext[probe][3:6]: net contact force on the probe, world axes */
+    real tq_sensor[3];          /* torque sensor at ft_frame, site frame */
+    real min_margin;            /* smallest |dist| among near-contact candidate pairs (threshold diagnostics) */
+    int overflow;
+} Fwd;
+
+static real torso_dz(const Sim* S, int t, real* vz, real* az) {
+    /* prescribed base motion: free fall from the 4.7 mm spawn gap, then rest (ultrasound.py:313) */
+    *vz = 0; *az = 0;
+    if (!S->cfg.torso_drop) return (real)(-TORSO_DROP);
+    double tt = t * S->cfg.control_dt, z = -0.5 * GRAV * tt * tt;
+    if (z <= -TORSO_DROP) return (real)(-TORSO_DROP);
+    *vz = (real)(-GRAV * tt); *az = (real)(-GRAV);
+    return (real)z;
+}
+
+/* closest points between segments p1+s*d1 (s in [0,1]) and p2+t*d2 (Ericson, Real-Time Collision Detection 5.1.9) */
+static void seg_seg(const real* p1, const real* d1, const real* p2, const real* d2, real* c1, real* c2) {
+    real r[3]; v3sub(r, p1, p2);
+    real a = v3dot(d1, d1), e = v3dot(d2, d2), f = v3dot(d2, r), s, t;
+    const real EPS = (real)1e-12;
+    if (a <= EPS && e <= EPS) { s = t = 0; }
+    else if (a <= EPS) { s = 0; t = f / e; t = t < 0 ? 0 : (t > 1 ? 1 : t); }
+    else {
+        real c = v3dot(d1, r);
+        if (e <= EPS) { t = 0; s = -c / a; s = s < 0 ? 0 : (s > 1 ? 1 : s); }
+        else {
+            real b = v3dot(d1, d2), den = a * e - b * b;
+            s = (den > EPS) ? (b * f - c * e) / den : 0;
+            s = s < 0 ? 0 : (s > 1 ? 1 : s);
+            t = (b * s + f) / e;
+            if (t < 0) { t = 0; s = -c / a; s = s < 0 ? 0 : (s > 1 ? 1 : s); }
+            else if (t > 1) { t = 1; s = (b - c) / a; s = s < 0 ? 0 : (s > 1 ? 1 : s); }
+        }
+    }
+    v3addscl(c1, p1, d1, s); v3addscl(c2, p2, d2, t);
+}
+
+static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, const real* tau, Fwd* out) {
+    const Model* m = &S->m;
+    const real dt = (real)S->cfg.control_dt; (void)dt;
+    memset(out, 0, sizeof *out);
+    out->min_margin = (real)1e9;
+    /* smooth acceleration of the arm: M qacc_s = tau - bias - D qd */
+    real qs[NJ];
+    for (int i = 0; i < NJ; i++) qs[i] = tau[i] - k->bias[i] - (real)JOINT_DAMPING * E->qd[i];
+    chol_solve(k->Lm, NJ, qs);
+    int n = m->n_el;
+    real vz, az, dz = torso_dz(S, E->t > 0 ? E->t - 1 : 0, &vz, &az);   /* mj_step's forward runs at the pre-step time */
+    if (n == 0) {
+        memcpy(out->qacc, qs, sizeof qs);
+    } else {
+        /* ---- lattice equality rows, primal form: L a = a_s + w_fix aref_fix + w_ten sum aref_ij ---- */
+        const real dmax = (real)SOLIMP_DMAX;
+        const real kfix = (real)(1.0 / (SOLIMP_DMAX * SOLREF_TC * SOLREF_TC * SOLREF_DR * SOLREF_DR));  /* d/(dmax^2 tc^2 dr^2), d=dmax */
+        const real bfix = (real)(2.0 / (SOLIMP_DMAX * SOLREF_TC));
+        const real kten = E->kt_stiff / dmax, bten = E->kt_damp / dmax;   /* direct mode: k = stiffness d/dmax^2, b = damping/dmax */
+        real rhs[N_TOP];
+        for (int e = 0; e < n; e++) {
+            real as = -((real)GRAV + az) * m->el_axis[e][2];
+            real r = as + m->w_fix * (-bfix * E->sd[e] - kfix * E->s[e]);
+            for (int d = 0; d < m->el_nnbr[e]; d++) {
+                int j = m->el_nbr[e][d];
+                real sj = j >= 0 ? E->s[j] : 0, sdj = j >= 0 ? E->sd[j] : 0;
+                r += m->w_ten * (-bten * (E->sd[e] - sdj) - kten * (E->s[e] - sj));
+            }
+            rhs[e] = r;
+        }
+        chol_solve(m->lat_L, n, rhs);            /* rhs now holds a~ (element accelerations without contacts) */
+
+        /* ---- collision: probe capsule vs every dynamic element capsule, ascending shell id ---- */
+        real cc[3], ax[3], t3[3], p1[3], d1[3];
+        m3mulv(t3, k->Rs, m->cap_c_site); v3add(cc, k->x, t3);
+        m3mulv(ax, k->Rs, m->cap_axis_site);
+        v3addscl(p1, cc, ax, (real)(-S->cfg.probe_halflen)); v3set(d1, ax[0] * (real)(2 * S->cfg.probe_halflen), ax[1] * (real)(2 * S->cfg.probe_halflen), ax[2] * (real)(2 * S->cfg.probe_halflen));
+        int nc = 0;
+        real cn[USO_MAXC][3], cp[USO_MAXC][3], cdist[USO_MAXC];
+        for (int e = 0; e < n; e++) {
+            real tip[3], p2[3], d2[3], c1[3], c2[3], d[3];
+            for (int a = 0; a < 3; a++) tip[a] = m->torso_c[a] + m->el_pos[e][a] + (E->s[e] - (real)ELEM_RADIUS) * m->el_axis[e][a];
+            tip[2] += dz;
+            v3addscl(p2, tip, m->el_axis[e], (real)(-2 * ELEM_HALFLEN));
+            v3set(d2, m->el_axis[e][0] * (real)(2 * ELEM_HALFLEN), m->el_axis[e][1] * (real)(2 * ELEM_HALFLEN), m->el_axis[e][2] * (real)(2 * ELEM_HALFLEN));
+            seg_seg(p1, d1, p2, d2, c1, c2);
+            v3sub(d, c1, c2);
+            real len = v3norm(d), dist = len - (real)(S->cfg.probe_radius + ELEM_RADIUS);
+            real am = (real)fabs((double)dist);
+            if (am < out->min_margin) out->min_margin = am;
+            if (dist < 0) {
+                if (nc >= USO_MAXC) { out->overflow = 1; continue; }
+                if (len > (real)1e-9) { for (int a = 0; a < 3; a++) cn[nc][a] = d[a] / len; } else v3set(cn[nc], 0, 0, 1);
+                for (int a = 0; a < 3; a++) cp[nc][a] = c2[a] + cn[nc][a] * ((real)ELEM_RADIUS + (real)0.5 * dist);
+                cdist[nc] = dist; out->con_el[nc] = e; out->con_dist[nc] = dist; nc++;
+            }
+        }
+        out->ncon = nc;
+
+        /* ---- contact rows ---- */
+        real W[6] = {0, 0, 0, 0, 0, 0};           /* site-space wrench of all contact forces */
+        real gf[USO_MAXC];                        /* force along the element axis per contact */
+        if (nc > 0) {
+            /* Lam^-1 = J M^-1 J^T (6x6) */
+            real MiJt[NJ][6], Li[36];
+            for (int a = 0; a < 6; a++) { real col[NJ]; for (int i = 0; i < NJ; i++) col[i] = k->J[a][i]; chol_solve(k->Lm, NJ, col); for (int i = 0; i < NJ; i++) MiJt[i][a] = col[i]; }
+            for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) { real s = 0; for (int i = 0; i < NJ; i++) s += k->J[a][i] * MiJt[i][b]; Li[a * 6 + b] = s; }
+            real alpha[6], vsite[6];             /* site-space acceleration J qacc and velocity J qd */
+            for (int a = 0; a < 6; a++) { real s = 0, u = 0; for (int i = 0; i < NJ; i++) { s += k->J[a][i] * qs[i]; u += k->J[a][i] * E->qd[i]; } alpha[a] = s; vsite[a] = u; }
+            real w[USO_MAXC][3][6], g[USO_MAXC][3], Liw[USO_MAXC][3][6], aref[USO_MAXC][3], Rr[USO_MAXC][3], Ad[USO_MAXC][3], f[USO_MAXC][3], ae[USO_MAXC];
+            const real b = (real)(2.0 / (SOLIMP_DMAX * SOLREF_TC));
+            for (int c = 0; c < nc; c++) {
+                int e = out->con_el[c];
+                real dir[3][3];
+                v3cpy(dir[0], cn[c]);
+                real ref[3] = {1, 0, 0}; if (fabs((double)cn[c][0]) > 0.9) v3set(ref, 0, 1, 0);
+                v3cross(dir[1], cn[c], ref); real l1 = v3norm(dir[1]); for (int a = 0; a < 3; a++) dir[1][a] /= l1;
+                v3cross(dir[2], cn[c], dir[1]);
+                real r[3]; v3sub(r, cp[c], k->x);
+                /* impedance d(r) (solimp .9 .95 .001 .5 2) */
+                real xx = -cdist[c] / (real)SOLIMP_WIDTH; if (xx > 1) xx = 1;
+                real y = xx < (real)0.5 ? 2 * xx * xx : 1 - 2 * (1 - xx) * (1 - xx);
+                real dimp = (real)SOLIMP_D0 + y * (real)(SOLIMP_DMAX - SOLIMP_D0);
+                real kk = dimp / (real)(SOLIMP_DMAX * SOLIMP_DMAX * SOLREF_TC * SOLREF_TC * SOLREF_DR * SOLREF_DR);
+                real Rn = (1 - dimp) / dimp * m->invw_contact;
+                ae[c] = rhs[e];
+                for (int d = 0; d < 3; d++) {
+                    real rx[3]; v3cross(rx, r, dir[d]);
+                    for (int a = 0; a < 3; a++) { w[c][d][a] = dir[d][a]; w[c][d][3 + a] = rx[a]; }
+                    g[c][d] = -v3dot(dir[d], m->el_axis[e]);
+                    for (int a = 0; a < 6; a++) { real s = 0; for (int bb = 0; bb < 6; bb++) s += Li[a * 6 + bb] * w[c][d][bb]; Liw[c][d][a] = s; }
+                    real vrel = g[c][d] * E->sd[e] - dir[d][2] * vz;
+                    for (int a = 0; a < 6; a++) vrel += w[c][d][a] * vsite[a];
+                    aref[c][d] = -b * vrel - (d == 0 ? kk * cdist[c] : 0);
+                    Rr[c][d] = d == 0 ? Rn : Rn / (real)IMPRATIO;
+                    real Aii = g[c][d] * g[c][d] * m->lat_Linv[e * n + e] / (real)ELEM_MASS;
+                    for (int a = 0; a < 6; a++) Aii += w[c][d][a] * Liw[c][d][a];
+                    Ad[c][d] = Aii;
+                    f[c][d] = 0;
+                }
+            }
+            /* ---- projected Gauss-Seidel on the dual, fixed sweep count, no warm start ---- */
+            for (int it = 0; it < S->cfg.pgs_iters; it++) {
+                for (int c = 0; c < nc; c++) {
+                    int e = out->con_el[c];
+                    for (int d = 0; d < 3; d++) {
+                        real res = g[c][d] * ae[c] - aref[c][d] + Rr[c][d] * f[c][d];
+                        for (int a = 0; a < 6; a++) res += w[c][d][a] * alpha[a];
+                        real fn = f[c][d] - res / (Ad[c][d] + Rr[c][d]);
+                        if (d == 0 && fn < 0) fn = 0;
+                        real df = fn - f[c][d];
+                        f[c][d] = fn;
+                        for (int a = 0; a < 6; a++) alpha[a] += Liw[c][d][a] * df;
+                        for (int c2 = 0; c2 < nc; c2++) ae[c2] += m->lat_Linv[out->con_el[c2] * n + e] * g[c][d] * df / (real)ELEM_MASS;
+                    }
+                    /* elliptic cone: |f_t| <= mu f_n */
+                    real ft = (real)sqrt((double)(f[c][1] * f[c][1] + f[c][2] * f[c][2])), lim = E->mu * f[c][0];
+                    if (ft > lim) {
+                        real sc = ft > 0 ? lim / ft : 0;
+                        for (int d = 1; d < 3; d++) {
+                            real df = f[c][d] * sc - f[c][d];
+                            f[c][d] += df;
+                            for (int a = 0; a < 6; a++) alpha[a] += Liw[c][d][a] * df;
+                            for (int c2 = 0; c2 < nc; c2++) ae[c2] += m->lat_Linv[out->con_el[c2] * n + e] * g[c][d] * df / (real)ELEM_MASS;
+                        }
+                    }
+                }
+            }
+            for (int c = 0; c < nc; c++) {
+                gf[c] = 0;
+                for (int d = 0; d < 3; d++) {
+                    for (int a = 0; a < 6; a++) W[a] += w[c][d][a] * f[c][d];
+                    gf[c] += g[c][d] * f[c][d];
+                }
+            }
+        }
+        /* accelerations */
+        for (int i = 0; i < NJ; i++) { real s = 0; for (int a = 0; a < 6; a++) s += k->J[a][i] * W[a]; out->qacc[i] = s; }
+        chol_solve(k->Lm, NJ, out->qacc);
+        for (int i = 0; i < NJ; i++) out->qacc[i] += qs[i];
+        for (int e = 0; e < n; e++) {
+            real a = rhs[e];
+            for (int c = 0; c < nc; c++) a += m->lat_Linv[e * n + out->con_el[c]] * gf[c] / (real)ELEM_MASS;
+            out->ael[e] = a;
+        }
+        v3set(out->fc, W[0], W[1], W[2]);
+        /* contact torque about the site is W[3..5] */
+        out->tq_sensor[0] = W[3]; out->tq_sensor[1] = W[4]; out->tq_sensor[2] = W[5];
+    }
+}
+
+/* torque sensor at ft_frame [RESTATED: MuJoCo mj_rnePostConstraint cfrc_int of the probe body expressed in
+ * the site frame]: wrench the hand applies to the probe = inertial + gravity - contact, about the site */
+static void torque_sensor(const Sim* S, const Env* E, const KinDyn* k, const real* qacc, const real* contact_torque, real* out) {
+    const Model* m = &S->m;
+    real tau[NJ], w7[3], al7[3], a7[3], o[NJ][3], R[NJ][9];
+    rne(m, E->q, E->qd, qacc, (real)GRAV, tau, w7, al7, a7, o, R);
+    real rc[3], rs[3], ac[3], t1[3], t2[3];
+    m3mulv(rc, R[6], m->probe_com7);
+    v3cross(t1, al7, rc); v3cross(t2, w7, rc); v3cross(t2, w7, t2);
+    for (int a = 0; a < 3; a++) ac[a] = a7[a] + t1[a] + t2[a];
+    real Iw[9], tmp[9], Rt[9] = {R[6][0], R[6][3], R[6][6], R[6][1], R[6][4], R[6][7], R[6][2], R[6][5], R[6][8]};
+    m3mul(tmp, R[6], m->probe_inertia7); m3mul(Iw, tmp, Rt);
+    real Ial[3], Iww[3], N[3], F[3];
+    m3mulv(Ial, Iw, al7); m3mulv(Iww, Iw, w7); v3cross(t1, w7, Iww);
+    for (int a = 0; a < 3; a++) { N[a] = Ial[a] + t1[a]; F[a] = (real)PROBE_MASS * ac[a]; }
+    /* moment about the site: N + (c - x) x F - contact torque about the site */
+    real c[3]; v3add(c, o[6], rc); v3sub(rs, c, k->x); v3cross(t1, rs, F);
+    real tw[3];
+    for (int a = 0; a < 3; a++) tw[a] = N[a] + t1[a] - contact_torque[a];
+    m3tmulv(out, k->Rs, tw);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * quaternion helpers  (src/utils/quaternion.py; robosuite transform_utils.mat2quat [RESTATED])
+ * ---------------------------------------------------------------------------------------------- */
+static void mat2quat_xyzw(const real* R, real* q) {
+    /* robosuite T.mat2quat returns the unit quaternion of R with w >= 0 (eigenvector of the K matrix, then
+     * `if q1[0] < 0: negate`), as (x,y,z,w).  Restated with Shepperd's method + the same sign rule. */
+    real m00 = R[0], m01 = R[1], m02 = R[2], m10 = R[3], m11 = R[4], m12 = R[5], m20 = R[6], m21 = R[7], m22 = R[8];
+    real tr = m00 + m11 + m22, w, x, y, z;
+    if (tr > 0) { real s = (real)sqrt((double)(tr + 1)) * 2; w = s / 4; x = (m21 - m12) / s; y = (m02 - m20) / s; z = (m10 - m01) / s; }
+    else if (m00 > m11 && m00 > m22) { real s = (real)sqrt((double)(1 + m00 - m11 - m22)) * 2; w = (m21 - m12) / s; x = s / 4; y = (m01 + m10) / s; z = (m02 + m20) / s; }
+    else if (m11 > m22) { real s = (real)sqrt((double)(1 + m11 - m00 - m22)) * 2; w = (m02 - m20) / s; x = (m01 + m10) / s; y = s / 4; z = (m12 + m21) / s; }
+    else { real s = (real)sqrt((double)(1 + m22 - m00 - m11)) * 2; w = (m10 - m01) / s; x = (m02 + m20) / s; y = (m12 + m21) / s; z = s / 4; }
+    if (w < 0) { w = -w; x = -x; y = -y; z = -z; }
+    q[0] = x; q[1] = y; q[2] = z; q[3] = w;
+}
+/* transforms3d qmult(a, qconjugate(b)) on 4-vectors whose index 0 is treated as the scalar (quaternion.py:23-35) */
+static void difference_quat(const real* a, const real* b, real* o) {
+    real bw = b[0], bx = -b[1], by = -b[2], bz = -b[3];
+    o[0] = a[0] * bw - a[1] * bx - a[2] * by - a[3] * bz;
+    o[1] = a[0] * bx + a[1] * bw + a[2] * bz - a[3] * by;
+    o[2] = a[0] * by - a[1] * bz + a[2] * bw + a[3] * bx;
+    o[3] = a[0] * bz + a[1] * by - a[2] * bx + a[3] * bw;
+}
+/* distance_quat (quaternion.py:38-59) with q_log (quaternion.py:4-20); arguments are (w,x,y,z) */
+static real distance_quat(const real* q1, const real* q2) {
+    real qm[4]; difference_quat(q1, q2, qm);
+    real v = qm[0]; if (v > 1) v = 1; if (v < -1) v = -1;        /* np.clip(q[0], -1, 1) :14 */
+    real un = (real)sqrt((double)(qm[1] * qm[1] + qm[2] * qm[2] + qm[3] * qm[3]));
+    real ln = (un == 0) ? 0 : (real)acos((double)v);               /* |arccos(v) u/|u|| = arccos(v) :17-20 */
+    real dist = 2 * ln;                                            /* :54 */
+    if (dist > (real)PI) dist = (real)fabs((double)(2 * (real)PI - dist));   /* :56-57 */
+    return dist;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * env-level logic (ultrasound.py)
+ * ---------------------------------------------------------------------------------------------- */
+static void traj_eval(const Sim* S, const Env* E, int t, real* pt) {
+    /* ultrasound.py:528-532: traj_step = t/(horizon/(num_waypoints-1)) + u0, klampt linear Trajectory with
+     * 'halt' end behaviour [RESTATED]: clamp to [0, 1] */
+    real u = (real)t / (real)S->cfg.horizon + E->u0;
+    if (u < 0) u = 0;
+    if (u > 1) u = 1;
+    for (int a = 0; a < 3; a++) pt[a] = E->traj_start[a] + u * (E->traj_end[a] - E->traj_start[a]);
+}
+
+static void make_obs(const Sim* S, const Env* E, const KinDyn* k, const Fwd* f, const real* tq, const real* hand_vel,
+                     const real* traj_pt_world, real* obs) {
+    /* ultrasound.py:363-401, order :394-401 */
+    for (int a = 0; a < 3; a++) { obs[a] = f->fc[a]; obs[3 + a] = tq[a]; obs[6 + a] = hand_vel[a]; }
+    obs[9] = E->fzbar - (real)GOAL_FORCE;          /* :376-377 */
+    obs[10] = E->dfz - (real)GOAL_DFORCE;          /* :380-381 */
+    obs[11] = E->vbar - (real)GOAL_VELOCITY;       /* :384-385 */
+    for (int a = 0; a < 3; a++) obs[12 + a] = k->x[a] + (real)BASE_WORLD[a] - traj_pt_world[a];   /* :389 */
+    real qe[4], qg[4] = {(real)GOAL_QUAT_XYZW[0], (real)GOAL_QUAT_XYZW[1], (real)GOAL_QUAT_XYZW[2], (real)GOAL_QUAT_XYZW[3]};
+    mat2quat_xyzw(k->Rs, qe);
+    difference_quat(qe, qg, obs + 15);             /* :390 -- xyzw arrays through a wxyz routine, reproduced literally */
+    (void)S;
+}
+
+/* full forward pass at the current state: controller (or zero torque), constrained dynamics, sensors */
+typedef struct { KinDyn k; Fwd f; real tau[NJ]; real tq[3]; } Pass;
+
+static void forward_pass(const Sim* S, const Env* E, const real* act, int zero_torque, Pass* P) {
+    const uso_config* c = &S->cfg;
+    kin_dyn(&S->m, E->q, E->qd, &P->k);
+    if (zero_torque) { for (int i = 0; i < NJ; i++) P->tau[i] = 0; }
+    else {
+        real kp[6], kd[6], gpos[3], grot[9], tp[3];
+        traj_eval(S, E, E->t - 1, tp);      /* controller.traj_pos was set by the previous _post_action / reset (:455,:535) */
+        if (c->mode == USO_MODE_FIXED) {
+            /* robosuite OSC set_goal, impedance_mode "fixed", control_delta: goal = current pose + scaled delta */
+            real d[6];
+            for (int a = 0; a < 6; a++) { real v = act[a]; if (v > 1) v = 1; if (v < -1) v = -1; d[a] = v * (real)(a < 3 ? c->out_max_pos : c->out_max_ori); }
+            for (int a = 0; a < 3; a++) gpos[a] = P->k.x[a] + d[a];
+            real ang = (real)sqrt((double)(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]));
+            if (ang < (real)1e-12) memcpy(grot, P->k.Rs, sizeof grot);
+            else {
+                double h = 0.5 * (double)ang, sh = sin(h) / (double)ang;
+                double qq[4] = {cos(h), d[3] * sh, d[4] * sh, d[5] * sh};
+                real Re[9]; quat_wxyz_to_mat(Re, qq); m3mul(grot, Re, P->k.Rs);
+            }
+            for (int a = 0; a < 6; a++) { kp[a] = (real)c->kp_fixed; kd[a] = (real)(2.0 * sqrt(c->kp_fixed) * c->damping_ratio); }
+        } else {
+            /* fork-only "tracking"/"variable_z" (SURVEY C.3): action -> kp in kp_limits, kd = 2 sqrt(kp), goal = trajectory */
+            for (int a = 0; a < 6; a++) {
+                real v = act[a]; if (v > 1) v = 1; if (v < 0) v = 0;
+                kp[a] = (real)c->kp_min + v * (real)(c->kp_max - c->kp_min);
+                kd[a] = 2 * (real)sqrt((double)kp[a]) * (real)c->damping_ratio;
+            }
+            for (int a = 0; a < 3; a++) gpos[a] = tp[a] - (real)BASE_WORLD[a];
+            if (c->mode == USO_MODE_VARIABLE_Z) { real v = act[6]; if (v > 1) v = 1; if (v < -1) v = -1; gpos[2] += v * (real)c->out_max_pos; }
+            memcpy(grot, S->m.goal_rot, sizeof grot);
+        }
+        osc_torque(S, &P->k, E->q, E->qd, E->q0, gpos, grot, kp, kd, P->tau);
+    }
+    constrained_forward(S, E, &P->k, P->tau, &P->f);
+    torque_sensor(S, E, &P->k, P->f.qacc, P->f.tq_sensor, P->tq);
+}
+
+static void reset_env(Sim* S, int i, const double* ex /* explicit draws or NULL */, double* obs_out) {
+    Env* E = &S->env[i];
+    const uso_config* c = &S->cfg;
+    const Model* m = &S->m;
+    int episode = E->episode + 1;
+    uint32_t A[4], B[4], C[4];
+    uint32_t gid = (uint32_t)(c->env_offset + i), k0 = (uint32_t)c->seed, k1 = (uint32_t)(c->seed >> 32);
+    philox4x32(gid, (uint32_t)episode, 0, 0, k0, k1, A);
+    philox4x32(gid, (uint32_t)episode, 1, 0, k0, k1, B);
+    philox4x32(gid, (uint32_t)episode, 2, 0, k0, k1, C);
+    double start[3], end[3], u0, noise[3] = {0, 0, 0}, stiff = c->stiffness, damp = c->damping, mu;
+    double tz = TORSO_WORLD[2] + TOP_TORSO_OFFSET;
+    if (ex) {
+        for (int a = 0; a < 3; a++) { start[a] = ex[a]; end[a] = ex[3 + a]; noise[a] = ex[7 + a]; }
+        u0 = ex[6]; stiff = ex[10]; damp = ex[11]; mu = ex[12];
+    } else {
+        if (c->deterministic_trajectory) {    /* ultrasound.py:762-764 */
+            start[0] = 0.062; start[1] = -0.020; start[2] = 0.896; end[0] = -0.032; end[1] = -0.075; end[2] = 0.896;
+        } else {                               /* ultrasound.py:778-809: np.linspace grids, np.random.choice */
+            double xs = (-X_RANGE + TORSO_WORLD[0] + 0.03), xstep = (X_RANGE + TORSO_WORLD[0] - xs) / (GRID_PTS - 1);
+            double ys = (-Y_RANGE + TORSO_WORLD[1]), ystep = (2 * Y_RANGE) / (GRID_PTS - 1);
+            start[0] = xs + urange(A[0], GRID_PTS) * xstep; start[1] = ys + urange(A[1], GRID_PTS) * ystep; start[2] = tz;
+            end[0] = xs + urange(A[2], GRID_PTS) * xstep; end[1] = ys + urange(A[3], GRID_PTS) * ystep; end[2] = tz;
+        }
+        u0 = u01(B[0]);                        /* ultrasound.py:443 (unseeded there; seeded stream here) */
+        if (c->initial_probe_pos_randomization) {   /* ultrasound.py:880-881 */
+            double r1 = sqrt(-2.0 * log(u01_open(B[1]))), th1 = 2.0 * PI * u01(B[2]);
+            double r2 = sqrt(-2.0 * log(u01_open(B[3]))), th2 = 2.0 * PI * u01(C[0]);
+            noise[0] = r1 * cos(th1) * NOISE_SIGMA / 4; noise[1] = r1 * sin(th1) * NOISE_SIGMA / 4; noise[2] = r2 * cos(th2) * NOISE_SIGMA;
+        }
+        if (c->torso_solref_randomization) {   /* ultrasound.py:293-294: randint(1300,1600), randint(17,41) */
+            stiff = 1300 + urange(C[1], 300); damp = 17 + urange(C[2], 24);
+        }
+        double pf = c->probe_friction;
+        if (c->friction_randomization) pf *= 0.5 + 1.5 * u01(C[3]);
+        mu = pf > c->elem_friction ? pf : c->elem_friction;   /* MuJoCo contact friction = max of the two geoms [RESTATED] */
+    }
+    memset(E, 0, sizeof *E);
+    E->episode = episode;
+    for (int a = 0; a < 3; a++) { E->traj_start[a] = (real)start[a]; E->traj_end[a] = (real)end[a]; }
+    E->u0 = (real)u0; E->kt_stiff = (real)stiff; E->kt_damp = (real)damp; E->mu = (real)mu;
+    E->has_touched = 0;                       /* ultrasound.py:434 */
+    /* initial pose: IK to (traj_pt + noise, goal_quat) from init_qpos (ultrasound.py:812-844).  The
+     * reference runs roboticstoolbox ikine_min on a DH Panda with empirical offsets; the net effect seen in
+     * the decoded fixtures is eef = target + INIT_POS_BIAS.  Restated as fixed-count damped least squares. */
+    real tp[3], target[3];
+    traj_eval(S, E, 0, tp);
+    for (int a = 0; a < 3; a++) target[a] = tp[a] + (real)(noise[a] + INIT_POS_BIAS[a] - BASE_WORLD[a]);
+    real q[NJ]; for (int j = 0; j < NJ; j++) q[j] = (real)INIT_QPOS[j];
+    for (int it = 0; it < c->ik_iters; it++) {
+        real o[NJ][3], R[NJ][9], x[3], Rs[9], t[3], J[6][NJ], e[6];
+        fk_all(m, q, o, R);
+        m3mulv(t, R[6], m->site_pos7); v3add(x, o[6], t); m3mul(Rs, R[6], m->site_rot7);
+        for (int j = 0; j < NJ; j++) { real z[3] = {R[j][2], R[j][5], R[j][8]}, r[3], cx[3]; v3sub(r, x, o[j]); v3cross(cx, z, r); for (int a = 0; a < 3; a++) { J[a][j] = cx[a]; J[3 + a][j] = z[a]; } }
+        for (int a = 0; a < 3; a++) e[a] = target[a] - x[a];
+        e[3] = e[4] = e[5] = 0;
+        for (int cc = 0; cc < 3; cc++) { real rc[3] = {Rs[cc], Rs[3 + cc], Rs[6 + cc]}, rd[3] = {m->goal_rot[cc], m->goal_rot[3 + cc], m->goal_rot[6 + cc]}, xx[3]; v3cross(xx, rc, rd); for (int a = 0; a < 3; a++) e[3 + a] += (real)0.5 * xx[a]; }
+        real A6[36];
+        for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) { real s = (a == b) ? (real)1e-6 : 0; for (int j = 0; j < NJ; j++) s += J[a][j] * J[b][j]; A6[a * 6 + b] = s; }
+        chol(A6, 6); chol_solve(A6, 6, e);
+        for (int j = 0; j < NJ; j++) { real s = 0; for (int a = 0; a < 6; a++) s += J[a][j] * e[a]; q[j] += s; }
+    }
+    for (int j = 0; j < NJ; j++) { E->q[j] = q[j]; E->q0[j] = q[j]; E->qd[j] = 0; }   /* :462-465 */
+    E->t = 0; E->fzprev = 0; E->dfz = 0; E->ep_return = 0;   /* :468-471 */
+    /* sim.forward() with zero ctrl -> initial contact force, running means (:474-477) */
+    Pass P; forward_pass(S, E, 0, 1, &P);
+    real hv[3] = {0, 0, 0};
+    E->vbar = 0;                              /* |hand_vel| with qvel = 0 */
+    E->fzbar = P.f.fc[2];
+    E->ncon = P.f.ncon; for (int cix = 0; cix < P.f.ncon; cix++) E->con_el[cix] = m->el_shell_id[P.f.con_el[cix]];
+    if (obs_out) {
+        real ob[USO_OBS_DIM], tpw[3]; traj_eval(S, E, 0, tpw);
+        make_obs(S, E, &P.k, &P.f, P.tq, hv, tpw, ob);
+        for (int a = 0; a < USO_OBS_DIM; a++) obs_out[a] = (double)ob[a];
+    }
+}
+
+static void step_env(Sim* S, int i, const double* act_d, double* obs, double* rew, uint8_t* done_out, double* term_obs,
+                     int32_t* contacts, int auto_reset) {
+    Env* E = &S->env[i];
+    const uso_config* c = &S->cfg;
+    const Model* m = &S->m;
+    const real dt = (real)c->control_dt;
+    real act[8]; for (int a = 0; a < S->adim; a++) act[a] = (real)act_d[a];
+    E->t += 1;                                             /* MujocoEnv.step: timestep += 1 [RESTATED, SURVEY C.1] */
+    Pass P; forward_pass(S, E, act, 0, &P);
+    /* mj_Euler with implicit joint damping [RESTATED]: qd += dt (M + dt D)^-1 M qacc ; q += dt qd */
+    real Md[NJ * NJ], rhs[NJ];
+    for (int a = 0; a < NJ; a++) { real s = 0; for (int b = 0; b < NJ; b++) s += P.k.M[a * NJ + b] * P.f.qacc[b]; rhs[a] = s; }
+    memcpy(Md, P.k.M, sizeof Md);
+    for (int a = 0; a < NJ; a++) Md[a * NJ + a] += dt * (real)JOINT_DAMPING;
+    chol(Md, NJ); chol_solve(Md, NJ, rhs);
+    for (int a = 0; a < NJ; a++) { E->qd[a] += dt * rhs[a]; E->q[a] += dt * E->qd[a]; }
+    for (int e = 0; e < m->n_el; e++) { E->sd[e] += dt * P.f.ael[e]; E->s[e] += dt * E->sd[e]; }
+    /* sensors read mj_step's data: kinematics/contacts from before the integration, qvel from after
+     * (SURVEY C.4 "after mj_step, cfrc_ext/contacts describe the pre-integration state") */
+    real hv[3], vs[6];
+    for (int a = 0; a < 6; a++) { real s = 0; for (int j = 0; j < NJ; j++) s += P.k.J[a][j] * E->qd[j]; vs[a] = s; }
+    { real r[3], cx[3]; v3sub(r, P.k.hand, P.k.x); v3cross(cx, vs + 3, r); for (int a = 0; a < 3; a++) hv[a] = vs[a] + cx[a]; }   /* robosuite _hand_vel = Jp(right_hand) qvel */
+    real tp_prev[3]; traj_eval(S, E, E->t - 1, tp_prev);
+    real ob[USO_OBS_DIM];
+    make_obs(S, E, &P.k, &P.f, P.tq, hv, tp_prev, ob);
+    /* reward (ultrasound.py:230-269), evaluated inside super()._post_action before the bookkeeping below */
+    int contact = P.f.ncon > 0;                            /* _check_probe_contact_with_torso :714-736 */
+    if (contact) E->has_touched = 1;                       /* :733 */
+    real xw[3]; for (int a = 0; a < 3; a++) xw[a] = P.k.x[a] + (real)BASE_WORLD[a];
+    real pe0 = (real)POS_ERR_MUL * (xw[0] - tp_prev[0]), pe1 = (real)POS_ERR_MUL * (xw[1] - tp_prev[1]);
+    pe0 *= pe0; pe1 *= pe1;                                /* :247 np.square */
+    real pos_err_norm = (real)sqrt((double)(pe0 * pe0 + pe1 * pe1));
+    real pos_rew = (real)POS_REW_MUL * (real)exp(-(double)pos_err_norm);            /* :248 */
+    real qe[4]; mat2quat_xyzw(P.k.Rs, qe);
+    real qc[4] = {qe[3], qe[0], qe[1], qe[2]};              /* convert_quat(to="wxyz") :243 */
+    real qg[4] = {(real)GOAL_QUAT_XYZW[3], (real)GOAL_QUAT_XYZW[0], (real)GOAL_QUAT_XYZW[1], (real)GOAL_QUAT_XYZW[2]};
+    real ori_err = (real)ORI_ERR_MUL * distance_quat(qc, qg);                        /* :251 */
+    real ori_rew = (real)ORI_REW_MUL * (real)exp(-(double)ori_err);                 /* :252 */
+    real ve = (real)VEL_ERR_MUL * (E->vbar - (real)GOAL_VELOCITY); ve *= ve;         /* :255 */
+    real vel_rew = (real)VEL_REW_MUL * (real)exp(-(double)ve);                      /* :256 */
+    real fe = (real)FORCE_ERR_MUL * (E->fzbar - (real)GOAL_FORCE); fe *= fe;         /* :259 */
+    real force_rew = contact ? (real)FORCE_REW_MUL * (real)exp(-(double)fe) : 0;    /* :260 */
+    real de = (real)DFORCE_ERR_MUL * (E->dfz - (real)GOAL_DFORCE); de *= de;         /* :263 */
+    real dforce_rew = contact ? (real)DFORCE_REW_MUL * (real)exp(-(double)de) : 0;  /* :264 */
+    real reward = pos_rew + ori_rew + vel_rew + force_rew + dforce_rew;              /* :267 */
+    int done = (E->t >= c->horizon);                       /* base _post_action [RESTATED] */
+    /* bookkeeping (ultrasound.py:528-546) */
+    real hvn = v3norm(hv);
+    E->vbar += (hvn - E->vbar) / (real)E->t;               /* :538 */
+    real fz = P.f.fc[2];
+    E->dfz = (fz - E->fzprev) / dt;                        /* :542 */
+    E->fzprev = fz;                                        /* :543 */
+    E->fzbar = (real)FORCE_EMA_ALPHA * fz + (1 - (real)FORCE_EMA_ALPHA) * E->fzbar;   /* :546 */
+    if (c->early_termination) {                            /* :549-550 -> :635-670 */
+        int term = 0;
+        for (int j = 0; j < NJ; j++) if (E->q[j] < (real)(Q_MIN[j] + QLIM_TOL) || E->q[j] > (real)(Q_MAX[j] - QLIM_TOL)) term = 1;   /* :651 */
+        if (pos_err_norm > (real)POS_ERR_THRESH) term = 1;                           /* :656 */
+        if (contact && ori_err > (real)ORI_ERR_THRESH) term = 1;                     /* :661 */
+        if (E->has_touched && !contact) term = 1;                                    /* :666 */
+        done = done || term;
+    }
+    E->ep_return += reward;
+    E->ncon = P.f.ncon; for (int cix = 0; cix < P.f.ncon; cix++) E->con_el[cix] = m->el_shell_id[P.f.con_el[cix]];
+    if (P.f.overflow) E->status |= 1;
+    if (contacts) { contacts[0] = P.f.ncon; for (int cix = 0; cix < USO_MAXC; cix++) contacts[1 + cix] = cix < P.f.ncon ? E->con_el[cix] : -1; }
+    if (rew) *rew = (double)reward;
+    if (done_out) *done_out = (uint8_t)done;
+    if (term_obs) for (int a = 0; a < USO_OBS_DIM; a++) term_obs[a] = (double)ob[a];
+    if (obs) for (int a = 0; a < USO_OBS_DIM; a++) obs[a] = (double)ob[a];
+    if (done && auto_reset) reset_env(S, i, 0, obs);       /* SB3 VecEnv: obs of a finished env is its reset obs */
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * C interface
+ * ---------------------------------------------------------------------------------------------- */
+void uso_default_config(uso_config* c) {
+    memset(c, 0, sizeof *c);
+    c->mode = USO_MODE_TRACKING; c->torso = USO_TORSO_TOP; c->horizon = 1000; c->early_termination = 1;
+    c->deterministic_trajectory = 0; c->torso_solref_randomization = 1; c->initial_probe_pos_randomization = 1;
+    c->friction_randomization = 0; c->torso_drop = 1; c->pgs_iters = 10; c->ik_iters = 8; c->env_offset = 0;
+    c->seed = 3; c->control_dt = 0.002; c->kp_fixed = 300; c->damping_ratio = 1; c->kp_min = 0; c->kp_max = 500;
+    c->out_max_pos = 0.05; c->out_max_ori = 0.5; c->stiffness = 1324.17; c->damping = 17.59;
+    c->elem_friction = 0.01; c->probe_friction = 1e-4;
+    c->probe_radius = PROBE_RADIUS; c->probe_halflen = PROBE_HALFLEN;
+}
+void* uso_create(const uso_config* c, int n) {
+    Sim* S = (Sim*)calloc(1, sizeof(Sim));
+    S->cfg = *c; S->n = n; S->adim = (c->mode == USO_MODE_VARIABLE_Z) ? 7 : 6;
+    build_model(S);
+    S->env = (Env*)calloc((size_t)n, sizeof(Env));
+    return S;
+}
+void uso_destroy(void* h) { Sim* S = (Sim*)h; if (!S) return; free(S->m.lat_L); free(S->m.lat_Linv); free(S->env); free(S); }
+int uso_action_dim(void* h) { return ((Sim*)h)->adim; }
+int uso_num_elements(void* h) { return ((Sim*)h)->m.n_el; }
+int uso_shell_edges(void* h) { return ((Sim*)h)->m.n_shell_edges; }
+double uso_contact_invweight(void* h) { return (double)((Sim*)h)->m.invw_contact; }
+
+int uso_reset(void* h, const uint8_t* mask, double* obs_out) {
+    Sim* S = (Sim*)h;
+    for (int i = 0; i < S->n; i++) if (!mask || mask[i]) reset_env(S, i, 0, obs_out ? obs_out + (size_t)i * USO_OBS_DIM : 0);
+    return 0;
+}
+int uso_reset_explicit(void* h, const uint8_t* mask, const double* params, double* obs_out) {
+    Sim* S = (Sim*)h;
+    for (int i = 0; i < S->n; i++) if (!mask || mask[i]) reset_env(S, i, params + (size_t)i * 13, obs_out ? obs_out + (size_t)i * USO_OBS_DIM : 0);
+    return 0;
+}
+int uso_step(void* h, const double* act, double* obs, double* rew, uint8_t* done, double* term_obs, int32_t* contacts, int auto_reset) {
+    Sim* S = (Sim*)h;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int i = 0; i < S->n; i++)
+        step_env(S, i, act + (size_t)i * S->adim, obs ? obs + (size_t)i * USO_OBS_DIM : 0, rew ? rew + i : 0, done ? done + i : 0,
+                 term_obs ? term_obs + (size_t)i * USO_OBS_DIM : 0, contacts ? contacts + (size_t)i * (1 + USO_MAXC) : 0, auto_reset);
+    return 0;
+}
+/* scalar layout: q[0..6] qd[7..13] q0[14..20] traj_start[21..23] traj_end[24..26] u0[27] vbar[28] fzbar[29]
+ * fzprev[30] dfz[31] stiffness[32] damping[33] mu[34] t[35] has_touched[36] episode[37] ep_return[38] status[39] */
+int uso_get_state(void* h, double* sc, double* lat) {
+    Sim* S = (Sim*)h; int n_el = S->m.n_el;
+    for (int i = 0; i < S->n; i++) {
+        const Env* E = &S->env[i]; double* o = sc + (size_t)i * USO_NSCALAR;
+        for (int j = 0; j < NJ; j++) { o[j] = E->q[j]; o[7 + j] = E->qd[j]; o[14 + j] = E->q0[j]; }
+        for (int a = 0; a < 3; a++) { o[21 + a] = E->traj_start[a]; o[24 + a] = E->traj_end[a]; }
+        o[27] = E->u0; o[28] = E->vbar; o[29] = E->fzbar; o[30] = E->fzprev; o[31] = E->dfz; o[32] = E->kt_stiff; o[33] = E->kt_damp; o[34] = E->mu;
+        o[35] = E->t; o[36] = E->has_touched; o[37] = E->episode; o[38] = E->ep_return; o[39] = E->status;
+        if (lat) for (int e = 0; e < n_el; e++) { lat[((size_t)i * n_el + e) * 2] = E->s[e]; lat[((size_t)i * n_el + e) * 2 + 1] = E->sd[e]; }
+    }
+    return 0;
+}
+int uso_set_state(void* h, const double* sc, const double* lat) {
+    Sim* S = (Sim*)h; int n_el = S->m.n_el;
+    for (int i = 0; i < S->n; i++) {
+        Env* E = &S->env[i]; const double* o = sc + (size_t)i * USO_NSCALAR;
+        for (int j = 0; j < NJ; j++) { E->q[j] = (real)o[j]; E->qd[j] = (real)o[7 + j]; E->q0[j] = (real)o[14 + j]; }
+        for (int a = 0; a < 3; a++) { E->traj_start[a] = (real)o[21 + a]; E->traj_end[a] = (real)o[24 + a]; }
+        E->u0 = (real)o[27]; E->vbar = (real)o[28]; E->fzbar = (real)o[29]; E->fzprev = (real)o[30]; E->dfz = (real)o[31];
+        E->kt_stiff = (real)o[32]; E->kt_damp = (real)o[33]; E->mu = (real)o[34];
+        E->t = (int)o[35]; E->has_touched = (int)o[36]; E->episode = (int)o[37]; E->ep_return = (real)o[38]; E->status = (int)o[39];
+        if (lat) for (int e = 0; e < n_el; e++) { E->s[e] = (real)lat[((size_t)i * n_el + e) * 2]; E->sd[e] = (real)lat[((size_t)i * n_el + e) * 2 + 1]; }
+    }
+    return 0;
+}
+int uso_random_actions(void* h, int64_t step, double* act) {
+    Sim* S = (Sim*)h; const uso_config* c = &S->cfg;
+    uint32_t k0 = (uint32_t)c->seed, k1 = (uint32_t)(c->seed >> 32);
+    for (int i = 0; i < S->n; i++) {
+        uint32_t r[8];
+        philox4x32((uint32_t)(c->env_offset + i), (uint32_t)step, (uint32_t)((uint64_t)step >> 32), 1, k0, k1, r);
+        philox4x32((uint32_t)(c->env_offset + i), (uint32_t)step, (uint32_t)((uint64_t)step >> 32), 2, k0, k1, r + 4);
+        for (int a = 0; a < S->adim; a++) {
+            double u = u01(r[a]);
+            int signedbox = (c->mode == USO_MODE_FIXED) || (c->mode == USO_MODE_VARIABLE_Z && a == 6);
+            act[(size_t)i * S->adim + a] = signedbox ? 2.0 * u - 1.0 : u;
+        }
+    }
+    return 0;
+}
+int uso_debug_forward(void* h, int env, double* out) {
+    Sim* S = (Sim*)h; Env* E = &S->env[env];
+    Pass P; forward_pass(S, E, 0, 1, &P);
+    for (int a = 0; a < 3; a++) out[a] = (double)P.k.x[a] + BASE_WORLD[a];
+    for (int a = 0; a < 9; a++) out[3 + a] = (double)P.k.Rs[a];
+    for (int a = 0; a < 49; a++) out[12 + a] = (double)P.k.M[a];
+    for (int a = 0; a < 7; a++) out[61 + a] = (double)P.k.bias[a];
+    for (int a = 0; a < 6; a++) for (int j = 0; j < NJ; j++) out[68 + a * NJ + j] = (double)P.k.J[a][j];
+    for (int a = 0; a < 3; a++) { out[110 + a] = (double)P.f.fc[a]; out[113 + a] = (double)P.tq[a]; }
+    out[116] = (double)P.f.ncon; out[117] = (double)P.f.min_margin;
+    for (int j = 0; j < NJ; j++) out[118 + j] = (double)P.f.qacc[j];
+    return 0;
+}
+/* standalone helpers exported for known-answer tests of the env-level formulas */
+double uso_distance_quat(const double* q1_wxyz, const double* q2_wxyz) {
+    real a[4], b[4]; for (int i = 0; i < 4; i++) { a[i] = (real)q1_wxyz[i]; b[i] = (real)q2_wxyz[i]; }
+    return (double)distance_quat(a, b);
+}
+void uso_difference_quat(const double* a_, const double* b_, double* o_) {
+    real a[4], b[4], o[4]; for (int i = 0; i < 4; i++) { a[i] = (real)a_[i]; b[i] = (real)b_[i]; }
+    difference_quat(a, b, o); for (int i = 0; i < 4; i++) o_[i] = (double)o[i];
+}
+void uso_mat2quat(const double* R_, double* q_) {
+    real R[9], q[4]; for (int i = 0; i < 9; i++) R[i] = (real)R_[i];
+    mat2quat_xyzw(R, q); for (int i = 0; i < 4; i++) q_[i] = (double)q[i];
+}
+void uso_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) { philox4x32(c0, c1, c2, c3, k0, k1, out); }

@@ -1,0 +1,102 @@
+/*
+ * usim_oracle.h -- C interface of the CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * The oracle is a plain-C, scalar, one-environment-at-a-time restatement of the reference's
+ * Ultrasound env.step()/reset() hot path.  It exists so that
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg can check / time the HIP path
+ * against an independently written implementation.  Nothing under robotic-ultrasound-imaging_amd/
+ * may include, link or dlopen it.
+ *
+ * PARITY STATUS: "parity unpinned" at the MuJoCo boundary.  The reference's arithmetic lives in
+ * un-vendored dependencies (MuJoCo 2.0 binary, mujoco-py, robosuite fork) that can
+ * be neither compiled nor imported here, and the reference ships no tests or golden trajectories.
+ * What IS pinned: the env-level formulas that live in /root/reference/src (reward, observation
+ * layout, bookkeeping, termination, quaternion helpers, trajectory/reset sampling) and the decoded
+ * checkpoint data in tests/golden/reference_pins.npz (reset observations, force-depth line).
+ *
+ * Built twice from the same source: -DREAL=double (libusim_oracle_f64.so, the checker) and
+ * -DREAL=float (libusim_oracle_f32.so, used to separate precision effects from logic errors).
+ */
+#ifndef USIM_ORACLE_H
+#define USIM_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define USO_OBS_DIM 19
+#define USO_MAXC 8          /* contact slots per env */
+#define USO_NSCALAR 40      /* scalar state words per env exported by uso_get_state */
+
+/* impedance_mode of the OSC controller (rl_config.yaml:41, main.py:33, utils/plot.py:203-211,303-313) */
+enum { USO_MODE_TRACKING = 0, USO_MODE_FIXED = 1, USO_MODE_VARIABLE_Z = 2 };
+/* torso model: 0 = rigid/absent (BASELINE config #2), 1 = 99 top-face elements dynamic (config #3) */
+enum { USO_TORSO_NONE = 0, USO_TORSO_TOP = 1 };
+
+typedef struct uso_config {
+    int32_t mode;                 /* USO_MODE_* */
+    int32_t torso;                /* USO_TORSO_* */
+    int32_t horizon;              /* rl_config.yaml:27 (1000) */
+    int32_t early_termination;    /* rl_config.yaml:52 */
+    int32_t deterministic_trajectory;        /* rl_config.yaml:54, ultrasound.py:762-764 */
+    int32_t torso_solref_randomization;      /* rl_config.yaml:55, ultrasound.py:291-297 */
+    int32_t initial_probe_pos_randomization; /* rl_config.yaml:56, ultrasound.py:870-887 */
+    int32_t friction_randomization;          /* BASELINE config #5 (new knob) */
+    int32_t torso_drop;           /* 1: torso base follows the 4.7 mm free-fall of ultrasound.py:313 */
+    int32_t pgs_iters;            /* fixed contact-PGS sweep count */
+    int32_t ik_iters;             /* fixed reset-IK iteration count */
+    int32_t env_offset;           /* global index of env 0 (multi-GPU shards) */
+    uint64_t seed;                /* rl_config.yaml:1 */
+    double control_dt;            /* 1/control_freq = 0.002 (rl_config.yaml:26) */
+    double kp_fixed;              /* rl_config.yaml:38 / main.py:31 */
+    double damping_ratio;         /* rl_config.yaml:39 */
+    double kp_min, kp_max;        /* kp_limits rl_config.yaml:42 */
+    double out_max_pos, out_max_ori;   /* output_max rl_config.yaml:36 */
+    double stiffness, damping;    /* soft_box.xml:9 solrefsmooth (1324.17, 17.59) */
+    double elem_friction;         /* soft_box.xml:10 (0.01) */
+    double probe_friction;        /* ultrasound_probe_gripper.xml:8 (1e-4) */
+    double probe_radius, probe_halflen;   /* stand-in capsule for the missing probe mesh (.MISSING_LARGE_BLOBS:1) */
+} uso_config;
+
+void  uso_default_config(uso_config* c);
+void* uso_create(const uso_config* c, int n_envs);
+void  uso_destroy(void* h);
+int   uso_action_dim(void* h);
+int   uso_num_elements(void* h);           /* dynamic torso elements (0 or 99) */
+
+/* All array I/O below is double precision regardless of REAL; the f32 build casts on entry/exit. */
+
+/* reset envs where mask[i]!=0 (mask NULL = all).  Draws come from the counter-based stream keyed
+ * (seed, env_offset+i, episode index).  obs_out (n x 19, may be NULL) gets the reset observation. */
+int uso_reset(void* h, const uint8_t* mask, double* obs_out);
+
+/* reset with explicit per-env draws instead of the RNG stream, params[i] =
+ * {start xyz, end xyz, u0, noise xyz, stiffness, damping, mu} (13 doubles, world coordinates). */
+int uso_reset_explicit(void* h, const uint8_t* mask, const double* params, double* obs_out);
+
+/* one env.step() for every env.  act: n x A.  Outputs (any may be NULL):
+ *   obs n x 19 (already the reset observation where done, SB3 VecEnv semantics),
+ *   rew n, done n, term_obs n x 19 (pre-reset observation; valid where done),
+ *   contacts n x (1+USO_MAXC) int32: count then ascending shell-element ids of probe<->element pairs.
+ * auto_reset!=0 applies the VecEnv auto-reset; 0 leaves finished envs frozen for inspection. */
+int uso_step(void* h, const double* act, double* obs, double* rew, uint8_t* done,
+             double* term_obs, int32_t* contacts, int auto_reset);
+
+/* scalar state n x USO_NSCALAR (layout in usim_oracle.c: uso_get_state) + lattice n x E x 2 (s, sdot) */
+int uso_get_state(void* h, double* scalars, double* lattice);
+int uso_set_state(void* h, const double* scalars, const double* lattice);
+
+/* counter-based synthetic actions for rollout step `step`: n x A uniform in the
+ * action box, keyed (seed, env_offset+i, step). */
+int uso_random_actions(void* h, int64_t step, double* act);
+
+/* diagnostics for unit tests: per-env forward quantities at the current state with zero torque
+ * out[0..2] eef pos (world), [3..11] eef rotmat row-major, [12..60] M 7x7, [61..67] bias,
+ * [68..109] J 6x7 (site, world axes), [110..112] contact force on probe, [113..115] ee torque sensor */
+int uso_debug_forward(void* h, int env, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,164 @@
+"""ctypes binding of the CPU oracle (oracle/usim_oracle.c).  TEST INFRASTRUCTURE: importable only from
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+ORACLE_DIR = ROOT / "oracle"
+OBS_DIM, MAXC, NSCALAR = 19, 8, 40
+MODE = {"tracking": 0, "fixed": 1, "variable_z": 2}
+TORSO = {"none": 0, "top": 1}
+
+SCALAR_FIELDS = {  # name -> slice in the uso_get_state scalar block
+    "q": slice(0, 7), "qd": slice(7, 14), "q0": slice(14, 21), "traj_start": slice(21, 24), "traj_end": slice(24, 27),
+    "u0": 27, "vbar": 28, "fzbar": 29, "fzprev": 30, "dfz": 31, "stiffness": 32, "damping": 33, "mu": 34,
+    "t": 35, "has_touched": 36, "episode": 37, "ep_return": 38, "status": 39,
+}
+
+
+class OracleConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "mode", "torso", "horizon", "early_termination", "deterministic_trajectory", "torso_solref_randomization",
+        "initial_probe_pos_randomization", "friction_randomization", "torso_drop", "pgs_iters", "ik_iters", "env_offset")] + \
+        [("seed", C.c_uint64)] + [(n, C.c_double) for n in (
+            "control_dt", "kp_fixed", "damping_ratio", "kp_min", "kp_max", "out_max_pos", "out_max_ori", "stiffness",
+            "damping", "elem_friction", "probe_friction", "probe_radius", "probe_halflen")]
+
+
+def build_oracle(native=False):
+    target = ["native"] if native else []
+    subprocess.run(["make", "-s", "-C", str(ORACLE_DIR)] + target, check=True)
+
+
+def _lib_path(precision, omp=False, native=False):
+    name = f"libusim_oracle_{precision}"
+    if omp:
+        name += "_omp_native" if native else "_omp"
+    return ORACLE_DIR / "_build" / (name + ".so")
+
+
+_dp = C.POINTER(C.c_double)
+
+
+def _ptr(a, t=C.c_double):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+class Oracle:
+    """n independent Ultrasound envs stepped by the C oracle.  precision: 'f64' (checker) or 'f32'."""
+
+    def __init__(self, n, precision="f64", omp=False, native=False, **cfg):
+        path = _lib_path(precision, omp, native)
+        if not path.exists():
+            build_oracle(native)
+        self.lib = C.CDLL(str(path))
+        L = self.lib
+        L.uso_create.restype = C.c_void_p
+        L.uso_create.argtypes = [C.POINTER(OracleConfig), C.c_int]
+        L.uso_destroy.argtypes = [C.c_void_p]
+        for f in ("uso_action_dim", "uso_num_elements", "uso_shell_edges"):
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.uso_contact_invweight.argtypes = [C.c_void_p]
+        L.uso_contact_invweight.restype = C.c_double
+        L.uso_reset.argtypes = [C.c_void_p, C.c_void_p, _dp]
+        L.uso_reset_explicit.argtypes = [C.c_void_p, C.c_void_p, _dp, _dp]
+        L.uso_step.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_void_p, _dp, C.c_void_p, C.c_int]
+        L.uso_get_state.argtypes = [C.c_void_p, _dp, _dp]
+        L.uso_set_state.argtypes = [C.c_void_p, _dp, _dp]
+        L.uso_random_actions.argtypes = [C.c_void_p, C.c_int64, _dp]
+        L.uso_debug_forward.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.uso_distance_quat.argtypes = [_dp, _dp]
+        L.uso_distance_quat.restype = C.c_double
+        L.uso_difference_quat.argtypes = [_dp, _dp, _dp]
+        L.uso_mat2quat.argtypes = [_dp, _dp]
+        L.uso_philox.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
+        self.cfg = OracleConfig()
+        L.uso_default_config(C.byref(self.cfg))
+        for k, v in cfg.items():
+            if k == "mode" and isinstance(v, str):
+                v = MODE[v]
+            if k == "torso" and isinstance(v, str):
+                v = TORSO[v]
+            if not hasattr(self.cfg, k):
+                raise KeyError(k)
+            setattr(self.cfg, k, v)
+        self.n = n
+        self.h = C.c_void_p(L.uso_create(C.byref(self.cfg), n))
+        self.adim = L.uso_action_dim(self.h)
+        self.n_el = L.uso_num_elements(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.uso_destroy(self.h)
+            self.h = None
+
+    def reset(self, mask=None):
+        obs = np.zeros((self.n, OBS_DIM))
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self.lib.uso_reset(self.h, None if m is None else m.ctypes.data, _ptr(obs))
+        return obs
+
+    def reset_explicit(self, params, mask=None):
+        """params: n x 13 = start xyz, end xyz, u0, noise xyz, stiffness, damping, mu (world coordinates)"""
+        p = np.ascontiguousarray(params, dtype=np.float64).reshape(self.n, 13)
+        obs = np.zeros((self.n, OBS_DIM))
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self.lib.uso_reset_explicit(self.h, None if m is None else m.ctypes.data, _ptr(p), _ptr(obs))
+        return obs
+
+    def step(self, act, auto_reset=True):
+        a = np.ascontiguousarray(act, dtype=np.float64).reshape(self.n, self.adim)
+        obs = np.zeros((self.n, OBS_DIM)); rew = np.zeros(self.n); done = np.zeros(self.n, dtype=np.uint8)
+        term = np.zeros((self.n, OBS_DIM)); con = np.zeros((self.n, 1 + MAXC), dtype=np.int32)
+        self.lib.uso_step(self.h, _ptr(a), _ptr(obs), _ptr(rew), done.ctypes.data, _ptr(term), con.ctypes.data, int(auto_reset))
+        return obs, rew, done.astype(bool), term, con
+
+    def get_state(self):
+        sc = np.zeros((self.n, NSCALAR)); lat = np.zeros((self.n, max(self.n_el, 1), 2))
+        self.lib.uso_get_state(self.h, _ptr(sc), _ptr(lat))
+        st = {k: sc[:, v].copy() for k, v in SCALAR_FIELDS.items()}
+        st["s"] = lat[:, : self.n_el, 0].copy(); st["sd"] = lat[:, : self.n_el, 1].copy()
+        return st
+
+    def set_state(self, st):
+        sc = np.zeros((self.n, NSCALAR)); lat = np.zeros((self.n, max(self.n_el, 1), 2))
+        for k, v in SCALAR_FIELDS.items():
+            sc[:, v] = st[k]
+        lat[:, : self.n_el, 0] = st["s"]; lat[:, : self.n_el, 1] = st["sd"]
+        self.lib.uso_set_state(self.h, _ptr(sc), _ptr(lat))
+
+    def random_actions(self, step):
+        a = np.zeros((self.n, self.adim))
+        self.lib.uso_random_actions(self.h, int(step), _ptr(a))
+        return a
+
+    def debug_forward(self, env=0):
+        out = np.zeros(128)
+        self.lib.uso_debug_forward(self.h, env, _ptr(out))
+        return {"x": out[0:3], "R": out[3:12].reshape(3, 3), "M": out[12:61].reshape(7, 7), "bias": out[61:68],
+                "J": out[68:110].reshape(6, 7), "fc": out[110:113], "torque": out[113:116], "ncon": int(out[116]),
+                "min_margin": out[117], "qacc": out[118:125]}
+
+    # env-level helpers for known-answer tests
+    def distance_quat(self, q1, q2):
+        a = np.ascontiguousarray(q1, dtype=np.float64); b = np.ascontiguousarray(q2, dtype=np.float64)
+        return self.lib.uso_distance_quat(_ptr(a), _ptr(b))
+
+    def difference_quat(self, q1, q2):
+        a = np.ascontiguousarray(q1, dtype=np.float64); b = np.ascontiguousarray(q2, dtype=np.float64); o = np.zeros(4)
+        self.lib.uso_difference_quat(_ptr(a), _ptr(b), _ptr(o))
+        return o
+
+    def mat2quat(self, R):
+        a = np.ascontiguousarray(R, dtype=np.float64); o = np.zeros(4)
+        self.lib.uso_mat2quat(_ptr(a), _ptr(o))
+        return o
+
+    def philox(self, c, k):
+        o = (C.c_uint32 * 4)()
+        self.lib.uso_philox(*[int(x) for x in c], *[int(x) for x in k], o)
+        return np.array(list(o), dtype=np.uint32)
