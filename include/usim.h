@@ -1,0 +1,141 @@
+/*
+ * usim.h -- C ABI of libusim, the MI355X-native batched Ultrasound simulator.
+ *
+ * This is the drop-in boundary of SURVEY.md section 8(b): one handle simulates n independent copies of the
+ * reference's `Ultrasound` robosuite environment (src/my_environments/ultrasound.py:29) and one call
+ * advances all of them by one env.step().  The reference has no FFI of its own (it is pure Python on top of
+ * mujoco-py); each entry point below names the reference interface it replaces.  The Python host class
+ * robotic-ultrasound-imaging_amd/vec_env.py binds exactly these symbols with ctypes and exposes the
+ * stable-baselines3 VecEnv surface used by src/rl.py:130-143.
+ *
+ * Conventions
+ *   - plain C, no exceptions across the boundary: every function returns 0 (USIM_OK) or a negative
+ *     usim_status; usim_strerror() maps it to text.  Per-environment numerical faults never fail a call;
+ *     they are reported in the status word of the environment (usim_get_state, field `status`).
+ *   - all `*_dev` pointers are device (HBM) pointers owned by the caller (PyTorch-ROCm tensors);
+ *     all other pointers are host pointers.  The library owns all simulator state and allocates nothing
+ *     inside usim_step().
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); work is only
+ *     enqueued, the call does not synchronise.  A handle is not thread-safe.
+ *   - observations are float32 [n][19] row-major, actions float32 [n][A] row-major (A = 6, or 7 for
+ *     variable_z), rewards float32 [n], dones uint8 [n].
+ */
+#ifndef USIM_H
+#define USIM_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define USIM_OBS_DIM 19   /* ultrasound.py:394-401: 3+3+3+1+1+1+7 */
+#define USIM_MAXC 8       /* contact slots per environment */
+#define USIM_NSCALAR 40   /* scalar state words per environment in usim_get_state/usim_set_state */
+#define USIM_RESET_PARAMS 13
+
+typedef enum usim_status {
+    USIM_OK = 0,
+    USIM_ERR_INVALID = -1,      /* bad argument / configuration */
+    USIM_ERR_NO_DEVICE = -2,    /* no HIP device, or device index out of range */
+    USIM_ERR_HIP = -3,          /* a HIP runtime call failed (see usim_last_hip_error) */
+    USIM_ERR_ALLOC = -4,
+    USIM_ERR_UNSUPPORTED = -5
+} usim_status;
+
+/* impedance_mode of the OSC_POSE controller: rl_config.yaml:41 ("tracking"), main.py:33 ("fixed"),
+ * utils/plot.py:208-211,303-313 ("variable_z") */
+enum { USIM_MODE_TRACKING = 0, USIM_MODE_FIXED = 1, USIM_MODE_VARIABLE_Z = 2 };
+/* torso model: BASELINE.json configs[1] (rigid, contact solver off) / configs[2] (soft torso) */
+enum { USIM_TORSO_NONE = 0, USIM_TORSO_TOP = 1 };
+
+/* Mirrors the `robosuite:` block of src/rl_config.yaml:18-57 (the kwargs of Ultrasound.__init__,
+ * ultrasound.py:99-136) plus the knobs the MJCF assets fix in the reference. */
+typedef struct usim_config {
+    int32_t mode;                              /* controller_configs.impedance_mode */
+    int32_t torso;                             /* USIM_TORSO_* */
+    int32_t horizon;                           /* rl_config.yaml:27 */
+    int32_t early_termination;                 /* rl_config.yaml:52 */
+    int32_t deterministic_trajectory;          /* rl_config.yaml:54 */
+    int32_t torso_solref_randomization;        /* rl_config.yaml:55 */
+    int32_t initial_probe_pos_randomization;   /* rl_config.yaml:56 */
+    int32_t friction_randomization;            /* BASELINE.json configs[4] */
+    int32_t torso_drop;                        /* reproduce the 4.7 mm spawn drop (ultrasound.py:313) */
+    int32_t pgs_iters;                         /* contact PGS sweeps per forward pass */
+    int32_t ik_iters;                          /* reset inverse-kinematics iterations */
+    int32_t env_offset;                        /* global index of env 0 of this handle (multi-GPU shard) */
+    uint64_t seed;                             /* rl_config.yaml:1 */
+    double control_dt;                         /* 1 / control_freq (rl_config.yaml:26) */
+    double kp_fixed, damping_ratio;            /* rl_config.yaml:38-39 */
+    double kp_min, kp_max;                     /* rl_config.yaml:42 */
+    double out_max_pos, out_max_ori;           /* rl_config.yaml:36 */
+    double stiffness, damping;                 /* soft_box.xml:9 solrefsmooth */
+    double elem_friction, probe_friction;      /* soft_box.xml:10, ultrasound_probe_gripper.xml:8 */
+    double probe_radius, probe_halflen;        /* stand-in capsule for the missing probe mesh */
+} usim_config;
+
+typedef struct usim_handle usim_handle;
+
+/* Per-step I/O block.  Required: obs, rew, done.  `act` may be NULL only for usim_rollout_random /
+ * usim_time_steps (actions are then drawn in-kernel).  Optional outputs may be NULL. */
+typedef struct usim_step_io {
+    const float* act_dev;      /* [n][A]   replaces the `action` argument of env.step (robosuite MujocoEnv.step) */
+    float* obs_dev;            /* [n][19]  GymWrapper-flattened observation; the RESET observation where done */
+    float* rew_dev;            /* [n]      Ultrasound.reward, ultrasound.py:230-269 */
+    uint8_t* done_dev;         /* [n]      ultrasound.py:549-550 + horizon */
+    float* term_obs_dev;       /* [n][19]  SB3 infos[i]["terminal_observation"]; written where done */
+    int32_t* contacts_dev;     /* [n][1+USIM_MAXC] count, then ascending shell-element ids (ultrasound.py:673-736) */
+    float* ep_return_dev;      /* [n]      SB3 Monitor infos[i]["episode"]["r"]; written where done */
+    int32_t* ep_length_dev;    /* [n]      SB3 Monitor infos[i]["episode"]["l"]; written where done */
+} usim_step_io;
+
+/* fills *c with the shipped configuration (src/rl_config.yaml) */
+int usim_default_config(usim_config* c);
+
+/* Replaces suite.make("Ultrasound", **options) + GymWrapper (src/rl.py:36-40) for n environments on HIP
+ * device `device`.  Environments start un-reset; call usim_reset first. */
+int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** out);
+void usim_destroy(usim_handle* h);
+
+int usim_num_envs(const usim_handle* h);
+int usim_action_dim(const usim_handle* h);     /* GymWrapper.action_space.shape[0] */
+int usim_num_elements(const usim_handle* h);   /* dynamic torso elements per env (0 or 99) */
+
+/* Replaces env.reset() (ultrasound.py:416-478) for the envs where mask_dev[i] != 0 (NULL = all).
+ * obs_dev [n][19] (may be NULL) receives the reset observation of the selected envs. */
+int usim_reset(usim_handle* h, const uint8_t* mask_dev, float* obs_dev, void* stream);
+
+/* Same, with explicit per-env draws instead of the seeded stream: params_dev [n][13] =
+ * start xyz, end xyz (world), u0, position noise xyz, stiffness, damping, contact friction. */
+int usim_reset_explicit(usim_handle* h, const uint8_t* mask_dev, const float* params_dev, float* obs_dev, void* stream);
+
+/* Replaces SubprocVecEnv.step_async + step_wait over n envs (src/rl.py:130): one env.step() each, with
+ * SB3 auto-reset semantics when auto_reset != 0. */
+int usim_step(usim_handle* h, const usim_step_io* io, int auto_reset, void* stream);
+
+/* Synthetic workload of BASELINE.md section 4: fills act_dev [n][A] with i.i.d. uniform actions from the
+ * counter-based stream keyed (seed, global env id, step). */
+int usim_random_actions(usim_handle* h, int64_t step, float* act_dev, void* stream);
+
+/* Enqueues nsteps consecutive steps whose actions are drawn in-kernel from the same stream as
+ * usim_random_actions(first_step + k) (io->act_dev ignored). */
+int usim_rollout_random(usim_handle* h, int64_t first_step, int nsteps, const usim_step_io* io, void* stream);
+
+/* Like usim_rollout_random, bracketed by HIP events on `stream`; blocks until done and returns the elapsed
+ * device time in milliseconds (bench.py roofline leg). */
+int usim_time_steps(usim_handle* h, int64_t first_step, int nsteps, const usim_step_io* io, void* stream, float* elapsed_ms);
+
+/* Checkpoint / inspection.  Host buffers; synchronises the device.
+ * scalars [n][USIM_NSCALAR]: q[0..6] qd[7..13] q0[14..20] traj_start[21..23] traj_end[24..26] u0[27] vbar[28]
+ * fzbar[29] fzprev[30] dfz[31] stiffness[32] damping[33] mu[34] t[35] has_touched[36] episode[37]
+ * ep_return[38] status[39];  lattice [n][E][2] = (s, sdot) per element (may be NULL when E == 0). */
+int usim_get_state(usim_handle* h, float* scalars, float* lattice);
+int usim_set_state(usim_handle* h, const float* scalars, const float* lattice);
+
+const char* usim_strerror(int status);
+const char* usim_last_hip_error(const usim_handle* h);
+const char* usim_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* USIM_H */

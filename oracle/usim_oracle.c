@@ -232,6 +232,7 @@ typedef struct {
     real s[N_TOP], sd[N_TOP];
     int ncon, con_el[USO_MAXC];
     int status;
+    double info[8];                                 /* diagnostics of the last step (uso_last_info) */
 } Env;
 
 typedef struct {
@@ -996,14 +997,20 @@ static void step_env(Sim* S, int i, const double* act_d, double* obs, double* re
     E->dfz = (fz - E->fzprev) / dt;                        /* :542 */
     E->fzprev = fz;                                        /* :543 */
     E->fzbar = (real)FORCE_EMA_ALPHA * fz + (1 - (real)FORCE_EMA_ALPHA) * E->fzbar;   /* :546 */
+    int cause = done ? 1 : 0;
+    double jmargin = 1e9;
+    for (int j = 0; j < NJ; j++) { double a = (double)E->q[j] - (Q_MIN[j] + QLIM_TOL), b = (Q_MAX[j] - QLIM_TOL) - (double)E->q[j]; if (a < jmargin) jmargin = a; if (b < jmargin) jmargin = b; }
     if (c->early_termination) {                            /* :549-550 -> :635-670 */
         int term = 0;
-        for (int j = 0; j < NJ; j++) if (E->q[j] < (real)(Q_MIN[j] + QLIM_TOL) || E->q[j] > (real)(Q_MAX[j] - QLIM_TOL)) term = 1;   /* :651 */
-        if (pos_err_norm > (real)POS_ERR_THRESH) term = 1;                           /* :656 */
-        if (contact && ori_err > (real)ORI_ERR_THRESH) term = 1;                     /* :661 */
-        if (E->has_touched && !contact) term = 1;                                    /* :666 */
+        for (int j = 0; j < NJ; j++) if (E->q[j] < (real)(Q_MIN[j] + QLIM_TOL) || E->q[j] > (real)(Q_MAX[j] - QLIM_TOL)) { term = 1; cause |= 2; }   /* :651 */
+        if (pos_err_norm > (real)POS_ERR_THRESH) { term = 1; cause |= 4; }           /* :656 */
+        if (contact && ori_err > (real)ORI_ERR_THRESH) { term = 1; cause |= 8; }     /* :661 */
+        if (E->has_touched && !contact) { term = 1; cause |= 16; }                   /* :666 */
         done = done || term;
     }
+    /* termination cause bitmask (1 horizon, 2 joint limit, 4 position, 8 orientation, 16 lost contact) and the
+     * distance of every thresholded quantity from its threshold, for razor-edge analysis in the parity tests */
+    double info_tmp[8] = {(double)cause, (double)pos_err_norm, (double)ori_err, jmargin, (double)P.f.min_margin, (double)P.f.ncon, (double)reward, 0};
     E->ep_return += reward;
     E->ncon = P.f.ncon; for (int cix = 0; cix < P.f.ncon; cix++) E->con_el[cix] = m->el_shell_id[P.f.con_el[cix]];
     if (P.f.overflow) E->status |= 1;
@@ -1013,6 +1020,7 @@ static void step_env(Sim* S, int i, const double* act_d, double* obs, double* re
     if (term_obs) for (int a = 0; a < USO_OBS_DIM; a++) term_obs[a] = (double)ob[a];
     if (obs) for (int a = 0; a < USO_OBS_DIM; a++) obs[a] = (double)ob[a];
     if (done && auto_reset) reset_env(S, i, 0, obs);       /* SB3 VecEnv: obs of a finished env is its reset obs */
+    memcpy(S->env[i].info, info_tmp, sizeof info_tmp);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -1101,6 +1109,11 @@ int uso_random_actions(void* h, int64_t step, double* act) {
             act[(size_t)i * S->adim + a] = signedbox ? 2.0 * u - 1.0 : u;
         }
     }
+    return 0;
+}
+int uso_last_info(void* h, double* out) {
+    Sim* S = (Sim*)h;
+    for (int i = 0; i < S->n; i++) memcpy(out + (size_t)i * 8, S->env[i].info, sizeof S->env[i].info);
     return 0;
 }
 int uso_debug_forward(void* h, int env, double* out) {

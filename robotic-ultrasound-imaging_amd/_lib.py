@@ -1,0 +1,88 @@
+"""ctypes binding of libusim.so -- exactly the symbols declared in include/usim.h.
+
+The product path has no CPU fallback: if the shared library is missing or cannot be loaded the import of the
+simulator raises, and every entry point that needs a GPU returns a negative usim_status that is raised as
+RuntimeError(usim_strerror)."""
+import ctypes as C
+import os
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "lib" / "libusim.so"
+
+OBS_DIM = 19
+MAXC = 8
+NSCALAR = 40
+RESET_PARAMS = 13
+
+MODE = {"tracking": 0, "fixed": 1, "variable_z": 2}
+TORSO = {"none": 0, "rigid": 0, "top": 1, "soft": 1}
+
+
+class UsimConfig(C.Structure):
+    """struct usim_config (include/usim.h)"""
+    _fields_ = [(n, C.c_int32) for n in (
+        "mode", "torso", "horizon", "early_termination", "deterministic_trajectory", "torso_solref_randomization",
+        "initial_probe_pos_randomization", "friction_randomization", "torso_drop", "pgs_iters", "ik_iters", "env_offset")] + \
+        [("seed", C.c_uint64)] + [(n, C.c_double) for n in (
+            "control_dt", "kp_fixed", "damping_ratio", "kp_min", "kp_max", "out_max_pos", "out_max_ori", "stiffness", "damping",
+            "elem_friction", "probe_friction", "probe_radius", "probe_halflen")]
+
+
+class UsimStepIO(C.Structure):
+    """struct usim_step_io (include/usim.h); all members are device pointers"""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "act_dev", "obs_dev", "rew_dev", "done_dev", "term_obs_dev", "contacts_dev", "ep_return_dev", "ep_length_dev")]
+
+
+# every exported symbol of include/usim.h: name -> (restype, argtypes)
+SYMBOLS = {
+    "usim_default_config": (C.c_int, [C.POINTER(UsimConfig)]),
+    "usim_create": (C.c_int, [C.POINTER(UsimConfig), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "usim_destroy": (None, [C.c_void_p]),
+    "usim_num_envs": (C.c_int, [C.c_void_p]),
+    "usim_action_dim": (C.c_int, [C.c_void_p]),
+    "usim_num_elements": (C.c_int, [C.c_void_p]),
+    "usim_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "usim_reset_explicit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "usim_step": (C.c_int, [C.c_void_p, C.POINTER(UsimStepIO), C.c_int, C.c_void_p]),
+    "usim_random_actions": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "usim_rollout_random": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(UsimStepIO), C.c_void_p]),
+    "usim_time_steps": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(UsimStepIO), C.c_void_p, C.POINTER(C.c_float)]),
+    "usim_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "usim_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "usim_strerror": (C.c_char_p, [C.c_int]),
+    "usim_last_hip_error": (C.c_char_p, [C.c_void_p]),
+    "usim_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libusim.so and bind every symbol; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("USIM_LIB", LIB_PATH))
+    if not path.exists():
+        raise RuntimeError(f"libusim.so not found at {path}: build it with `python __graft_entry__.py build` "
+                           f"(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(str(path))
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(lib, rc, handle=None):
+    if rc == 0:
+        return
+    msg = lib.usim_strerror(rc).decode()
+    if handle:
+        detail = lib.usim_last_hip_error(handle).decode()
+        if detail:
+            msg += f" [{detail}]"
+    raise RuntimeError(f"usim error {rc}: {msg}")

@@ -1,0 +1,103 @@
+"""Translate the reference's configuration (the `robosuite:` block of src/rl_config.yaml:18-57, i.e. the kwargs of
+Ultrasound.__init__, ultrasound.py:99-136) into a usim_config."""
+import ctypes as C
+
+from . import _lib
+
+# kwargs of the reference env that only concern rendering / bookkeeping and have no effect on step()/reset()
+_IGNORED = {
+    "env_id", "env_configuration", "use_camera_obs", "has_renderer", "has_offscreen_renderer", "render_camera",
+    "render_collision_mesh", "render_visual_mesh", "render_gpu_device_id", "camera_names", "camera_heights",
+    "camera_widths", "camera_depths", "reward_shaping", "reward_scale", "table_full_size", "table_friction",
+    "initialization_noise", "placement_initializer", "ignore_done", "hard_reset",
+}
+# extensions of this build (not kwargs of the reference env)
+_NATIVE = {"torso", "friction_randomization", "torso_drop", "pgs_iters", "ik_iters", "stiffness", "damping",
+           "elem_friction", "probe_friction", "probe_radius", "probe_halflen"}
+
+
+def default_robosuite_kwargs():
+    """The shipped configuration, src/rl_config.yaml:18-57."""
+    return {
+        "robots": "Panda", "use_object_obs": False, "control_freq": 500, "horizon": 1000,
+        "controller_configs": {
+            "type": "OSC_POSE", "input_max": 1, "input_min": -1,
+            "output_max": [0.05, 0.05, 0.05, 0.5, 0.5, 0.5], "output_min": [-0.05, -0.05, -0.05, -0.5, -0.5, -0.5],
+            "kp": 300, "damping_ratio": 1, "impedance_mode": "tracking", "kp_limits": [0, 500], "kp_input_max": 1,
+            "kp_input_min": 0, "damping_ratio_limits": [0, 2], "position_limits": None, "orientation_limits": None,
+            "uncouple_pos_ori": True, "control_delta": True, "interpolation": None, "ramp_ratio": 0.2,
+        },
+        "early_termination": True, "save_data": False, "deterministic_trajectory": False,
+        "torso_solref_randomization": True, "initial_probe_pos_randomization": True, "use_box_torso": True,
+    }
+
+
+def load_yaml(path):
+    """Read src/rl_config.yaml-style files; returns (seed, robosuite kwargs)."""
+    import yaml
+    with open(path) as f:
+        cfg = yaml.safe_load(f)
+    return int(cfg.get("seed", 0)), dict(cfg["robosuite"])
+
+
+def make_config(seed=3, env_offset=0, **kw):
+    """kwargs of Ultrasound.__init__ (+ native extensions) -> _lib.UsimConfig.  Unsupported settings raise
+    ValueError, mirroring the asserts at ultrasound.py:134-141."""
+    lib = _lib.load()
+    c = _lib.UsimConfig()
+    _lib.check(lib, lib.usim_default_config(C.byref(c)))
+    kw = dict(kw)
+    robots = kw.pop("robots", "Panda")
+    if isinstance(robots, (list, tuple)):
+        if len(robots) != 1:
+            raise ValueError("Ultrasound is a single-arm environment")
+        robots = robots[0]
+    if robots != "Panda":
+        raise ValueError("only the Panda robot of rl_config.yaml:20 is implemented (UR5e: SURVEY.md 8f)")
+    if kw.pop("gripper_types", "UltrasoundProbeGripper") != "UltrasoundProbeGripper":
+        raise ValueError("Tried to specify gripper other than UltrasoundProbeGripper in Ultrasound environment!")
+    if not kw.pop("use_box_torso", True):
+        raise ValueError("cylinder torso (soft_human_torso.xml) is not implemented (SURVEY.md 8f)")
+    if kw.pop("save_data", False):
+        raise ValueError("save_data CSV dump is not implemented (SURVEY.md 8f)")
+    if kw.pop("use_object_obs", False):
+        raise ValueError("use_object_obs=True is not implemented (rl_config.yaml:22 uses False)")
+    cc = kw.pop("controller_configs", None) or default_robosuite_kwargs()["controller_configs"]
+    if "OSC" not in str(cc.get("type", "OSC_POSE")):
+        raise ValueError("The robot controller must be of type OSC")
+    mode = cc.get("impedance_mode", "tracking")
+    if mode not in _lib.MODE:
+        raise ValueError(f"impedance_mode {mode!r} not implemented (have {sorted(_lib.MODE)})")
+    if not cc.get("uncouple_pos_ori", True) or cc.get("interpolation") is not None or not cc.get("control_delta", True):
+        raise ValueError("only uncouple_pos_ori=True, interpolation=None, control_delta=True are implemented")
+    c.mode = _lib.MODE[mode]
+    c.kp_fixed = float(cc.get("kp", 300))
+    c.damping_ratio = float(cc.get("damping_ratio", 1))
+    c.kp_min, c.kp_max = [float(v) for v in cc.get("kp_limits", [0, 500])]
+    omax = cc.get("output_max", [0.05] * 3 + [0.5] * 3)
+    omax = [omax] * 6 if not isinstance(omax, (list, tuple)) else list(omax)
+    c.out_max_pos, c.out_max_ori = float(omax[0]), float(omax[3])
+    c.control_dt = 1.0 / float(kw.pop("control_freq", 500))
+    c.horizon = int(kw.pop("horizon", 1000))
+    c.early_termination = int(bool(kw.pop("early_termination", False)))
+    c.deterministic_trajectory = int(bool(kw.pop("deterministic_trajectory", False)))
+    c.torso_solref_randomization = int(bool(kw.pop("torso_solref_randomization", False)))
+    c.initial_probe_pos_randomization = int(bool(kw.pop("initial_probe_pos_randomization", False)))
+    torso = kw.pop("torso", "soft")
+    if torso not in _lib.TORSO:
+        raise ValueError(f"torso must be one of {sorted(_lib.TORSO)}")
+    c.torso = _lib.TORSO[torso]
+    for k in ("friction_randomization", "torso_drop", "pgs_iters", "ik_iters"):
+        if k in kw:
+            setattr(c, k, int(kw.pop(k)))
+    for k in ("stiffness", "damping", "elem_friction", "probe_friction", "probe_radius", "probe_halflen"):
+        if k in kw:
+            setattr(c, k, float(kw.pop(k)))
+    for k in list(kw):
+        if k in _IGNORED:
+            kw.pop(k)
+    if kw:
+        raise TypeError(f"unexpected Ultrasound kwargs: {sorted(kw)}")
+    c.seed = int(seed)
+    c.env_offset = int(env_offset)
+    return c

@@ -1,0 +1,380 @@
+// usim_api.hip -- host side of the C ABI declared in include/usim.h (libusim.so).
+//
+// Builds the model constants in double precision (link-7 composite inertia, torso lattice tables, the inverse
+// of the lattice normal matrix), owns the SoA state block in HBM and enqueues the kernels of
+// usim_kernels.hip on the caller's HIP stream.  No torch types, no exceptions across the boundary.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <new>
+
+#include "../../include/usim.h"
+#include "usim_device.h"
+#include "usim_kernels.hip"      // single translation unit: kernels + host launcher (no relocatable device code)
+
+namespace usim { constexpr int LDS_WORDS_TOP_HOST = LDS_WORDS_TOP; }
+
+using namespace usim;
+
+struct usim_handle {
+    usim_config cfg;
+    int n = 0, npad = 0, device = 0, adim = 6, n_el = 0, nfields = 0;
+    DevModel M;
+    DevCfg C;
+    float* state = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    size_t lds_bytes = 0;
+    std::string hip_err;
+};
+
+#define HIPCHK(h, call)                                                                                     \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess) {                                                                             \
+            (h)->hip_err = std::string(#call) + ": " + hipGetErrorString(e_);                               \
+            return USIM_ERR_HIP;                                                                            \
+        }                                                                                                   \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
+// model data (the Panda chain constants themselves live in usim_kernels.hip)
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+const double kPi = 3.14159265358979323846;
+const double kGoalQuat[4] = {-0.69192486, 0.72186726, -0.00514253, -0.01100909};   // ultrasound.py:174 (x,y,z,w)
+const double kBase[3] = {-0.56, 0.0, 0.913};                                         // ultrasound.py:279-280 + mount height
+const double kTorso[3] = {0.0, 0.0, 0.8 + 0.005 + 0.0522};                           // ultrasound.py:146,313; soft_box.xml:14
+const double kHandPos[3] = {0, 0, 0.107};
+const double kProbePos[3] = {-0.004, -0.063, 0.128};                                 // ultrasound_probe_gripper.xml:6
+const double kProbeCom[3] = {0.0013, 0.021, -0.043};                                 // stand-in (mesh missing from the snapshot)
+const double kProbeI[3] = {1.6e-3, 1.6e-3, 2.0e-4};
+
+struct Inertial { double m; double c[3]; double I[3][3]; };
+
+void add_body(Inertial& a, double mb, const double cb[3], const double Ib[3][3]) {
+    double m = a.m + mb, c[3];
+    for (int i = 0; i < 3; ++i) c[i] = (a.m * a.c[i] + mb * cb[i]) / m;
+    double I[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) I[i][j] = a.I[i][j] + Ib[i][j];
+    auto shift = [&](double mm, const double* cc) {
+        double d[3] = {cc[0] - c[0], cc[1] - c[1], cc[2] - c[2]}, dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) I[i][j] += mm * ((i == j ? dd : 0.0) - d[i] * d[j]);
+    };
+    shift(a.m, a.c); shift(mb, cb);
+    a.m = m;
+    for (int i = 0; i < 3; ++i) { a.c[i] = c[i]; for (int j = 0; j < 3; ++j) a.I[i][j] = I[i][j]; }
+}
+
+void pack_sym(const double I[3][3], float* o) { o[0] = (float)I[0][0]; o[1] = (float)I[0][1]; o[2] = (float)I[0][2]; o[3] = (float)I[1][1]; o[4] = (float)I[1][2]; o[5] = (float)I[2][2]; }
+
+bool on_shell(int a, int b, int c) {
+    if (a < 0 || a >= 9 || b < 0 || b >= 4 || c < 0 || c >= 11) return false;
+    return a == 0 || a == 8 || b == 0 || b == 3 || c == 0 || c == 10;
+}
+
+// dense symmetric positive definite inverse by Gauss-Jordan in double precision
+std::vector<double> invert(std::vector<double> a, int n) {
+    std::vector<double> inv((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) inv[(size_t)i * n + i] = 1.0;
+    for (int c = 0; c < n; ++c) {
+        int p = c;
+        for (int r = c + 1; r < n; ++r) if (std::fabs(a[(size_t)r * n + c]) > std::fabs(a[(size_t)p * n + c])) p = r;
+        if (p != c) for (int k = 0; k < n; ++k) { std::swap(a[(size_t)p * n + k], a[(size_t)c * n + k]); std::swap(inv[(size_t)p * n + k], inv[(size_t)c * n + k]); }
+        double d = 1.0 / a[(size_t)c * n + c];
+        for (int k = 0; k < n; ++k) { a[(size_t)c * n + k] *= d; inv[(size_t)c * n + k] *= d; }
+        for (int r = 0; r < n; ++r) {
+            if (r == c) continue;
+            double f = a[(size_t)r * n + c];
+            if (f == 0.0) continue;
+            for (int k = 0; k < n; ++k) { a[(size_t)r * n + k] -= f * a[(size_t)c * n + k]; inv[(size_t)r * n + k] -= f * inv[(size_t)c * n + k]; }
+        }
+    }
+    return inv;
+}
+}  // namespace
+
+static int build_model(usim_handle* h) {
+    DevModel& M = h->M;
+    std::memset(&M, 0, sizeof M);
+    // site / hand / probe in the link-7 frame; hand frame is link 7 rotated by -45 deg about z
+    const double ch = std::cos(-kPi / 4), sh = std::sin(-kPi / 4);
+    const double Rh[3][3] = {{ch, -sh, 0}, {sh, ch, 0}, {0, 0, 1}};
+    double site7[3], pcom7[3], Ip7[3][3];
+    for (int i = 0; i < 3; ++i) {
+        site7[i] = kHandPos[i]; pcom7[i] = 0;
+        for (int k = 0; k < 3; ++k) site7[i] += Rh[i][k] * kProbePos[k];
+    }
+    for (int i = 0; i < 3; ++i) { pcom7[i] = site7[i]; for (int k = 0; k < 3; ++k) pcom7[i] += Rh[i][k] * kProbeCom[k]; }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { Ip7[i][j] = 0; for (int k = 0; k < 3; ++k) Ip7[i][j] += Rh[i][k] * kProbeI[k] * Rh[j][k]; }
+    // link-7 composite: link7 (0.5 kg, com z 0.08, I 0.05) + hand (0.5 kg at the hand origin, I 0.05) + probe (1 kg)
+    Inertial c7{0.5, {0, 0, 0.08}, {{0.05, 0, 0}, {0, 0.05, 0}, {0, 0, 0.05}}};
+    const double Ih[3][3] = {{0.05, 0, 0}, {0, 0.05, 0}, {0, 0, 0.05}};
+    add_body(c7, 0.5, kHandPos, Ih);
+    add_body(c7, 1.0, pcom7, Ip7);
+    M.m7 = (float)c7.m;
+    for (int i = 0; i < 3; ++i) { M.c7[i] = (float)c7.c[i]; M.site7[i] = (float)site7[i]; M.hand7[i] = (float)kHandPos[i]; M.pcom7[i] = (float)pcom7[i]; }
+    pack_sym(c7.I, M.I7); pack_sym(Ip7, M.pI7);
+    for (int i = 0; i < 3; ++i) { M.torso[i] = (float)(kTorso[i] - kBase[i]); M.base[i] = (float)kBase[i]; }
+    {
+        double x = kGoalQuat[0], y = kGoalQuat[1], z = kGoalQuat[2], w = kGoalQuat[3];
+        double nn = std::sqrt(x * x + y * y + z * z + w * w); x /= nn; y /= nn; z /= nn; w /= nn;
+        const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), 1 - 2 * (x * x + z * z),
+                             2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+        for (int i = 0; i < 9; ++i) M.grot[i] = (float)R[i];
+        for (int i = 0; i < 4; ++i) M.gquat[i] = (float)kGoalQuat[i];
+    }
+    const double dmax = 0.95;
+    M.wfix = (float)(dmax / (1 - dmax));
+    M.wten = (float)(0.5 * dmax / (1 - dmax));
+
+    // ---- torso lattice: top face (iy = 3) of the 9 x 4 x 11 shell, shell ids in creation order ----
+    h->n_el = (h->cfg.torso == USIM_TORSO_TOP) ? N_TOP : 0;
+    if (h->n_el == 0) return USIM_OK;
+    std::vector<float> elpos(N_TOP * 3), elaxis(N_TOP * 3);
+    std::vector<int> nbr(N_TOP * 4, -2), shell(N_TOP);
+    int sid = 0, top_index[9][11];
+    for (int a = 0; a < 9; ++a) for (int b = 0; b < 4; ++b) for (int c = 0; c < 11; ++c) {
+        if (!on_shell(a, b, c)) continue;
+        if (b == 3) { top_index[a][c] = a * 11 + c; shell[a * 11 + c] = sid; }
+        ++sid;
+    }
+    std::vector<double> L((size_t)N_TOP * N_TOP, 0.0);
+    for (int a = 0; a < 9; ++a) for (int c = 0; c < 11; ++c) {
+        const int e = top_index[a][c];
+        const double loc[3] = {(a - 4) * 0.035, 1.5 * 0.035, (c - 5) * 0.035};
+        const double len = std::sqrt(loc[0] * loc[0] + loc[1] * loc[1] + loc[2] * loc[2]);
+        // parent quat (0.5, 0.5, -0.5, -0.5): world x = -local z, world y = -local x, world z = local y
+        const double w[3] = {-loc[2], -loc[0], loc[1]};
+        for (int k = 0; k < 3; ++k) { elpos[e * 3 + k] = (float)w[k]; elaxis[e * 3 + k] = (float)(w[k] / len); }
+        int nn = 0;
+        const int da[4] = {-1, 1, 0, 0}, dc[4] = {0, 0, -1, 1};
+        for (int d = 0; d < 4; ++d) {
+            int a2 = a + da[d], c2 = c + dc[d];
+            if (a2 >= 0 && a2 < 9 && c2 >= 0 && c2 < 11) nbr[e * 4 + nn++] = top_index[a2][c2];
+        }
+        if (on_shell(a, 2, c)) nbr[e * 4 + nn++] = -1;     // side-face neighbour below the rim: pinned
+        L[(size_t)e * N_TOP + e] = 1.0 + dmax / (1 - dmax) + 0.5 * dmax / (1 - dmax) * nn;
+        for (int d = 0; d < nn; ++d) if (nbr[e * 4 + d] >= 0) L[(size_t)e * N_TOP + nbr[e * 4 + d]] = -0.5 * dmax / (1 - dmax);
+    }
+    std::vector<double> Li = invert(L, N_TOP);
+    std::vector<float> linv((size_t)N_TOP * N_TOP), blk((size_t)LINV_NBLK * N_TOP * LINV_BLK, 0.f);
+    for (int i = 0; i < N_TOP; ++i) for (int j = 0; j < N_TOP; ++j) {
+        linv[(size_t)i * N_TOP + j] = (float)Li[(size_t)i * N_TOP + j];
+        blk[((size_t)(i / LINV_BLK) * N_TOP + j) * LINV_BLK + (i % LINV_BLK)] = (float)Li[(size_t)i * N_TOP + j];
+    }
+    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(c_el_pos), elpos.data(), elpos.size() * 4));
+    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(c_el_axis), elaxis.data(), elaxis.size() * 4));
+    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(c_el_nbr), nbr.data(), nbr.size() * 4));
+    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(c_el_shell), shell.data(), shell.size() * 4));
+    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(c_linv), linv.data(), linv.size() * 4));
+    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(c_linv_blk), blk.data(), blk.size() * 4));
+    return USIM_OK;
+}
+
+template <int TORSO>
+static hipError_t launch_step(usim_handle* h, const DevIO& io, int flags, long long rstep, hipStream_t s) {
+    dim3 grid(h->npad / WG), block(WG);
+    hipLaunchKernelGGL(usim_step_kernel<TORSO>, grid, block, h->lds_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
+    return hipGetLastError();
+}
+
+static int launch(usim_handle* h, const DevIO& io, int flags, long long rstep, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = h->n_el ? launch_step<1>(h, io, flags, rstep, s) : launch_step<0>(h, io, flags, rstep, s);
+    if (e != hipSuccess) { h->hip_err = std::string("usim_step_kernel launch: ") + hipGetErrorString(e); return USIM_ERR_HIP; }
+    return USIM_OK;
+}
+
+extern "C" {
+
+int usim_default_config(usim_config* c) {
+    if (!c) return USIM_ERR_INVALID;
+    std::memset(c, 0, sizeof *c);
+    c->mode = USIM_MODE_TRACKING; c->torso = USIM_TORSO_TOP; c->horizon = 1000; c->early_termination = 1;
+    c->deterministic_trajectory = 0; c->torso_solref_randomization = 1; c->initial_probe_pos_randomization = 1;
+    c->friction_randomization = 0; c->torso_drop = 1; c->pgs_iters = 10; c->ik_iters = 8; c->env_offset = 0; c->seed = 3;
+    c->control_dt = 0.002; c->kp_fixed = 300; c->damping_ratio = 1; c->kp_min = 0; c->kp_max = 500; c->out_max_pos = 0.05; c->out_max_ori = 0.5;
+    c->stiffness = 1324.17; c->damping = 17.59; c->elem_friction = 0.01; c->probe_friction = 1e-4; c->probe_radius = 0.03; c->probe_halflen = 0.02;
+    return USIM_OK;
+}
+
+int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** out) {
+    if (!cfg || !out || n_envs <= 0) return USIM_ERR_INVALID;
+    if (cfg->mode < 0 || cfg->mode > 2 || cfg->torso < 0 || cfg->torso > 1 || cfg->horizon <= 0 || cfg->control_dt <= 0 ||
+        cfg->probe_halflen < 1e-4 || cfg->probe_radius <= 0 || cfg->pgs_iters < 0 || cfg->ik_iters < 0) return USIM_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return USIM_ERR_NO_DEVICE;
+    usim_handle* h = new (std::nothrow) usim_handle();
+    if (!h) return USIM_ERR_ALLOC;
+    *out = h;                       // returned even on failure so that usim_last_hip_error can be read; caller destroys
+    h->cfg = *cfg; h->n = n_envs; h->npad = (n_envs + WG - 1) / WG * WG; h->device = device;
+    h->adim = (cfg->mode == USIM_MODE_VARIABLE_Z) ? 7 : 6;
+    HIPCHK(h, hipSetDevice(device));
+    int rc = build_model(h);
+    if (rc != USIM_OK) return rc;
+    DevCfg& C = h->C;
+    C.mode = cfg->mode; C.horizon = cfg->horizon; C.early_term = cfg->early_termination; C.det_traj = cfg->deterministic_trajectory;
+    C.rand_solref = cfg->torso_solref_randomization; C.rand_pos = cfg->initial_probe_pos_randomization; C.rand_fric = cfg->friction_randomization;
+    C.torso_drop = cfg->torso_drop; C.pgs_iters = cfg->pgs_iters; C.ik_iters = cfg->ik_iters; C.env_offset = cfg->env_offset; C.adim = h->adim;
+    C.key0 = (uint32_t)cfg->seed; C.key1 = (uint32_t)(cfg->seed >> 32);
+    C.dt = (float)cfg->control_dt; C.kp_fixed = (float)cfg->kp_fixed; C.damping_ratio = (float)cfg->damping_ratio; C.kp_min = (float)cfg->kp_min;
+    C.kp_max = (float)cfg->kp_max; C.out_pos = (float)cfg->out_max_pos; C.out_ori = (float)cfg->out_max_ori; C.stiffness = (float)cfg->stiffness;
+    C.damping = (float)cfg->damping; C.elem_fric = (float)cfg->elem_friction; C.probe_fric = (float)cfg->probe_friction;
+    C.probe_r = (float)cfg->probe_radius; C.probe_hl = (float)cfg->probe_halflen;
+    h->nfields = h->n_el ? F_TOTAL_TOP : F_NSCALAR;
+    size_t bytes = (size_t)h->nfields * h->npad * sizeof(float);
+    HIPCHK(h, hipMalloc(&h->state, bytes));
+    HIPCHK(h, hipMemset(h->state, 0, bytes));
+    HIPCHK(h, hipEventCreate(&h->ev0));
+    HIPCHK(h, hipEventCreate(&h->ev1));
+    h->lds_bytes = h->n_el ? (size_t)LDS_WORDS_TOP_HOST * WG * sizeof(float) : 0;
+    if (h->n_el)
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    // contact regulariser scale: translational inverse weight of the probe at init_qpos (device, one lane) + element
+    {
+        float* d_w = nullptr; float w = 0.f;
+        HIPCHK(h, hipMalloc(&d_w, sizeof(float)));
+        hipLaunchKernelGGL(usim_invweight_kernel, dim3(1), dim3(WG), 0, 0, h->M, d_w);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpy(&w, d_w, sizeof(float), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipFree(d_w));
+        const double invw_elem = (1.0 / 0.01 + 2.0 / (270 * 0.01)) / 3.0;
+        h->M.invw = (float)((double)w + invw_elem);
+    }
+    return USIM_OK;
+}
+
+void usim_destroy(usim_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->state) (void)hipFree(h->state);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+}
+
+int usim_num_envs(const usim_handle* h) { return h ? h->n : USIM_ERR_INVALID; }
+int usim_action_dim(const usim_handle* h) { return h ? h->adim : USIM_ERR_INVALID; }
+int usim_num_elements(const usim_handle* h) { return h ? h->n_el : USIM_ERR_INVALID; }
+
+int usim_reset(usim_handle* h, const uint8_t* mask_dev, float* obs_dev, void* stream) {
+    if (!h) return USIM_ERR_INVALID;
+    DevIO io{}; io.mask = mask_dev; io.obs = obs_dev;
+    return launch(h, io, LF_RESET_ONLY, 0, stream);
+}
+
+int usim_reset_explicit(usim_handle* h, const uint8_t* mask_dev, const float* params_dev, float* obs_dev, void* stream) {
+    if (!h || !params_dev) return USIM_ERR_INVALID;
+    DevIO io{}; io.mask = mask_dev; io.obs = obs_dev; io.reset_params = params_dev;
+    return launch(h, io, LF_RESET_ONLY, 0, stream);
+}
+
+static int fill_io(const usim_step_io* s, DevIO& io, bool need_act) {
+    if (!s || !s->obs_dev || !s->rew_dev || !s->done_dev || (need_act && !s->act_dev)) return USIM_ERR_INVALID;
+    io = DevIO{};
+    io.act = s->act_dev; io.obs = s->obs_dev; io.rew = s->rew_dev; io.done = s->done_dev; io.term_obs = s->term_obs_dev;
+    io.contacts = s->contacts_dev; io.ep_ret = s->ep_return_dev; io.ep_len = s->ep_length_dev;
+    return USIM_OK;
+}
+
+int usim_step(usim_handle* h, const usim_step_io* s, int auto_reset, void* stream) {
+    if (!h) return USIM_ERR_INVALID;
+    DevIO io; int rc = fill_io(s, io, true);
+    if (rc) return rc;
+    return launch(h, io, auto_reset ? LF_AUTO_RESET : 0, 0, stream);
+}
+
+int usim_random_actions(usim_handle* h, int64_t step, float* act_dev, void* stream) {
+    if (!h || !act_dev) return USIM_ERR_INVALID;
+    hipLaunchKernelGGL(usim_random_actions_kernel, dim3((h->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->C, h->n, (long long)step, act_dev);
+    HIPCHK(h, hipGetLastError());
+    return USIM_OK;
+}
+
+int usim_rollout_random(usim_handle* h, int64_t first_step, int nsteps, const usim_step_io* s, void* stream) {
+    if (!h || nsteps < 0) return USIM_ERR_INVALID;
+    DevIO io; int rc = fill_io(s, io, false);
+    if (rc) return rc;
+    io.act = nullptr;
+    for (int k = 0; k < nsteps; ++k) {
+        rc = launch(h, io, LF_AUTO_RESET | LF_RANDOM_ACT, (long long)(first_step + k), stream);
+        if (rc) return rc;
+    }
+    return USIM_OK;
+}
+
+int usim_time_steps(usim_handle* h, int64_t first_step, int nsteps, const usim_step_io* s, void* stream, float* elapsed_ms) {
+    if (!h || !elapsed_ms) return USIM_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(h, hipEventRecord(h->ev0, st));
+    int rc = usim_rollout_random(h, first_step, nsteps, s, stream);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev1, st));
+    HIPCHK(h, hipEventSynchronize(h->ev1));
+    HIPCHK(h, hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+    return USIM_OK;
+}
+
+int usim_get_state(usim_handle* h, float* scalars, float* lattice) {
+    if (!h || !scalars) return USIM_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    std::vector<float> buf((size_t)h->nfields * h->npad);
+    HIPCHK(h, hipMemcpy(buf.data(), h->state, buf.size() * sizeof(float), hipMemcpyDeviceToHost));
+    const int int_fields[4] = {F_T, F_TOUCH, F_EPISODE, F_STATUS};
+    for (int i = 0; i < h->n; ++i) {
+        for (int f = 0; f < F_NSCALAR; ++f) scalars[(size_t)i * USIM_NSCALAR + f] = buf[(size_t)f * h->npad + i];
+        for (int k = 0; k < 4; ++k) {
+            int v; std::memcpy(&v, &buf[(size_t)int_fields[k] * h->npad + i], 4);
+            scalars[(size_t)i * USIM_NSCALAR + int_fields[k]] = (float)v;
+        }
+        if (lattice && h->n_el)
+            for (int e = 0; e < h->n_el; ++e) {
+                lattice[((size_t)i * h->n_el + e) * 2] = buf[(size_t)(F_S + e) * h->npad + i];
+                lattice[((size_t)i * h->n_el + e) * 2 + 1] = buf[(size_t)(F_SD + e) * h->npad + i];
+            }
+    }
+    return USIM_OK;
+}
+
+int usim_set_state(usim_handle* h, const float* scalars, const float* lattice) {
+    if (!h || !scalars) return USIM_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    std::vector<float> buf((size_t)h->nfields * h->npad);
+    HIPCHK(h, hipMemcpy(buf.data(), h->state, buf.size() * sizeof(float), hipMemcpyDeviceToHost));
+    const int int_fields[4] = {F_T, F_TOUCH, F_EPISODE, F_STATUS};
+    for (int i = 0; i < h->n; ++i) {
+        for (int f = 0; f < F_NSCALAR; ++f) buf[(size_t)f * h->npad + i] = scalars[(size_t)i * USIM_NSCALAR + f];
+        for (int k = 0; k < 4; ++k) {
+            int v = (int)scalars[(size_t)i * USIM_NSCALAR + int_fields[k]];
+            std::memcpy(&buf[(size_t)int_fields[k] * h->npad + i], &v, 4);
+        }
+        if (lattice && h->n_el)
+            for (int e = 0; e < h->n_el; ++e) {
+                buf[(size_t)(F_S + e) * h->npad + i] = lattice[((size_t)i * h->n_el + e) * 2];
+                buf[(size_t)(F_SD + e) * h->npad + i] = lattice[((size_t)i * h->n_el + e) * 2 + 1];
+            }
+    }
+    HIPCHK(h, hipMemcpy(h->state, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice));
+    return USIM_OK;
+}
+
+const char* usim_strerror(int status) {
+    switch (status) {
+        case USIM_OK: return "ok";
+        case USIM_ERR_INVALID: return "invalid argument or configuration";
+        case USIM_ERR_NO_DEVICE: return "no usable HIP device";
+        case USIM_ERR_HIP: return "HIP runtime error (see usim_last_hip_error)";
+        case USIM_ERR_ALLOC: return "allocation failed";
+        case USIM_ERR_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown usim status";
+    }
+}
+const char* usim_last_hip_error(const usim_handle* h) { return h ? h->hip_err.c_str() : ""; }
+const char* usim_version(void) { return "usim 0.1 (gfx950)"; }
+
+}  // extern "C"

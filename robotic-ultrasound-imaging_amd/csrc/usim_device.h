@@ -1,0 +1,63 @@
+// usim_device.h -- data layout shared by the HIP kernels (usim_kernels.hip) and the host side of the C ABI
+// (usim_api.hip).  gfx950 only.
+//
+// HBM layout: every per-environment quantity is a float32 (or int32 bit pattern) array
+// over environments, `field f of env i` at state[f * n_pad + i] -- struct-of-arrays with the environment as
+// the fastest index, so a wave64 touching one field of 64 consecutive environments reads one aligned 256-byte
+// row.  n_pad is n rounded up to the workgroup width.
+#pragma once
+#include <stdint.h>
+
+namespace usim {
+
+constexpr int NJ = 7;
+constexpr int OBS_DIM = 19;
+constexpr int MAXC = 8;
+constexpr int N_TOP = 99;         // dynamic torso elements (top face of the 9x4x11 shell, soft_box.xml:9)
+constexpr int LAT_NA = 9;         // lattice ix count (outer index of the shell order)
+constexpr int LAT_NC = 11;        // lattice iz count (inner index)
+constexpr int LINV_BLK = 8;       // row block of the blocked lattice inverse
+constexpr int LINV_NBLK = 13;     // ceil(99 / 8)
+constexpr int WG = 64;            // one wave64 per workgroup: one environment per lane
+
+// scalar state fields (same order as usim_get_state's [n][USIM_NSCALAR] block)
+enum Field : int {
+    F_Q = 0, F_QD = 7, F_Q0 = 14, F_TS = 21, F_TE = 24, F_U0 = 27, F_VBAR = 28, F_FZBAR = 29, F_FZPREV = 30,
+    F_DFZ = 31, F_KST = 32, F_KDMP = 33, F_MU = 34, F_T = 35, F_TOUCH = 36, F_EPISODE = 37, F_EPRET = 38,
+    F_STATUS = 39, F_NSCALAR = 40,
+    F_S = 40,                       // s[e]   at F_S + e
+    F_SD = 40 + N_TOP,              // sd[e]  at F_SD + e
+    F_TOTAL_TOP = 40 + 2 * N_TOP
+};
+
+// model constants (host-built in fp64, narrowed once; passed to the kernels by value -> kernarg/SGPRs)
+struct DevModel {
+    float m7, c7[3], I7[6];         // link-7 composite (link7 + hand + probe): mass, COM, inertia about COM (xx,xy,xz,yy,yz,zz), link-7 frame
+    float site7[3], hand7[3];       // eef site / right_hand origin in the link-7 frame
+    float pcom7[3], pI7[6];         // probe body alone (torque sensor), link-7 frame
+    float torso[3];                 // torso centre at spawn, base-centred world axes
+    float grot[9];                  // rotation matrix of goal_quat (row-major)
+    float gquat[4];                 // goal_quat (x,y,z,w)
+    float base[3];                  // robot base in world coordinates
+    float invw, wfix, wten;         // contact regulariser scale, lattice soft-equality weights
+};
+
+struct DevCfg {
+    int mode, horizon, early_term, det_traj, rand_solref, rand_pos, rand_fric, torso_drop;
+    int pgs_iters, ik_iters, env_offset, adim;
+    uint32_t key0, key1;
+    float dt, kp_fixed, damping_ratio, kp_min, kp_max, out_pos, out_ori;
+    float stiffness, damping, elem_fric, probe_fric, probe_r, probe_hl;
+};
+
+struct DevIO {
+    const float* act;               // [n][A] or nullptr (in-kernel synthetic actions)
+    float* obs; float* rew; uint8_t* done;
+    float* term_obs; int* contacts; float* ep_ret; int* ep_len;
+    const uint8_t* mask;            // reset mask (reset-only launches)
+    const float* reset_params;      // [n][13] explicit reset draws or nullptr
+};
+
+enum LaunchFlags : int { LF_AUTO_RESET = 1, LF_RESET_ONLY = 2, LF_RANDOM_ACT = 4 };
+
+}  // namespace usim

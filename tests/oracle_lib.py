@@ -71,6 +71,7 @@ class Oracle:
         L.uso_set_state.argtypes = [C.c_void_p, _dp, _dp]
         L.uso_random_actions.argtypes = [C.c_void_p, C.c_int64, _dp]
         L.uso_debug_forward.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.uso_last_info.argtypes = [C.c_void_p, _dp]
         L.uso_distance_quat.argtypes = [_dp, _dp]
         L.uso_distance_quat.restype = C.c_double
         L.uso_difference_quat.argtypes = [_dp, _dp, _dp]
@@ -135,6 +136,14 @@ class Oracle:
         a = np.zeros((self.n, self.adim))
         self.lib.uso_random_actions(self.h, int(step), _ptr(a))
         return a
+
+    def last_info(self):
+        """per env: cause bitmask (1 horizon, 2 joint limit, 4 position, 8 orientation, 16 lost contact), pos_err_norm,
+        ori_err, joint-limit margin, smallest |contact distance|, ncon, reward"""
+        out = np.zeros((self.n, 8))
+        self.lib.uso_last_info(self.h, _ptr(out))
+        return {"cause": out[:, 0].astype(int), "pos_err": out[:, 1], "ori_err": out[:, 2], "joint_margin": out[:, 3],
+                "contact_margin": out[:, 4], "ncon": out[:, 5].astype(int), "reward": out[:, 6]}
 
     def debug_forward(self, env=0):
         out = np.zeros(128)
