@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s of the batched Ultrasound step at 4096 envs/GPU, random-action rollout
+(BASELINE.json metric).  One process per GPU; for N > 1 the driver launches this file under torch.distributed.run.
+
+A "step" is one env.step() of every environment of the rank (controller + forward dynamics + soft contact + sensors +
+reward + termination + auto-reset), actions drawn in-kernel from the counter-based stream of BASELINE.md section 4,
+transitions written into rollout blocks in HBM; with N > 1 each finished block is all-gathered over RCCL on a side
+stream.  Prints ONE JSON line on rank 0."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for p in (str(ROOT), str(ROOT / "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0              # MI355X HBM3E peak (guides/MI355X_MICROARCH.md)
+FP32_VALU_PEAK_TFLOPS = 157.3
+# algorithmic bytes per env-step: compulsory fp32 state read+write with state resident in HBM
+ALGO_BYTES = {"rigid": 316, "soft": 1912}
+# algorithmic flops per env-step of this build's step
+ALGO_FLOPS = {"rigid": 9.0e3, "soft": 5.5e4}
+WORKLOAD_NAME = {"rigid": "configs[1]: 4096 envs/GPU, rigid torso (contact solver off), OSC controller only",
+                 "soft": "configs[2]: 4096 envs/GPU, soft-torso contact + force/velocity-tracking reward"}
+
+
+def cpu_baseline(workload, n_envs, budget_s=15.0):
+    """The oracle (kind "port": the reference's own mujoco-py path cannot run) timed on this box's host
+    cores with OpenMP over environments, on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle_lib import Oracle, build_oracle
+    native = True
+    try:
+        build_oracle(native=True)
+    except Exception:
+        native = False
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    ora = Oracle(n_envs, precision="f64", omp=True, native=native, torso="top" if workload == "soft" else "none", seed=3)
+    ora.reset()
+    acts = [ora.random_actions(k) for k in range(4)]
+    t0 = time.perf_counter()
+    for k in range(4):
+        ora.step(acts[k])
+    per_step = (time.perf_counter() - t0) / 4
+    steps = int(max(8, min(2000, budget_s / max(per_step, 1e-6))))
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ora.step(acts[k % 4])
+    dt = time.perf_counter() - t0
+    return {"value": n_envs * steps / dt, "unit": "env-steps/s", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
+            "sample": f"{n_envs} envs x {steps} steps of the same workload, fp64 C oracle, OpenMP over envs, "
+                      f"{'-O3 -march=native' if native else '-O3'}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--workload", choices=["soft", "rigid"], default="soft")
+    ap.add_argument("--block", type=int, default=128, help="rollout block length T (steps per all-gather)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU: the simulator has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    usim = importlib.import_module("robotic-ultrasound-imaging_amd")
+    from importlib import import_module
+    dmod = import_module("robotic-ultrasound-imaging_amd.distributed")
+    n = args.envs_per_gpu
+    env = usim.UltrasoundVecEnv(n, device=device, seed=3, env_offset=rank * n, torso=args.workload, **usim.default_robosuite_kwargs())
+    T = max(1, min(args.block, args.steps))
+    blocks = [env.alloc_block(T), env.alloc_block(T)]      # double-buffered: gather block b while simulating b^1
+    gather = dmod.RolloutGather(device=device) if (world > 1 and not args.no_gather) else None
+
+    env.reset_tensor()
+    step = 0
+    done_w = 0
+    while done_w < args.warmup:                            # untimed warm-up steps
+        k = min(T, args.warmup - done_w)
+        env.rollout_random(step, k, blocks[0]); step += k; done_w += k
+    if gather is not None:
+        gather.gather_async(blocks[0]); gather.wait()
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    sync()
+    t0 = time.perf_counter()
+    done_s, b, dev_ms = 0, 0, 0.0
+    while done_s < args.steps:                             # EXACTLY args.steps timed steps
+        k = min(T, args.steps - done_s)
+        dev_ms += env.time_steps(step, k, blocks[b]) if gather is None else 0.0
+        if gather is not None:
+            gather.wait()                                  # previous block's gather (overlapped with this block's launch queue)
+            env.rollout_random(step, k, blocks[b])
+            gather.gather_async(blocks[b])
+        step += k; done_s += k; b ^= 1
+    if gather is not None:
+        gather.wait()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel-duration leg of the roofline: HIP events around the same launches on the launch stream (rank 0, N == 1 path)
+    if gather is not None:
+        dev_ms = env.time_steps(step, min(256, args.steps), blocks[0]); kern_steps = min(256, args.steps)
+    else:
+        kern_steps = args.steps
+    avg_kernel_s = dev_ms * 1e-3 / kern_steps
+    achieved_gbs = ALGO_BYTES[args.workload] * n / avg_kernel_s / 1e9
+    valu_tflops = ALGO_FLOPS[args.workload] * n / avg_kernel_s / 1e12
+
+    if rank == 0:
+        total_steps = args.steps * n * world
+        out = {
+            "metric": "env-steps/sec (whole node) at 4096 envs/GPU, random-action rollout",
+            "value": total_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOAD_NAME[args.workload], "envs_per_gpu": n, "global_envs": n * world,
+                       "controller": "OSC_POSE impedance_mode=tracking", "rollout_block": T,
+                       "parallelism": f"env-shard x{world}" + (" + RCCL all-gather of transition blocks" if gather is not None else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_env_step": ALGO_BYTES[args.workload],
+                         "avg_kernel_us": avg_kernel_s * 1e6, "kernel": "usim_step_kernel",
+                         "valu_fp32_tflops": valu_tflops, "valu_frac": valu_tflops / FP32_VALU_PEAK_TFLOPS,
+                         "note": "kernel is FP32-VALU/latency bound at 4096 envs (64 waves on 256 CUs), not HBM bound; see DESIGN.md section 5"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, n)
+        print(json.dumps(out))
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

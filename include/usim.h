@@ -86,6 +86,7 @@ typedef struct usim_step_io {
     int32_t* contacts_dev;     /* [n][1+USIM_MAXC] count, then ascending shell-element ids (ultrasound.py:673-736) */
     float* ep_return_dev;      /* [n]      SB3 Monitor infos[i]["episode"]["r"]; written where done */
     int32_t* ep_length_dev;    /* [n]      SB3 Monitor infos[i]["episode"]["l"]; written where done */
+    float* act_out_dev;        /* [n][A]   usim_rollout_random only: the actions drawn in-kernel (completes the transition) */
 } usim_step_io;
 
 /* fills *c with the shipped configuration (src/rl_config.yaml) */
@@ -117,12 +118,14 @@ int usim_step(usim_handle* h, const usim_step_io* io, int auto_reset, void* stre
 int usim_random_actions(usim_handle* h, int64_t step, float* act_dev, void* stream);
 
 /* Enqueues nsteps consecutive steps whose actions are drawn in-kernel from the same stream as
- * usim_random_actions(first_step + k) (io->act_dev ignored). */
-int usim_rollout_random(usim_handle* h, int64_t first_step, int nsteps, const usim_step_io* io, void* stream);
+ * usim_random_actions(first_step + k) (io->act_dev ignored).  block_advance == 0: every step writes the same
+ * buffers.  block_advance != 0: the non-NULL buffers of io are rollout blocks [nsteps][n][...] and step k writes
+ * slice k (SB3 RolloutBuffer layout, the unit that is all-gathered across GPUs). */
+int usim_rollout_random(usim_handle* h, int64_t first_step, int nsteps, const usim_step_io* io, int block_advance, void* stream);
 
 /* Like usim_rollout_random, bracketed by HIP events on `stream`; blocks until done and returns the elapsed
  * device time in milliseconds (bench.py roofline leg). */
-int usim_time_steps(usim_handle* h, int64_t first_step, int nsteps, const usim_step_io* io, void* stream, float* elapsed_ms);
+int usim_time_steps(usim_handle* h, int64_t first_step, int nsteps, const usim_step_io* io, int block_advance, void* stream, float* elapsed_ms);
 
 /* Checkpoint / inspection.  Host buffers; synchronises the device.
  * scalars [n][USIM_NSCALAR]: q[0..6] qd[7..13] q0[14..20] traj_start[21..23] traj_end[24..26] u0[27] vbar[28]

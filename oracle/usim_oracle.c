@@ -101,7 +101,7 @@ static const double PROBE_POS[3] = {-0.004, -0.063, 0.128};   /* ultrasound_prob
 /* The probe mesh is missing from the reference snapshot (.MISSING_LARGE_BLOBS:1): stand-in geometry */
 static const double PROBE_COM[3] = {0.0013, 0.021, -0.043};
 static const double PROBE_INERTIA[3] = {1.6e-3, 1.6e-3, 2.0e-4};
-#define PROBE_RADIUS 0.030
+#define PROBE_RADIUS 0.040
 #define PROBE_HALFLEN 0.020
 /* capsule axis = probe-frame y, centre one radius behind the tip (tip == grip_site) */
 
@@ -112,6 +112,10 @@ static const double PROBE_INERTIA[3] = {1.6e-3, 1.6e-3, 2.0e-4};
 #define LAT_SPACING 0.035
 #define ELEM_RADIUS 0.0075
 #define ELEM_HALFLEN 0.025
+/* collision geometry of an element = the outer cap sphere of its capsule (centre one radius behind the tip).  The
+ * shaft is ignored: against the primitive probe stand-in it only produces inward-pointing normals at deep
+ * penetration (deviations) */
+#define ELEM_COLL_HALFLEN 0.0
 #define ELEM_MASS 0.01
 #define N_SHELL 270
 #define N_TOP 99
@@ -637,8 +641,8 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
             real tip[3], p2[3], d2[3], c1[3], c2[3], d[3];
             for (int a = 0; a < 3; a++) tip[a] = m->torso_c[a] + m->el_pos[e][a] + (E->s[e] - (real)ELEM_RADIUS) * m->el_axis[e][a];
             tip[2] += dz;
-            v3addscl(p2, tip, m->el_axis[e], (real)(-2 * ELEM_HALFLEN));
-            v3set(d2, m->el_axis[e][0] * (real)(2 * ELEM_HALFLEN), m->el_axis[e][1] * (real)(2 * ELEM_HALFLEN), m->el_axis[e][2] * (real)(2 * ELEM_HALFLEN));
+            v3addscl(p2, tip, m->el_axis[e], (real)(-2 * ELEM_COLL_HALFLEN));
+            v3set(d2, m->el_axis[e][0] * (real)(2 * ELEM_COLL_HALFLEN), m->el_axis[e][1] * (real)(2 * ELEM_COLL_HALFLEN), m->el_axis[e][2] * (real)(2 * ELEM_COLL_HALFLEN));
             seg_seg(p1, d1, p2, d2, c1, c2);
             v3sub(d, c1, c2);
             real len = v3norm(d), dist = len - (real)(S->cfg.probe_radius + ELEM_RADIUS);

@@ -32,7 +32,8 @@ class UsimConfig(C.Structure):
 class UsimStepIO(C.Structure):
     """struct usim_step_io (include/usim.h); all members are device pointers"""
     _fields_ = [(n, C.c_void_p) for n in (
-        "act_dev", "obs_dev", "rew_dev", "done_dev", "term_obs_dev", "contacts_dev", "ep_return_dev", "ep_length_dev")]
+        "act_dev", "obs_dev", "rew_dev", "done_dev", "term_obs_dev", "contacts_dev", "ep_return_dev", "ep_length_dev",
+        "act_out_dev")]
 
 
 # every exported symbol of include/usim.h: name -> (restype, argtypes)
@@ -47,8 +48,8 @@ SYMBOLS = {
     "usim_reset_explicit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "usim_step": (C.c_int, [C.c_void_p, C.POINTER(UsimStepIO), C.c_int, C.c_void_p]),
     "usim_random_actions": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
-    "usim_rollout_random": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(UsimStepIO), C.c_void_p]),
-    "usim_time_steps": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(UsimStepIO), C.c_void_p, C.POINTER(C.c_float)]),
+    "usim_rollout_random": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(UsimStepIO), C.c_int, C.c_void_p]),
+    "usim_time_steps": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(UsimStepIO), C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "usim_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "usim_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "usim_strerror": (C.c_char_p, [C.c_int]),

@@ -125,6 +125,8 @@ static int build_model(usim_handle* h) {
                              2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
         for (int i = 0; i < 9; ++i) M.grot[i] = (float)R[i];
         for (int i = 0; i < 4; ++i) M.gquat[i] = (float)kGoalQuat[i];
+        M.ghat[0] = (float)w; M.ghat[1] = (float)x; M.ghat[2] = (float)y; M.ghat[3] = (float)z;
+        M.geps = (float)(1.0 - nn);
     }
     const double dmax = 0.95;
     M.wfix = (float)(dmax / (1 - dmax));
@@ -197,7 +199,7 @@ int usim_default_config(usim_config* c) {
     c->deterministic_trajectory = 0; c->torso_solref_randomization = 1; c->initial_probe_pos_randomization = 1;
     c->friction_randomization = 0; c->torso_drop = 1; c->pgs_iters = 10; c->ik_iters = 8; c->env_offset = 0; c->seed = 3;
     c->control_dt = 0.002; c->kp_fixed = 300; c->damping_ratio = 1; c->kp_min = 0; c->kp_max = 500; c->out_max_pos = 0.05; c->out_max_ori = 0.5;
-    c->stiffness = 1324.17; c->damping = 17.59; c->elem_friction = 0.01; c->probe_friction = 1e-4; c->probe_radius = 0.03; c->probe_halflen = 0.02;
+    c->stiffness = 1324.17; c->damping = 17.59; c->elem_friction = 0.01; c->probe_friction = 1e-4; c->probe_radius = 0.04; c->probe_halflen = 0.02;
     return USIM_OK;
 }
 
@@ -276,7 +278,7 @@ static int fill_io(const usim_step_io* s, DevIO& io, bool need_act) {
     if (!s || !s->obs_dev || !s->rew_dev || !s->done_dev || (need_act && !s->act_dev)) return USIM_ERR_INVALID;
     io = DevIO{};
     io.act = s->act_dev; io.obs = s->obs_dev; io.rew = s->rew_dev; io.done = s->done_dev; io.term_obs = s->term_obs_dev;
-    io.contacts = s->contacts_dev; io.ep_ret = s->ep_return_dev; io.ep_len = s->ep_length_dev;
+    io.contacts = s->contacts_dev; io.ep_ret = s->ep_return_dev; io.ep_len = s->ep_length_dev; io.act_out = s->act_out_dev;
     return USIM_OK;
 }
 
@@ -294,23 +296,32 @@ int usim_random_actions(usim_handle* h, int64_t step, float* act_dev, void* stre
     return USIM_OK;
 }
 
-int usim_rollout_random(usim_handle* h, int64_t first_step, int nsteps, const usim_step_io* s, void* stream) {
+int usim_rollout_random(usim_handle* h, int64_t first_step, int nsteps, const usim_step_io* s, int block_advance, void* stream) {
     if (!h || nsteps < 0) return USIM_ERR_INVALID;
     DevIO io; int rc = fill_io(s, io, false);
     if (rc) return rc;
     io.act = nullptr;
+    const size_t n = (size_t)h->n;
     for (int k = 0; k < nsteps; ++k) {
         rc = launch(h, io, LF_AUTO_RESET | LF_RANDOM_ACT, (long long)(first_step + k), stream);
         if (rc) return rc;
+        if (block_advance) {
+            io.obs += n * OBS_DIM; io.rew += n; io.done += n;
+            if (io.term_obs) io.term_obs += n * OBS_DIM;
+            if (io.contacts) io.contacts += n * (1 + MAXC);
+            if (io.ep_ret) io.ep_ret += n;
+            if (io.ep_len) io.ep_len += n;
+            if (io.act_out) io.act_out += n * h->adim;
+        }
     }
     return USIM_OK;
 }
 
-int usim_time_steps(usim_handle* h, int64_t first_step, int nsteps, const usim_step_io* s, void* stream, float* elapsed_ms) {
+int usim_time_steps(usim_handle* h, int64_t first_step, int nsteps, const usim_step_io* s, int block_advance, void* stream, float* elapsed_ms) {
     if (!h || !elapsed_ms) return USIM_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(h, hipEventRecord(h->ev0, st));
-    int rc = usim_rollout_random(h, first_step, nsteps, s, stream);
+    int rc = usim_rollout_random(h, first_step, nsteps, s, block_advance, stream);
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->ev1, st));
     HIPCHK(h, hipEventSynchronize(h->ev1));

@@ -37,7 +37,8 @@ struct DevModel {
     float pcom7[3], pI7[6];         // probe body alone (torque sensor), link-7 frame
     float torso[3];                 // torso centre at spawn, base-centred world axes
     float grot[9];                  // rotation matrix of goal_quat (row-major)
-    float gquat[4];                 // goal_quat (x,y,z,w)
+    float gquat[4];                 // goal_quat (x,y,z,w) exactly as written at ultrasound.py:174
+    float ghat[4], geps;            // unit goal quaternion (w,x,y,z) and 1 - |goal_quat|
     float base[3];                  // robot base in world coordinates
     float invw, wfix, wten;         // contact regulariser scale, lattice soft-equality weights
 };
@@ -54,6 +55,7 @@ struct DevIO {
     const float* act;               // [n][A] or nullptr (in-kernel synthetic actions)
     float* obs; float* rew; uint8_t* done;
     float* term_obs; int* contacts; float* ep_ret; int* ep_len;
+    float* act_out;                 // [n][A] drawn actions (LF_RANDOM_ACT) or nullptr
     const uint8_t* mask;            // reset mask (reset-only launches)
     const float* reset_params;      // [n][13] explicit reset draws or nullptr
 };

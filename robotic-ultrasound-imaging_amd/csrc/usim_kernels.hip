@@ -57,7 +57,7 @@ __device__ constexpr float INITQ[NJ] = {0.f, 0.19634954084936207f, 0.f, -2.61799
 constexpr float JOINT_DAMP = 0.1f;
 constexpr float GRAV = 9.81f;
 constexpr float PROBE_MASS = 1.0f;
-constexpr float ELEM_R = 0.0075f, ELEM_HL = 0.025f, ELEM_MASS = 0.01f;
+constexpr float ELEM_R = 0.0075f, ELEM_MASS = 0.01f;
 constexpr float TORSO_DROP = 0.0047f;
 // MuJoCo default soft-constraint parameters (solref 0.02 1, solimp 0.9 0.95 0.001 0.5 2) and robosuite's impratio
 constexpr float SR_TC = 0.02f, SI_D0 = 0.9f, SI_DMAX = 0.95f, SI_WIDTH = 0.001f, IMPRATIO = 20.f;
@@ -257,28 +257,26 @@ DI void difference_quat(const float* a, const float* b, float* o) {
     o[2] = a[0] * by - a[1] * bz + a[2] * bw + a[3] * bx;
     o[3] = a[0] * bz + a[1] * by - a[2] * bx + a[3] * bw;
 }
-// distance_quat (quaternion.py:38-59) on (w,x,y,z) inputs
-DI float distance_quat(const float* q1, const float* q2) {
-    float qm[4]; difference_quat(q1, q2, qm);
-    // |q_log| = arccos(clip(w)) for a unit quaternion; evaluated as atan2(|u|, w), which is the same angle but is
-    // well conditioned in fp32 near w = +-1 (arccos loses half the mantissa there)
-    float un2 = qm[1] * qm[1] + qm[2] * qm[2] + qm[3] * qm[3];
-    float ln = (un2 == 0.f) ? 0.f : atan2f(sqrtf(un2), qm[0]);
-    float dist = 2.f * ln;
-    if (dist > PI_F) dist = fabsf(2.f * PI_F - dist);
-    return dist;
+// distance_quat(q, goal) (quaternion.py:38-59) for a unit quaternion q (w,x,y,z) and the goal quaternion as written at
+// ultrasound.py:174, whose norm is 1 - eps_g (eps_g = 1.2e-9).  The reference evaluates 2 arccos(clip(w)) with
+// w = q . g and folds distances above pi to |2 pi - d|, i.e. d = 2 arccos(|w|).  arccos loses half the mantissa near
+// |w| = 1 (where the probe spends its life), so 1 - |w| is formed without cancellation from the chord to the unit goal
+// g^:  q . g^ = 1 - |q - g^|^2 / 2  =>  1 - |w| = eps_g + (1 - eps_g) min(|q - g^|^2, |q + g^|^2) / 2,
+// and d = 4 arcsin(sqrt((1 - |w|) / 2)).  Same value as the reference formula, accurate to fp32 rounding.
+DI float distance_quat_goal(const float* q, const float* ghat, float eps_g) {
+    float dm = 0.f, dp = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { float a = q[i] - ghat[i], b = q[i] + ghat[i]; dm = fmaf(a, a, dm); dp = fmaf(b, b, dp); }
+    float m = fminf(dm, dp);
+    if (m == 0.f) return 0.f;                           // q_log: zero vector part (quaternion.py:17-18)
+    float h = eps_g + 0.5f * m * (1.f - eps_g);
+    return 4.f * asinf(sqrtf(fminf(0.5f * h, 1.f)));
 }
 
-// closest points between segments p1 + s d1 and p2 + t d2, s,t in [0,1]
-DI void seg_seg(f3 p1, f3 d1, f3 p2, f3 d2, f3& c1, f3& c2) {
-    f3 r = p1 - p2;
-    float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), c = dot(d1, r), b = dot(d1, d2);
-    float den = a * e - b * b;
-    float s = (den > 1e-12f) ? clampf((b * f - c * e) / den, 0.f, 1.f) : 0.f;
-    float t = (b * s + f) / e;
-    if (t < 0.f) { t = 0.f; s = clampf(-c / a, 0.f, 1.f); }
-    else if (t > 1.f) { t = 1.f; s = clampf((b - c) / a, 0.f, 1.f); }
-    c1 = madd(p1, d1, s); c2 = madd(p2, d2, t);
+// closest point of the segment p1 + s d1 (s in [0,1]) to the point c
+DI f3 seg_point(f3 p1, f3 d1, f3 c) {
+    float s = clampf(dot(d1, c - p1) / dot(d1, d1), 0.f, 1.f);
+    return madd(p1, d1, s);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -336,6 +334,7 @@ __global__ __launch_bounds__(WG) void usim_step_kernel(const DevModel M, const D
                 float u = u01(rr[a]);
                 bool sgn = (C.mode == 1) || (C.mode == 2 && a == 6);
                 act[a] = sgn ? 2.f * u - 1.f : u;
+                if (io.act_out && valid && a < C.adim) io.act_out[(size_t)ei * C.adim + a] = act[a];
             }
         } else {
 #pragma unroll
@@ -628,8 +627,8 @@ __global__ __launch_bounds__(WG) void usim_step_kernel(const DevModel M, const D
                     f3 ax = mk(c_el_axis[3 * e], c_el_axis[3 * e + 1], c_el_axis[3 * e + 2]);
                     float se = LDSW(L_S, e);
                     f3 tip = mk(M.torso[0] + c_el_pos[3 * e], M.torso[1] + c_el_pos[3 * e + 1], M.torso[2] + c_el_pos[3 * e + 2] + dz) + ax * (se - ELEM_R);
-                    f3 p2 = tip - ax * (2.f * ELEM_HL), d2 = ax * (2.f * ELEM_HL);
-                    f3 c1, c2; seg_seg(p1, d1, p2, d2, c1, c2);
+                    // element collision geometry = the cap sphere (centre `tip`, radius ELEM_R); DESIGN.md section 2
+                    f3 c2 = tip, c1 = seg_point(p1, d1, tip);
                     f3 dd = c1 - c2;
                     float len = sqrtf(dot(dd, dd)), dist = len - (C.probe_r + ELEM_R);
                     if (dist < 0.f) {
@@ -886,8 +885,8 @@ __global__ __launch_bounds__(WG) void usim_step_kernel(const DevModel M, const D
                     pe0 *= pe0; pe1 *= pe1;
                     pos_err_norm = sqrtf(pe0 * pe0 + pe1 * pe1);
                     float pos_rew = 5.f * expf(-pos_err_norm);
-                    float qc[4] = {qe[3], qe[0], qe[1], qe[2]}, qg[4] = {M.gquat[3], M.gquat[0], M.gquat[1], M.gquat[2]};
-                    ori_err = 0.2f * distance_quat(qc, qg);
+                    float qc[4] = {qe[3], qe[0], qe[1], qe[2]};
+                    ori_err = 0.2f * distance_quat_goal(qc, M.ghat, M.geps);
                     float ori_rew = expf(-ori_err);
                     float ve = 45.f * (vbar - 0.04f); ve *= ve;
                     float vel_rew = expf(-ve);

@@ -68,7 +68,7 @@ class UltrasoundVecEnv:
             self._ep_ret = torch.zeros(n, dtype=torch.float32, device=self.device)
             self._ep_len = torch.zeros(n, dtype=torch.int32, device=self.device)
         self._io = _lib.UsimStepIO(self._act.data_ptr(), self._obs.data_ptr(), self._rew.data_ptr(), self._done.data_ptr(),
-                                   self._term.data_ptr(), self._contacts.data_ptr(), self._ep_ret.data_ptr(), self._ep_len.data_ptr())
+                                   self._term.data_ptr(), self._contacts.data_ptr(), self._ep_ret.data_ptr(), self._ep_len.data_ptr(), None)
         self._t_start = time.time()
         self._pending = False
         self.horizon = int(self.cfg.horizon)
@@ -146,15 +146,34 @@ class UltrasoundVecEnv:
         self._check(self.lib.usim_random_actions(self._handle, int(step), out.data_ptr(), self._stream()))
         return out
 
-    def rollout_random(self, first_step, nsteps):
-        """Enqueue nsteps steps with in-kernel synthetic actions."""
-        self._check(self.lib.usim_rollout_random(self._handle, int(first_step), int(nsteps), C.byref(self._io), self._stream()))
+    def _block_io(self, block):
+        """usim_step_io over a rollout block (dict of [T, n, ...] device tensors: obs, rew, done and optionally act)."""
+        act = block.get("act")
+        return _lib.UsimStepIO(None, block["obs"].data_ptr(), block["rew"].data_ptr(), block["done"].data_ptr(), None, None, None, None,
+                               None if act is None else act.data_ptr())
 
-    def time_steps(self, first_step, nsteps):
+    def rollout_random(self, first_step, nsteps, block=None):
+        """Enqueue nsteps steps with in-kernel synthetic actions.  With `block`, step k
+        writes slice k of the [nsteps, n, ...] tensors (the transition block that is all-gathered across GPUs)."""
+        io = self._io if block is None else self._block_io(block)
+        self._check(self.lib.usim_rollout_random(self._handle, int(first_step), int(nsteps), C.byref(io), int(block is not None), self._stream()))
+
+    def time_steps(self, first_step, nsteps, block=None):
         """Same as rollout_random but bracketed by HIP events on the current stream; returns elapsed ms."""
         ms = C.c_float(0)
-        self._check(self.lib.usim_time_steps(self._handle, int(first_step), int(nsteps), C.byref(self._io), self._stream(), C.byref(ms)))
+        io = self._io if block is None else self._block_io(block)
+        self._check(self.lib.usim_time_steps(self._handle, int(first_step), int(nsteps), C.byref(io), int(block is not None), self._stream(), C.byref(ms)))
         return float(ms.value)
+
+    def alloc_block(self, nsteps, with_actions=True):
+        """Device tensors of one rollout block: obs [T,n,19], act [T,n,A], rew [T,n], done [T,n] (uint8)."""
+        n, T = self.num_envs, int(nsteps)
+        blk = {"obs": torch.zeros((T, n, _lib.OBS_DIM), dtype=torch.float32, device=self.device),
+               "rew": torch.zeros((T, n), dtype=torch.float32, device=self.device),
+               "done": torch.zeros((T, n), dtype=torch.uint8, device=self.device)}
+        if with_actions:
+            blk["act"] = torch.zeros((T, n, self.action_dim), dtype=torch.float32, device=self.device)
+        return blk
 
     @property
     def terminal_obs(self):
@@ -178,8 +197,10 @@ class UltrasoundVecEnv:
         return obs.cpu().numpy().copy()
 
     def step_async(self, actions):
-        a = torch.as_tensor(np.asarray(actions, dtype=np.float32)).reshape(self.num_envs, self.action_dim)
-        self._act.copy_(a, non_blocking=False)
+        a = np.asarray(actions, dtype=np.float32)
+        if a.shape != (self.num_envs, self.action_dim):
+            raise ValueError(f"actions must have shape {(self.num_envs, self.action_dim)}, got {a.shape}")
+        self._act.copy_(torch.from_numpy(np.ascontiguousarray(a)), non_blocking=False)
         self.step_tensor(self._act)
         self._pending = True
 

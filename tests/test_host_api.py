@@ -1,0 +1,187 @@
+"""CPU-side checks of the product's host layer: the C-ABI library loads and exports every symbol include/usim.h declares,
+the configuration translation follows the reference's rl_config.yaml schema, spaces match the reference checkpoints,
+and the GPU-only path fails loudly without a GPU (no CPU fallback)."""
+import ctypes as C
+import re
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+
+# the `robosuite:` block of /root/reference/src/rl_config.yaml:18-57 (configuration data, verbatim values)
+RL_CONFIG_YAML = """
+seed: 3
+robosuite:
+  env_id: "Ultrasound"
+  robots: "Panda"
+  use_camera_obs: False
+  use_object_obs: False
+  has_renderer: False
+  has_offscreen_renderer: False
+  render_camera: null
+  control_freq: 500
+  horizon: 1000
+  camera_names: "agentview"
+  camera_heights: 48
+  camera_widths: 48
+  camera_depths: false
+  reward_shaping: true
+  controller_configs:
+    type: "OSC_POSE"
+    input_max: 1
+    input_min: -1
+    output_max: [0.05, 0.05, 0.05, 0.5, 0.5, 0.5]
+    output_min: [-0.05, -0.05, -0.05, -0.5, -0.5, -0.5]
+    kp: 300
+    damping_ratio: 1
+    impedance_mode: "tracking"
+    kp_limits: [0, 500]
+    kp_input_max: 1
+    kp_input_min: 0
+    damping_ratio_limits: [0, 2]
+    position_limits: null
+    orientation_limits: null
+    uncouple_pos_ori: True
+    control_delta: True
+    interpolation: null
+    ramp_ratio: 0.2
+  early_termination: True
+  save_data: False
+  deterministic_trajectory: False
+  torso_solref_randomization: True
+  initial_probe_pos_randomization: True
+  use_box_torso: True
+"""
+
+
+def _declared_functions():
+    text = (ROOT / "include" / "usim.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(usim_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(usim):
+    lib = usim._lib.load()
+    declared = _declared_functions()
+    assert len(declared) >= 17
+    assert sorted(usim._lib.SYMBOLS) == declared               # the ctypes binding covers exactly the header
+    for name in declared:
+        assert getattr(lib, name) is not None
+    nm = subprocess.run(["nm", "-D", "--defined-only", str(usim._lib.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (usim_[a-z_]+)", nm))
+    assert set(declared) <= exported
+    assert lib.usim_version().decode().startswith("usim")
+    assert lib.usim_strerror(-2).decode() == "no usable HIP device"
+
+
+def test_struct_layouts_match_header(usim):
+    """ctypes structures must have the C layout of include/usim.h (compile a probe with the system compiler)."""
+    src = '#include "usim.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(usim_config), sizeof(usim_step_io), offsetof(usim_config, seed), offsetof(usim_config, control_dt), offsetof(usim_config, probe_halflen));return 0;}'
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        (Path(d) / "p.c").write_text(src)
+        subprocess.run(["gcc", "-I", str(ROOT / "include"), "-o", f"{d}/p", f"{d}/p.c"], check=True)
+        out = subprocess.run([f"{d}/p"], capture_output=True, text=True, check=True).stdout.split()
+    cfg, io = usim._lib.UsimConfig, usim._lib.UsimStepIO
+    assert [int(v) for v in out] == [C.sizeof(cfg), C.sizeof(io), cfg.seed.offset, cfg.control_dt.offset, cfg.probe_halflen.offset]
+
+
+def test_default_config_is_the_shipped_rl_config(usim, tmp_path):
+    p = tmp_path / "rl_config.yaml"
+    p.write_text(RL_CONFIG_YAML)
+    seed, kwargs = usim.load_yaml(p)
+    assert seed == 3
+    c = usim.make_config(seed=seed, **kwargs)
+    d = usim.make_config(seed=3, **usim.default_robosuite_kwargs())
+    for name, _ in usim._lib.UsimConfig._fields_:
+        assert getattr(c, name) == getattr(d, name), name
+    assert (c.mode, c.torso, c.horizon, c.early_termination) == (0, 1, 1000, 1)
+    assert (c.torso_solref_randomization, c.initial_probe_pos_randomization, c.deterministic_trajectory) == (1, 1, 0)
+    assert c.control_dt == pytest.approx(0.002) and (c.kp_min, c.kp_max) == (0.0, 500.0)
+    assert (c.stiffness, c.damping) == (1324.17, 17.59)          # soft_box.xml:9
+
+
+def test_config_rejects_what_the_reference_rejects(usim):
+    kw = usim.default_robosuite_kwargs()
+    with pytest.raises(ValueError):
+        usim.make_config(**{**kw, "robots": "Sawyer"})             # ultrasound.py:137-138
+    with pytest.raises(ValueError):
+        usim.make_config(**{**kw, "gripper_types": "PandaGripper"})  # ultrasound.py:134-135
+    with pytest.raises(ValueError):
+        usim.make_config(**{**kw, "controller_configs": {**kw["controller_configs"], "type": "JOINT_VELOCITY"}})
+    with pytest.raises(ValueError):
+        usim.make_config(**{**kw, "controller_configs": {**kw["controller_configs"], "impedance_mode": "variable"}})
+    with pytest.raises(TypeError):
+        usim.make_config(**{**kw, "no_such_option": 1})
+    fixed = usim.make_config(**{**kw, "controller_configs": {**kw["controller_configs"], "impedance_mode": "fixed"}})
+    assert fixed.mode == 1 and fixed.kp_fixed == 300.0
+
+
+def test_action_spaces_match_reference_checkpoints(usim, pins):
+    from importlib import import_module
+    ve = import_module("robotic-ultrasound-imaging_amd.vec_env")
+    for name, mode in (("tracking", 0), ("variable_z", 2)):
+        lo, hi = ve._ACTION_BOX[mode]
+        assert np.array_equal(np.array(lo), pins[name + "_action_low"]) and np.array_equal(np.array(hi), pins[name + "_action_high"])
+    b = usim.Box(np.zeros(6), np.ones(6))
+    assert b.shape == (6,) and b.dtype == np.float32 and b.contains(b.sample(np.random.default_rng(0)))
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_fails_loudly_without_gpu(usim):
+    lib = usim._lib.load()
+    cfg = usim.make_config()
+    h = C.c_void_p()
+    assert lib.usim_create(C.byref(cfg), 4, 0, C.byref(h)) == -2 and not h
+    with pytest.raises(RuntimeError, match="no usable HIP device"):
+        usim.UltrasoundVecEnv(4)
+    with pytest.raises(RuntimeError):
+        usim.UltrasoundVecEnv(4, device="cpu")
+
+
+def test_create_validates_arguments(usim):
+    lib = usim._lib.load()
+    cfg = usim.make_config()
+    h = C.c_void_p()
+    assert lib.usim_create(C.byref(cfg), 0, 0, C.byref(h)) == -1
+    cfg.probe_halflen = 0.0
+    assert lib.usim_create(C.byref(cfg), 4, 0, C.byref(h)) == -1
+    assert lib.usim_step(None, None, 1, None) == -1
+    assert lib.usim_get_state(None, None, None) == -1
+
+
+def test_missing_library_is_an_error(usim, monkeypatch, tmp_path):
+    monkeypatch.setattr(usim._lib, "_lib", None)
+    monkeypatch.setenv("USIM_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        usim._lib.load()
+    monkeypatch.delenv("USIM_LIB")
+    monkeypatch.setattr(usim._lib, "_lib", None)
+    usim._lib.load()
+
+
+def test_shard_range_partitions_exactly(usim):
+    from importlib import import_module
+    d = import_module("robotic-ultrasound-imaging_amd.distributed")
+    for total, world in ((32768, 8), (10, 3), (7, 8)):
+        r = [d.shard_range(total, world, k) for k in range(world)]
+        assert r[0][0] == 0 and r[-1][1] == total and all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+        assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+def test_pack_unpack_block_roundtrip(usim):
+    from importlib import import_module
+    d = import_module("robotic-ultrasound-imaging_amd.distributed")
+    T, n, A = 5, 7, 6
+    g = torch.Generator().manual_seed(0)
+    blk = {"obs": torch.randn(T, n, 19, generator=g), "act": torch.rand(T, n, A, generator=g), "rew": torch.randn(T, n, generator=g),
+           "done": (torch.rand(T, n, generator=g) > 0.7).to(torch.uint8)}
+    p = d.pack_block(blk)
+    assert p.shape == (T, n, 19 + A + 2)
+    u = d.unpack_block(p, A)
+    assert torch.equal(u["obs"], blk["obs"]) and torch.equal(u["act"], blk["act"]) and torch.equal(u["rew"], blk["rew"])
+    assert torch.equal(u["done"], blk["done"].bool())

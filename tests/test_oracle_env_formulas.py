@@ -1,0 +1,201 @@
+"""Oracle vs the env-level formulas that live in /root/reference/src (restated here in numpy from the cited lines)
+and vs the decoded reference fixtures (tests/golden/reference_pins.npz)."""
+import numpy as np
+import pytest
+
+from oracle_lib import Oracle
+
+GOAL_QUAT = np.array([-0.69192486, 0.72186726, -0.00514253, -0.01100909])  # ultrasound.py:174 (x,y,z,w)
+
+
+# ---- numpy transcription of src/utils/quaternion.py (transforms3d conventions: w first) ----
+def qmult(a, b):  # transforms3d.quaternions.qmult
+    w1, x1, y1, z1 = a; w2, x2, y2, z2 = b
+    return np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2])
+
+
+def difference_quat_ref(q1, q2):  # quaternion.py:23-35
+    return qmult(q1, q2 * np.array([1.0, -1, -1, -1]))
+
+
+def q_log_ref(q):  # quaternion.py:4-20
+    v = np.clip(q[0], -1, 1); u = q[1:]; n = np.linalg.norm(u)
+    return np.zeros(3) if n == 0 else np.arccos(v) * u / n
+
+
+def distance_quat_ref(q1, q2):  # quaternion.py:38-59
+    d = 2 * np.linalg.norm(q_log_ref(difference_quat_ref(q1, q2)))
+    return abs(2 * np.pi - d) if d > np.pi else d
+
+
+@pytest.fixture(scope="module")
+def ora():
+    return Oracle(1, torso="none")
+
+
+def test_quaternion_helpers_match_reference_formulas(ora):
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        a = rng.normal(size=4); a /= np.linalg.norm(a)
+        b = rng.normal(size=4); b /= np.linalg.norm(b)
+        assert np.allclose(ora.difference_quat(a, b), difference_quat_ref(a, b), atol=1e-14)
+        assert abs(ora.distance_quat(a, b) - distance_quat_ref(a, b)) < 1e-12
+    q = np.array([0.3, 0.1, -0.2, 0.9]); q /= np.linalg.norm(q)
+    assert ora.distance_quat(q, q) < 1e-7                       # identical orientations
+    assert ora.distance_quat(q, -q) < 1e-7                      # double cover folded by quaternion.py:56-57
+    half = np.array([np.cos(0.25), np.sin(0.25), 0, 0])          # rotation by 0.5 rad about x
+    assert abs(ora.distance_quat(half, np.array([1.0, 0, 0, 0])) - 0.5) < 1e-12
+
+
+def test_mat2quat_sign_convention(ora):
+    """robosuite T.mat2quat returns (x,y,z,w) with w >= 0; the goal orientation then gives the (-1,0,0,0) quaternion
+    channel seen in every decoded reset observation."""
+    x, y, z, w = GOAL_QUAT / np.linalg.norm(GOAL_QUAT)
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                  [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                  [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    q = ora.mat2quat(R)
+    assert q[3] >= 0
+    assert np.allclose(q, -GOAL_QUAT / np.linalg.norm(GOAL_QUAT), atol=1e-9)
+    d = ora.difference_quat(q, GOAL_QUAT)                        # ultrasound.py:390: xyzw arrays through the wxyz routine
+    assert np.allclose(d, [-1, 0, 0, 0], atol=1e-7)
+
+
+def test_philox_known_answers(ora):
+    # Random123 kat_vectors for philox4x32-10
+    assert list(ora.philox((0, 0, 0, 0), (0, 0))) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert list(ora.philox((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2)) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert list(ora.philox((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0))) == \
+        [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_lattice_topology():
+    o = Oracle(1, torso="top")
+    assert o.n_el == 99                                           # top face of count="9 4 11" (soft_box.xml:9)
+    assert o.lib.uso_shell_edges(o.h) == 536
+
+
+def test_reset_observation_layout_matches_fixtures(pins):
+    """Structure of the 19-vector at reset, pinned by the 3x64 decoded reset observations."""
+    ref = np.concatenate([pins[m + "_reset_obs"] for m in ("tracking", "variable_z", "wrench")])
+    o = Oracle(512)
+    obs = o.reset()
+    for a, name in ((ref, "reference"), (obs, "oracle")):
+        assert np.all(a[:, 6:9] == 0), name                        # eef_vel exactly zero at reset
+        assert np.allclose(a[:, 9], a[:, 2] - 5.0, atol=1e-9), name  # running mean initialised to Fz (:477), minus goal 5 N
+        assert np.all(a[:, 10] == 0), name                         # derivative of force
+        assert np.allclose(a[:, 11], -0.04), name                  # v_mean - goal velocity
+        assert np.allclose(a[:, 15], -1.0, atol=1e-3), name        # quaternion channel quirk
+        assert np.abs(a[:, 16:19]).max() < 1e-3, name
+        assert np.all(a[:, 2] >= 0), name                          # the torso can only push the probe up
+    # contact force is zero exactly when there is no contact
+    assert np.all((obs[:, 2] == 0) == (np.abs(obs[:, :3]).sum(1) == 0))
+
+
+def test_reset_position_noise_statistics(pins):
+    """eef - traj_pt at reset = IK bias + N(0, (sigma/4)^2) in x,y and N(0, sigma^2) in z (ultrasound.py:880-881);
+    the decoded reference rows give bias (2.8, 0.8, 6.6) mm and std (2.1, 2.3, 10.6) mm."""
+    ref = pins["tracking_reset_obs"][:, 12:15]
+    o = Oracle(4096, torso="none")
+    d = o.reset()[:, 12:15]
+    assert np.allclose(d.mean(0), [0.0028, 0.0008, 0.0066], atol=6e-4)
+    assert np.allclose(d.std(0), [0.0025, 0.0025, 0.010], rtol=0.06)
+    # the reference sample (64 rows) is statistically compatible with those parameters
+    assert np.allclose(ref.mean(0), d.mean(0), atol=4 * np.array([0.0025, 0.0025, 0.010]) / np.sqrt(64))
+    assert np.all(np.abs(ref.std(0) / d.std(0) - 1) < 0.3)
+
+
+def test_reset_force_depth_relation(pins):
+    """Contact onset and force-vs-depth at reset against the pooled reference rows:
+    no contact above z_err ~ 0.0146+, Fz ~ -4372 z_err + 57.9 N over the contacting rows."""
+    ref = np.concatenate([pins[m + "_reset_obs"] for m in ("tracking", "variable_z", "wrench")])
+    o = Oracle(4096)
+    obs = o.reset()
+    z, fz = obs[:, 14], obs[:, 2]
+    rz, rfz = ref[:, 14], ref[:, 2]
+    # onset: first contact where the eef site reaches the nominal top surface (torso centre + 0.0525 -> z_err 0.0135)
+    assert 0.0125 < z[fz > 0].max() < 0.0185
+    assert rz[rfz > 0].max() < 0.0185
+    assert np.all(fz[z > 0.0185] == 0)
+    # binned force-depth curve in the range where the reference has dense data
+    for lo, hi in ((-0.005, 0.0), (0.0, 0.005), (0.005, 0.010), (0.010, 0.015)):
+        m, r = (z >= lo) & (z < hi), (rz >= lo) & (rz < hi)
+        assert r.sum() >= 20
+        ours, theirs = fz[m].mean(), rfz[r].mean()
+        assert abs(ours - theirs) < 0.45 * theirs + 3.0, (lo, hi, ours, theirs)
+    # overall slope of the contacting rows, shallow-to-moderate penetration
+    sel = (fz > 0) & (z > -0.010)
+    rsel = (rfz > 0) & (rz > -0.010)
+    slope, slope_ref = np.polyfit(z[sel], fz[sel], 1)[0], np.polyfit(rz[rsel], rfz[rsel], 1)[0]
+    assert 0.6 < slope / slope_ref < 1.4, (slope, slope_ref)
+
+
+def test_trajectory_sampling_grid():
+    """Waypoints come from the 50 x 50 grid of ultrasound.py:787-788 at z = torso_z + 0.039 (:807)."""
+    o = Oracle(2048, torso="none")
+    o.reset()
+    st = o.get_state()
+    xs = np.linspace(-0.15 + 0.03, 0.15, 50); ys = np.linspace(-0.09, 0.09, 50)
+    for key in ("traj_start", "traj_end"):
+        p = st[key]
+        assert np.abs(p[:, 0][:, None] - xs[None]).min(1).max() < 1e-12
+        assert np.abs(p[:, 1][:, None] - ys[None]).min(1).max() < 1e-12
+        assert np.allclose(p[:, 2], 0.8572 + 0.039)
+        assert len(np.unique(np.round(p[:, 0], 9))) == 50 and len(np.unique(np.round(p[:, 1], 9))) == 50
+    assert 0 <= st["u0"].min() and st["u0"].max() < 1
+    assert set(np.unique(st["stiffness"])) <= set(range(1300, 1600)) and st["stiffness"].min() < 1310 and st["stiffness"].max() > 1590
+    assert set(np.unique(st["damping"])) <= set(range(17, 41)) and st["damping"].min() == 17 and st["damping"].max() == 40
+
+
+def test_deterministic_trajectory_option():
+    o = Oracle(4, torso="none", deterministic_trajectory=1)
+    o.reset()
+    st = o.get_state()
+    assert np.allclose(st["traj_start"], [0.062, -0.020, 0.896]) and np.allclose(st["traj_end"], [-0.032, -0.075, 0.896])   # ultrasound.py:763-764
+
+
+def _reward_from_formulas(obs_prev_stats, eef_xy_minus_traj_xy, ori_dist, contact):
+    vbar, fzbar, dfz = obs_prev_stats
+    pos_err = np.square(90 * eef_xy_minus_traj_xy)                       # ultrasound.py:247
+    r = 5 * np.exp(-np.linalg.norm(pos_err))                              # :248
+    r += 1 * np.exp(-0.2 * ori_dist)                                      # :251-252
+    r += 1 * np.exp(-np.square(45 * (vbar - 0.04)))                       # :255-256
+    if contact:
+        r += 3 * np.exp(-np.square(0.7 * (fzbar - 5)))                    # :259-260
+        r += 2 * np.exp(-np.square(0.01 * dfz))                           # :263-264
+    return r
+
+
+def test_reward_and_bookkeeping_against_formulas():
+    """One step of the oracle vs the reward / post-action formulas evaluated from its own observation channels."""
+    n = 256
+    o = Oracle(n)
+    obs0 = o.reset()
+    st0 = o.get_state()
+    for k in range(30):
+        st_prev = o.get_state()
+        obs, rew, done, term, con = o.step(o.random_actions(k), auto_reset=False)
+        st = o.get_state()
+        live = ~done
+        for i in np.nonzero(live)[0][:64]:
+            # observation channels 9-11 and the reward use the statistics from BEFORE this step's bookkeeping
+            assert obs[i, 9] == pytest.approx(st_prev["fzbar"][i] - 5.0, abs=1e-12)
+            assert obs[i, 10] == pytest.approx(st_prev["dfz"][i], abs=1e-9)
+            assert obs[i, 11] == pytest.approx(st_prev["vbar"][i] - 0.04, abs=1e-12)
+            qd = obs[i, 15:19]                                               # eef_xyzw (x) conj(goal_xyzw), index 0 as scalar
+            # recover the eef quaternion: d = q_e (x) conj(g)  =>  q_e = d (x) g / |g|^2 (same index-0-scalar algebra);
+            # goal_quat is used exactly as written at ultrasound.py:174 (|g| = 1 - 1.2e-9, which matters at tiny angles)
+            qe = qmult(qd, GOAL_QUAT) / np.dot(GOAL_QUAT, GOAL_QUAT)
+            qe_wxyz = np.array([qe[3], qe[0], qe[1], qe[2]]); g_wxyz = np.array([GOAL_QUAT[3], *GOAL_QUAT[:3]])
+            ori = distance_quat_ref(qe_wxyz, g_wxyz)
+            r = _reward_from_formulas((st_prev["vbar"][i], st_prev["fzbar"][i], st_prev["dfz"][i]), obs[i, 12:14], ori, con[i, 0] > 0)
+            assert rew[i] == pytest.approx(r, abs=2e-6)
+            # bookkeeping (ultrasound.py:538-546)
+            t = st["t"][i]
+            hv = np.linalg.norm(obs[i, 6:9])
+            assert st["vbar"][i] == pytest.approx(st_prev["vbar"][i] + (hv - st_prev["vbar"][i]) / t, abs=1e-12)
+            assert st["dfz"][i] == pytest.approx((obs[i, 2] - st_prev["fzprev"][i]) / 0.002, abs=1e-6)
+            assert st["fzbar"][i] == pytest.approx(0.1 * obs[i, 2] + 0.9 * st_prev["fzbar"][i], abs=1e-10)
+            assert st["fzprev"][i] == obs[i, 2]
+    assert st["t"].max() == 30
