@@ -63,6 +63,7 @@ typedef struct usim_config {
     int32_t pgs_iters;                         /* contact PGS sweeps per forward pass */
     int32_t ik_iters;                          /* reset inverse-kinematics iterations */
     int32_t env_offset;                        /* global index of env 0 of this handle (multi-GPU shard) */
+    int32_t lanes_per_env;                     /* soft-torso kernel mapping: 0 auto, 8 or 16 lanes per environment */
     uint64_t seed;                             /* rl_config.yaml:1 */
     double control_dt;                         /* 1 / control_freq (rl_config.yaml:26) */
     double kp_fixed, damping_ratio;            /* rl_config.yaml:38-39 */

@@ -15,17 +15,24 @@
 #include "usim_device.h"
 #include "usim_kernels.hip"      // single translation unit: kernels + host launcher (no relocatable device code)
 
-namespace usim { constexpr int LDS_WORDS_TOP_HOST = LDS_WORDS_TOP; }
 
 using namespace usim;
 
 struct usim_handle {
     usim_config cfg;
-    int n = 0, npad = 0, device = 0, adim = 6, n_el = 0, nfields = 0;
+    int n = 0, npad = 0, device = 0, adim = 6, n_el = 0, nfields = 0, lpe = 1;
     DevModel M;
     DevCfg C;
     float* state = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // reset bank machinery: refill kernels run on a side stream, one step behind the step kernels
+    hipStream_t side = nullptr;
+    hipEvent_t ev_step[2] = {nullptr, nullptr}, ev_refill[2] = {nullptr, nullptr};
+    int* d_list = nullptr;            // [2][npad] environments that consumed a bank slot at step s (ring = s & 1)
+    int* d_count = nullptr;           // [2]
+    long long step_index = 0;
+    bool refill_pending[2] = {false, false};
+    int bank_row0 = 0;
     size_t lds_bytes = 0;
     std::string hip_err;
 };
@@ -162,30 +169,30 @@ static int build_model(usim_handle* h) {
         for (int d = 0; d < nn; ++d) if (nbr[e * 4 + d] >= 0) L[(size_t)e * N_TOP + nbr[e * 4 + d]] = -0.5 * dmax / (1 - dmax);
     }
     std::vector<double> Li = invert(L, N_TOP);
-    std::vector<float> linv((size_t)N_TOP * N_TOP), blk((size_t)LINV_NBLK * N_TOP * LINV_BLK, 0.f);
-    for (int i = 0; i < N_TOP; ++i) for (int j = 0; j < N_TOP; ++j) {
-        linv[(size_t)i * N_TOP + j] = (float)Li[(size_t)i * N_TOP + j];
-        blk[((size_t)(i / LINV_BLK) * N_TOP + j) * LINV_BLK + (i % LINV_BLK)] = (float)Li[(size_t)i * N_TOP + j];
-    }
-    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(c_el_pos), elpos.data(), elpos.size() * 4));
-    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(c_el_axis), elaxis.data(), elaxis.size() * 4));
-    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(c_el_nbr), nbr.data(), nbr.size() * 4));
-    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(c_el_shell), shell.data(), shell.size() * 4));
-    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(c_linv), linv.data(), linv.size() * 4));
-    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(c_linv_blk), blk.data(), blk.size() * 4));
+    // one table block, laid out exactly as the kernels' workgroup-resident LDS copy
+    std::vector<float> tb(TB_WORDS, 0.f);
+    for (int i = 0; i < N_TOP; ++i) for (int j = 0; j < N_TOP; ++j) tb[TB_LINV + (size_t)i * LROW + j] = (float)Li[(size_t)i * N_TOP + j];
+    for (int i = 0; i < N_TOP * 3; ++i) { tb[TB_POS + i] = elpos[i]; tb[TB_AXIS + i] = elaxis[i]; }
+    std::memcpy(&tb[TB_NBR], nbr.data(), nbr.size() * sizeof(int));
+    std::memcpy(&tb[TB_SHELL], shell.data(), shell.size() * sizeof(int));
+    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(c_tables), tb.data(), tb.size() * sizeof(float)));
     return USIM_OK;
 }
 
-template <int TORSO>
+template <int TORSO, int G, int MODE>
 static hipError_t launch_step(usim_handle* h, const DevIO& io, int flags, long long rstep, hipStream_t s) {
-    dim3 grid(h->npad / WG), block(WG);
-    hipLaunchKernelGGL(usim_step_kernel<TORSO>, grid, block, h->lds_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
+    dim3 grid((h->n + GroupGeom<G>::EPB - 1) / GroupGeom<G>::EPB), block(GroupGeom<G>::NT);
+    hipLaunchKernelGGL((usim_step_kernel<TORSO, G, MODE>), grid, block, h->lds_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
     return hipGetLastError();
 }
 
-static int launch(usim_handle* h, const DevIO& io, int flags, long long rstep, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    hipError_t e = h->n_el ? launch_step<1>(h, io, flags, rstep, s) : launch_step<0>(h, io, flags, rstep, s);
+template <int MODE>
+static int launch(usim_handle* h, DevIO io, int flags, long long rstep, hipStream_t s) {
+    io.bank_row0 = h->bank_row0;
+    hipError_t e;
+    if (!h->n_el) e = launch_step<0, 1, MODE>(h, io, flags, rstep, s);
+    else if (h->lpe == 8) e = launch_step<1, 8, MODE>(h, io, flags, rstep, s);
+    else e = launch_step<1, 16, MODE>(h, io, flags, rstep, s);
     if (e != hipSuccess) { h->hip_err = std::string("usim_step_kernel launch: ") + hipGetErrorString(e); return USIM_ERR_HIP; }
     return USIM_OK;
 }
@@ -197,7 +204,7 @@ int usim_default_config(usim_config* c) {
     std::memset(c, 0, sizeof *c);
     c->mode = USIM_MODE_TRACKING; c->torso = USIM_TORSO_TOP; c->horizon = 1000; c->early_termination = 1;
     c->deterministic_trajectory = 0; c->torso_solref_randomization = 1; c->initial_probe_pos_randomization = 1;
-    c->friction_randomization = 0; c->torso_drop = 1; c->pgs_iters = 10; c->ik_iters = 8; c->env_offset = 0; c->seed = 3;
+    c->friction_randomization = 0; c->torso_drop = 1; c->pgs_iters = 8; c->ik_iters = 5; c->env_offset = 0; c->lanes_per_env = 0; c->seed = 3;
     c->control_dt = 0.002; c->kp_fixed = 300; c->damping_ratio = 1; c->kp_min = 0; c->kp_max = 500; c->out_max_pos = 0.05; c->out_max_ori = 0.5;
     c->stiffness = 1324.17; c->damping = 17.59; c->elem_friction = 0.01; c->probe_friction = 1e-4; c->probe_radius = 0.04; c->probe_halflen = 0.02;
     return USIM_OK;
@@ -227,14 +234,32 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
     C.damping = (float)cfg->damping; C.elem_fric = (float)cfg->elem_friction; C.probe_fric = (float)cfg->probe_friction;
     C.probe_r = (float)cfg->probe_radius; C.probe_hl = (float)cfg->probe_halflen;
     h->nfields = h->n_el ? F_TOTAL_TOP : F_NSCALAR;
-    size_t bytes = (size_t)h->nfields * h->npad * sizeof(float);
+    h->bank_row0 = h->nfields;                                  // two reset-bank slots follow the live state rows
+    size_t bytes = (size_t)(h->nfields + 2 * BANK_WORDS) * h->npad * sizeof(float);
     HIPCHK(h, hipMalloc(&h->state, bytes));
     HIPCHK(h, hipMemset(h->state, 0, bytes));
+    HIPCHK(h, hipMalloc(&h->d_list, 2 * (size_t)h->npad * sizeof(int)));
+    HIPCHK(h, hipMalloc(&h->d_count, 2 * sizeof(int)));
+    HIPCHK(h, hipMemset(h->d_count, 0, 2 * sizeof(int)));
     HIPCHK(h, hipEventCreate(&h->ev0));
     HIPCHK(h, hipEventCreate(&h->ev1));
-    h->lds_bytes = h->n_el ? (size_t)LDS_WORDS_TOP_HOST * WG * sizeof(float) : 0;
-    if (h->n_el)
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    for (int r = 0; r < 2; ++r) {
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_step[r], hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_refill[r], hipEventDisableTiming));
+    }
+    // kernel mapping: rigid torso -> one environment per lane; soft torso -> 8 or 16 lanes per
+    // environment (auto = 16, which puts one 4-wave workgroup on every CU at 4096 envs/GPU)
+    h->lpe = h->n_el ? (cfg->lanes_per_env == 0 ? 16 : cfg->lanes_per_env) : 1;
+    if (h->n_el && h->lpe != 8 && h->lpe != 16) return USIM_ERR_INVALID;
+    h->lds_bytes = 0;
+    if (h->n_el) {
+        h->lds_bytes = (size_t)(h->lpe == 8 ? GroupGeom<8>::LDS_WORDS : GroupGeom<16>::LDS_WORDS) * sizeof(float);
+        const void* fn0 = h->lpe == 8 ? reinterpret_cast<const void*>(&usim_step_kernel<1, 8, 0>) : reinterpret_cast<const void*>(&usim_step_kernel<1, 16, 0>);
+        const void* fn1 = h->lpe == 8 ? reinterpret_cast<const void*>(&usim_step_kernel<1, 8, 1>) : reinterpret_cast<const void*>(&usim_step_kernel<1, 16, 1>);
+        HIPCHK(h, hipFuncSetAttribute(fn0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+        HIPCHK(h, hipFuncSetAttribute(fn1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    }
     // contact regulariser scale: translational inverse weight of the probe at init_qpos (device, one lane) + element
     {
         float* d_w = nullptr; float w = 0.f;
@@ -252,7 +277,12 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
 void usim_destroy(usim_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
     if (h->state) (void)hipFree(h->state);
+    if (h->d_list) (void)hipFree(h->d_list);
+    if (h->d_count) (void)hipFree(h->d_count);
+    if (h->side) (void)hipStreamDestroy(h->side);
+    for (int r = 0; r < 2; ++r) { if (h->ev_step[r]) (void)hipEventDestroy(h->ev_step[r]); if (h->ev_refill[r]) (void)hipEventDestroy(h->ev_refill[r]); }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -262,16 +292,29 @@ int usim_num_envs(const usim_handle* h) { return h ? h->n : USIM_ERR_INVALID; }
 int usim_action_dim(const usim_handle* h) { return h ? h->adim : USIM_ERR_INVALID; }
 int usim_num_elements(const usim_handle* h) { return h ? h->n_el : USIM_ERR_INVALID; }
 
+// direct reset of the selected environments followed by the two bank fills (episodes +1 and +2), all on `stream`
+static int reset_common(usim_handle* h, const uint8_t* mask_dev, const float* params_dev, float* obs_dev, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    // outstanding refills target bank slots this reset is about to recompute
+    for (int r = 0; r < 2; ++r)
+        if (h->refill_pending[r]) { HIPCHK(h, hipStreamWaitEvent(s, h->ev_refill[r], 0)); h->refill_pending[r] = false; }
+    DevIO io{}; io.mask = mask_dev; io.obs = obs_dev; io.reset_params = params_dev; io.ahead = 0;
+    int rc = launch<1>(h, io, 0, 0, s);
+    for (int ahead = 1; ahead <= 2 && rc == USIM_OK; ++ahead) {
+        DevIO b{}; b.mask = mask_dev; b.ahead = ahead;
+        rc = launch<1>(h, b, 0, 0, s);
+    }
+    return rc;
+}
+
 int usim_reset(usim_handle* h, const uint8_t* mask_dev, float* obs_dev, void* stream) {
     if (!h) return USIM_ERR_INVALID;
-    DevIO io{}; io.mask = mask_dev; io.obs = obs_dev;
-    return launch(h, io, LF_RESET_ONLY, 0, stream);
+    return reset_common(h, mask_dev, nullptr, obs_dev, stream);
 }
 
 int usim_reset_explicit(usim_handle* h, const uint8_t* mask_dev, const float* params_dev, float* obs_dev, void* stream) {
     if (!h || !params_dev) return USIM_ERR_INVALID;
-    DevIO io{}; io.mask = mask_dev; io.obs = obs_dev; io.reset_params = params_dev;
-    return launch(h, io, LF_RESET_ONLY, 0, stream);
+    return reset_common(h, mask_dev, params_dev, obs_dev, stream);
 }
 
 static int fill_io(const usim_step_io* s, DevIO& io, bool need_act) {
@@ -282,11 +325,34 @@ static int fill_io(const usim_step_io* s, DevIO& io, bool need_act) {
     return USIM_OK;
 }
 
+// One step on `stream`.  With auto-reset the step kernel of step s appends the environments that consumed a bank slot to
+// list[s & 1]; the refill kernel for that list runs on the side stream and only has to be finished before step s + 2
+// (an environment reset at step s can finish again at s + 1 at the earliest, which takes the OTHER slot).
+static int step_common(usim_handle* h, DevIO io, int flags, long long rstep, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!(flags & LF_AUTO_RESET)) return launch<0>(h, io, flags, rstep, s);
+    const int ring = (int)(h->step_index & 1);
+    if (h->refill_pending[ring]) { HIPCHK(h, hipStreamWaitEvent(s, h->ev_refill[ring], 0)); h->refill_pending[ring] = false; }
+    io.list_out = h->d_list + (size_t)ring * h->npad; io.count = h->d_count + ring;
+    int rc = launch<0>(h, io, flags, rstep, s);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_step[ring], s));
+    HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_step[ring], 0));
+    DevIO b{}; b.list = h->d_list + (size_t)ring * h->npad; b.count = h->d_count + ring; b.ahead = 2;
+    rc = launch<1>(h, b, 0, 0, h->side);
+    if (rc) return rc;
+    HIPCHK(h, hipMemsetAsync(h->d_count + ring, 0, sizeof(int), h->side));
+    HIPCHK(h, hipEventRecord(h->ev_refill[ring], h->side));
+    h->refill_pending[ring] = true;
+    h->step_index += 1;
+    return USIM_OK;
+}
+
 int usim_step(usim_handle* h, const usim_step_io* s, int auto_reset, void* stream) {
     if (!h) return USIM_ERR_INVALID;
     DevIO io; int rc = fill_io(s, io, true);
     if (rc) return rc;
-    return launch(h, io, auto_reset ? LF_AUTO_RESET : 0, 0, stream);
+    return step_common(h, io, auto_reset ? LF_AUTO_RESET : 0, 0, stream);
 }
 
 int usim_random_actions(usim_handle* h, int64_t step, float* act_dev, void* stream) {
@@ -303,7 +369,7 @@ int usim_rollout_random(usim_handle* h, int64_t first_step, int nsteps, const us
     io.act = nullptr;
     const size_t n = (size_t)h->n;
     for (int k = 0; k < nsteps; ++k) {
-        rc = launch(h, io, LF_AUTO_RESET | LF_RANDOM_ACT, (long long)(first_step + k), stream);
+        rc = step_common(h, io, LF_AUTO_RESET | LF_RANDOM_ACT, (long long)(first_step + k), stream);
         if (rc) return rc;
         if (block_advance) {
             io.obs += n * OBS_DIM; io.rew += n; io.done += n;
@@ -371,6 +437,15 @@ int usim_set_state(usim_handle* h, const float* scalars, const float* lattice) {
             }
     }
     HIPCHK(h, hipMemcpy(h->state, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice));
+    // the bank is a pure function of (seed, env, episode): rebuild both slots for the restored episode counters
+    h->refill_pending[0] = h->refill_pending[1] = false;
+    HIPCHK(h, hipMemset(h->d_count, 0, 2 * sizeof(int)));
+    for (int ahead = 1; ahead <= 2; ++ahead) {
+        DevIO b{}; b.ahead = ahead;
+        int rc = launch<1>(h, b, 0, 0, nullptr);
+        if (rc) return rc;
+    }
+    HIPCHK(h, hipDeviceSynchronize());
     return USIM_OK;
 }
 

@@ -1,0 +1,259 @@
+// usim_devmath.h -- device-side building blocks shared by the step kernels: small vector helpers, the Panda chain
+// constants, Philox4x32-10, unrolled packed Cholesky, arm kinematics/dynamics (FK, RNE bias, CRBA), quaternion helpers.
+// gfx950 only; everything is __device__ __forceinline__ and lives in registers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "usim_device.h"
+
+namespace usim {
+
+// ------------------------------------------------------------------------------------------------------------
+// small vector helpers
+// ------------------------------------------------------------------------------------------------------------
+struct f3 { float x, y, z; };
+#define DI __device__ __forceinline__
+DI f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+DI f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+DI f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+DI f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+DI f3 operator*(float s, f3 a) { return mk(a.x * s, a.y * s, a.z * s); }
+DI float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DI f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+DI f3 madd(f3 a, f3 b, float s) { return mk(fmaf(b.x, s, a.x), fmaf(b.y, s, a.y), fmaf(b.z, s, a.z)); }
+DI float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+// symmetric 3x3 (xx,xy,xz,yy,yz,zz) times vector
+DI f3 symmul(const float* I, f3 v) {
+    return mk(I[0] * v.x + I[1] * v.y + I[2] * v.z, I[1] * v.x + I[3] * v.y + I[4] * v.z, I[2] * v.x + I[4] * v.y + I[5] * v.z);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Panda chain (robosuite asset, un-vendored; SURVEY.md Appendix B.4 -- the build's own model definition)
+// link i: fixed translation, fixed rotation about x by ROTX[i]*90 deg, then the joint rotation about z
+// ------------------------------------------------------------------------------------------------------------
+__device__ constexpr float LPOS[NJ][3] = {{0.f, 0.f, 0.333f}, {0.f, 0.f, 0.f}, {0.f, -0.316f, 0.f}, {0.0825f, 0.f, 0.f},
+                                          {-0.0825f, 0.384f, 0.f}, {0.f, 0.f, 0.f}, {0.088f, 0.f, 0.f}};
+__device__ constexpr int ROTX[NJ] = {0, -1, 1, 1, -1, 1, 1};
+__device__ constexpr float LCOM[NJ][3] = {{0.f, 0.f, -0.07f}, {0.f, -0.1f, 0.f}, {0.04f, 0.f, -0.05f}, {-0.04f, 0.05f, 0.f},
+                                          {0.f, 0.f, -0.15f}, {0.06f, 0.f, 0.f}, {0.f, 0.f, 0.f}};   // [6] comes from DevModel
+__device__ constexpr float LMASS[NJ] = {3.f, 3.f, 2.f, 2.f, 2.f, 1.5f, 0.f};                       // [6] comes from DevModel
+__device__ constexpr float LISO[NJ] = {0.3f, 0.3f, 0.2f, 0.2f, 0.2f, 0.1f, 0.f};                     // isotropic inertias
+__device__ constexpr float QMIN[NJ] = {-2.8973f, -1.7628f, -2.8973f, -3.0718f, -2.8973f, -0.0175f, -2.8973f};
+__device__ constexpr float QMAX[NJ] = {2.8973f, 1.7628f, 2.8973f, -0.0698f, 2.8973f, 3.7525f, 2.8973f};
+__device__ constexpr float TAUMAX[NJ] = {80.f, 80.f, 80.f, 80.f, 12.f, 12.f, 12.f};
+__device__ constexpr float INITQ[NJ] = {0.f, 0.19634954084936207f, 0.f, -2.6179938779914944f, 0.f, 2.941592653589793f, 0.7853981633974483f};
+constexpr float JOINT_DAMP = 0.1f;
+constexpr float GRAV = 9.81f;
+constexpr float PROBE_MASS = 1.0f;
+constexpr float ELEM_R = 0.0075f, ELEM_MASS = 0.01f;
+constexpr float TORSO_DROP = 0.0047f;
+// MuJoCo default soft-constraint parameters (solref 0.02 1, solimp 0.9 0.95 0.001 0.5 2) and robosuite's impratio
+constexpr float SR_TC = 0.02f, SI_D0 = 0.9f, SI_DMAX = 0.95f, SI_WIDTH = 0.001f, IMPRATIO = 20.f;
+constexpr float PI_F = 3.14159265358979323846f;
+
+// ------------------------------------------------------------------------------------------------------------
+// Philox4x32-10 counter-based RNG (Salmon et al. 2011)
+// ------------------------------------------------------------------------------------------------------------
+struct u4 { uint32_t a, b, c, d; };
+DI u4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    u4 o; o.a = c0; o.b = c1; o.c = c2; o.d = c3; return o;
+}
+DI float u01(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }
+DI float u01_open(uint32_t u) { return (float)((u >> 8) + 1u) * (1.0f / 16777216.0f); }
+DI uint32_t urange(uint32_t u, uint32_t n) { return __umulhi(u, n); }
+
+// ------------------------------------------------------------------------------------------------------------
+// packed-lower Cholesky helpers, fully unrolled (registers only)
+// ------------------------------------------------------------------------------------------------------------
+#define PK(i, j) ((i) * ((i) + 1) / 2 + (j))
+template <int N>
+DI void chol_packed(float* L, float* invd) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        float d = L[PK(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d = fmaf(-L[PK(j, k)], L[PK(j, k)], d);
+        d = sqrtf(fmaxf(d, 1e-30f));
+        float inv = 1.0f / d;
+        L[PK(j, j)] = d; invd[j] = inv;
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            float s = L[PK(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s = fmaf(-L[PK(i, k)], L[PK(j, k)], s);
+            L[PK(i, j)] = s * inv;
+        }
+    }
+}
+template <int N>
+DI void chol_solve(const float* L, const float* invd, float* b) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s = fmaf(-L[PK(i, k)], b[k], s);
+        b[i] = s * invd[i];
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        float s = b[i];
+#pragma unroll
+        for (int k = i + 1; k < N; ++k) s = fmaf(-L[PK(k, i)], b[k], s);
+        b[i] = s * invd[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// arm kinematics + dynamics
+// ------------------------------------------------------------------------------------------------------------
+struct Kin {
+    f3 o[NJ], z[NJ];          // joint origins / axes (base-centred world axes)
+    f3 c[NJ];                 // link COMs
+    f3 r7x, r7y, r7z;         // link-7 rotation columns
+    f3 x, sx, sy, sz;         // eef site position and rotation columns
+    f3 hand;                  // right_hand body origin
+};
+
+DI void fk(const DevModel& M, const float* q, Kin& K) {
+    f3 px = mk(1.f, 0.f, 0.f), py = mk(0.f, 1.f, 0.f), pz = mk(0.f, 0.f, 1.f), po = mk(0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        f3 o = po + px * LPOS[i][0] + py * LPOS[i][1] + pz * LPOS[i][2];
+        f3 ax = px, ay, az;
+        if (ROTX[i] == 0) { ay = py; az = pz; }
+        else if (ROTX[i] > 0) { ay = pz; az = mk(-py.x, -py.y, -py.z); }
+        else { ay = mk(-pz.x, -pz.y, -pz.z); az = py; }
+        float s, c;
+        sincosf(q[i], &s, &c);
+        f3 nx = ax * c + ay * s, ny = ay * c - ax * s;
+        K.o[i] = o; K.z[i] = az;
+        if (i < NJ - 1) K.c[i] = o + nx * LCOM[i][0] + ny * LCOM[i][1] + az * LCOM[i][2];
+        else K.c[i] = o + nx * M.c7[0] + ny * M.c7[1] + az * M.c7[2];
+        px = nx; py = ny; pz = az; po = o;
+    }
+    K.r7x = px; K.r7y = py; K.r7z = pz;
+    K.x = po + px * M.site7[0] + py * M.site7[1] + pz * M.site7[2];
+    K.hand = po + px * M.hand7[0] + py * M.hand7[1] + pz * M.hand7[2];
+    // site frame = link-7 frame rotated by -45 deg about z (robosuite right_hand quat 0.924 0 0 -0.383)
+    const float h = 0.70710678118654752f;
+    K.sx = (px - py) * h; K.sy = (px + py) * h; K.sz = pz;
+}
+
+struct Dyn {
+    float M[28];              // mass matrix, packed lower
+    float bias[NJ];           // qfrc_bias (gravity + Coriolis/centrifugal)
+    f3 w7, al7, a7;           // link 7: angular velocity, bias angular accel., bias accel. of its origin (incl. +g)
+};
+
+// R7 * I7 * R7^T * v for the link-7 frame symmetric inertia I7
+DI f3 rot_inertia_mul(const Kin& K, const float* I, f3 v) {
+    f3 l = mk(dot(K.r7x, v), dot(K.r7y, v), dot(K.r7z, v));
+    f3 t = symmul(I, l);
+    return K.r7x * t.x + K.r7y * t.y + K.r7z * t.z;
+}
+
+DI void dynamics(const DevModel& M, const Kin& K, const float* qd, Dyn& D) {
+    // ---- recursive Newton-Euler with qdd = 0, gravity as base acceleration +g ----
+    f3 F[NJ], Nc[NJ];
+    f3 w = mk(0, 0, 0), al = mk(0, 0, 0), a = mk(0, 0, GRAV), op = mk(0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        f3 r = K.o[i] - op;
+        a = a + cross(al, r) + cross(w, cross(w, r));
+        al = al + cross(w, K.z[i]) * qd[i];
+        w = w + K.z[i] * qd[i];
+        f3 rc = K.c[i] - K.o[i];
+        f3 ac = a + cross(al, rc) + cross(w, cross(w, rc));
+        float mi = (i < NJ - 1) ? LMASS[i] : M.m7;
+        F[i] = ac * mi;
+        f3 N;
+        if (i < NJ - 1) N = al * LISO[i];
+        else N = rot_inertia_mul(K, M.I7, al) + cross(w, rot_inertia_mul(K, M.I7, w));
+        Nc[i] = N + cross(K.c[i], F[i]);        // moment about the base origin
+        op = K.o[i];
+    }
+    D.w7 = w; D.al7 = al; D.a7 = a;
+    // ---- backward pass: bias torques and composite-rigid-body mass matrix (inertia about the base origin) ----
+    f3 vo[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) vo[j] = cross(K.o[j], K.z[j]);
+    f3 fa = mk(0, 0, 0), na = mk(0, 0, 0);
+    float cm = 0.f; f3 ch = mk(0, 0, 0);
+    float Io[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = NJ - 1; i >= 0; --i) {
+        fa = fa + F[i]; na = na + Nc[i];
+        D.bias[i] = dot(K.z[i], na - cross(K.o[i], fa));
+        float mi = (i < NJ - 1) ? LMASS[i] : M.m7;
+        f3 c = K.c[i];
+        cm += mi; ch = madd(ch, c, mi);
+        float cc = dot(c, c);
+        if (i < NJ - 1) { Io[0] += LISO[i]; Io[3] += LISO[i]; Io[5] += LISO[i]; }
+        else {
+            // R7 I7 R7^T, six unique entries
+            f3 e0 = rot_inertia_mul(K, M.I7, mk(1, 0, 0)), e1 = rot_inertia_mul(K, M.I7, mk(0, 1, 0)), e2 = rot_inertia_mul(K, M.I7, mk(0, 0, 1));
+            Io[0] += e0.x; Io[1] += e0.y; Io[2] += e0.z; Io[3] += e1.y; Io[4] += e1.z; Io[5] += e2.z;
+        }
+        Io[0] += mi * (cc - c.x * c.x); Io[1] -= mi * c.x * c.y; Io[2] -= mi * c.x * c.z;
+        Io[3] += mi * (cc - c.y * c.y); Io[4] -= mi * c.y * c.z; Io[5] += mi * (cc - c.z * c.z);
+        f3 n = symmul(Io, K.z[i]) + cross(ch, vo[i]);
+        f3 f = vo[i] * cm + cross(K.z[i], ch);
+#pragma unroll
+        for (int j = 0; j <= i; ++j) D.M[PK(i, j)] = dot(K.z[j], n) + dot(vo[j], f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// quaternion helpers (src/utils/quaternion.py; robosuite transform_utils.mat2quat sign convention w >= 0)
+// ------------------------------------------------------------------------------------------------------------
+DI void mat2quat_xyzw(f3 cx, f3 cy, f3 cz, float* q) {
+    // rotation matrix columns cx, cy, cz: m_rc = (column c).component r
+    float m00 = cx.x, m10 = cx.y, m20 = cx.z, m01 = cy.x, m11 = cy.y, m21 = cy.z, m02 = cz.x, m12 = cz.y, m22 = cz.z;
+    float tr = m00 + m11 + m22, w, x, y, z;
+    if (tr > 0.f) { float s = sqrtf(tr + 1.f) * 2.f; w = 0.25f * s; x = (m21 - m12) / s; y = (m02 - m20) / s; z = (m10 - m01) / s; }
+    else if (m00 > m11 && m00 > m22) { float s = sqrtf(1.f + m00 - m11 - m22) * 2.f; w = (m21 - m12) / s; x = 0.25f * s; y = (m01 + m10) / s; z = (m02 + m20) / s; }
+    else if (m11 > m22) { float s = sqrtf(1.f + m11 - m00 - m22) * 2.f; w = (m02 - m20) / s; x = (m01 + m10) / s; y = 0.25f * s; z = (m12 + m21) / s; }
+    else { float s = sqrtf(1.f + m22 - m00 - m11) * 2.f; w = (m10 - m01) / s; x = (m02 + m20) / s; y = (m12 + m21) / s; z = 0.25f * s; }
+    if (w < 0.f) { w = -w; x = -x; y = -y; z = -z; }
+    q[0] = x; q[1] = y; q[2] = z; q[3] = w;
+}
+// transforms3d qmult(a, qconjugate(b)) with index 0 treated as the scalar part (quaternion.py:23-35)
+DI void difference_quat(const float* a, const float* b, float* o) {
+    float bw = b[0], bx = -b[1], by = -b[2], bz = -b[3];
+    o[0] = a[0] * bw - a[1] * bx - a[2] * by - a[3] * bz;
+    o[1] = a[0] * bx + a[1] * bw + a[2] * bz - a[3] * by;
+    o[2] = a[0] * by - a[1] * bz + a[2] * bw + a[3] * bx;
+    o[3] = a[0] * bz + a[1] * by - a[2] * bx + a[3] * bw;
+}
+// distance_quat(q, goal) (quaternion.py:38-59) for a unit quaternion q (w,x,y,z) and the goal quaternion as written at
+// ultrasound.py:174, whose norm is 1 - eps_g (eps_g = 1.2e-9).  The reference evaluates 2 arccos(clip(w)) with
+// w = q . g and folds distances above pi to |2 pi - d|, i.e. d = 2 arccos(|w|).  arccos loses half the mantissa near
+// |w| = 1 (where the probe spends its life), so 1 - |w| is formed without cancellation from the chord to the unit goal
+// g^:  q . g^ = 1 - |q - g^|^2 / 2  =>  1 - |w| = eps_g + (1 - eps_g) min(|q - g^|^2, |q + g^|^2) / 2,
+// and d = 4 arcsin(sqrt((1 - |w|) / 2)).  Same value as the reference formula, accurate to fp32 rounding.
+DI float distance_quat_goal(const float* q, const float* ghat, float eps_g) {
+    float dm = 0.f, dp = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { float a = q[i] - ghat[i], b = q[i] + ghat[i]; dm = fmaf(a, a, dm); dp = fmaf(b, b, dp); }
+    float m = fminf(dm, dp);
+    if (m == 0.f) return 0.f;                           // q_log: zero vector part (quaternion.py:17-18)
+    float h = eps_g + 0.5f * m * (1.f - eps_g);
+    return 4.f * asinf(sqrtf(fminf(0.5f * h, 1.f)));
+}
+
+// closest point of the segment p1 + s d1 (s in [0,1]) to the point c
+DI f3 seg_point(f3 p1, f3 d1, f3 c) {
+    float s = clampf(dot(d1, c - p1) / dot(d1, d1), 0.f, 1.f);
+    return madd(p1, d1, s);
+}
+
+
+}  // namespace usim

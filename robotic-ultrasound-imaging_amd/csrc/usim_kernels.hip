@@ -1,10 +1,4 @@
-// usim_kernels.hip -- CDNA4 (gfx950) kernels of the batched Ultrasound simulator.
-//
-// One environment per lane, one wave64 per workgroup.  All 7-DoF arm mathematics (forward kinematics,
-// composite-rigid-body mass matrix, recursive Newton-Euler bias, 7x7/6x6/3x3 Cholesky solves, the OSC torque
-// law) lives in VGPRs, fully unrolled; the 99-element torso lattice and the contact rows are staged in LDS as
-// [word][lane] rows (bank = lane, conflict-free for wave-uniform word indices); per-environment state is read
-// and written once per step as coalesced 256-byte rows of the SoA state block in HBM.
+// usim_kernels.hip -- CDNA4 (gfx950) step/reset kernel of the batched Ultrasound simulator.
 //
 // The step replaces, per environment:
 //   a1 robosuite MujocoEnv.step driver            a2 OSC_POSE controller (rl_config.yaml:33-51)
@@ -14,282 +8,82 @@
 //   a7 probe<->torso contact predicate ultrasound.py:673-736          a8 utils/quaternion.py
 //   a10 reset ultrasound.py:416-478 (trajectory sampling, initial-pose IK, noise, solref randomisation)
 // Model and algorithm are specified in DESIGN.md; this file is written independently of oracle/.
+//
+// Mapping.  G lanes of a wave64 form the group of one environment.
+//   rigid torso  G = 1 : one environment per lane, 64 per workgroup, everything in VGPRs, no LDS.
+//   soft torso   G = 8 / 16 : 16 environments per workgroup (4096 envs -> 256 workgroups, one per CU, G/4 waves
+//                each).  All lanes of a group carry the same 7-DoF arm state (the arm mathematics is replicated, those
+//                lanes would otherwise idle) and split the 99-element lattice, the collision tests and the contacts:
+//                  - the lattice inverse (99 x 100 fp32) and the element tables are workgroup-resident in LDS and read
+//                    as 16-byte row chunks; per-environment scratch is a 548-word LDS block (548 mod 64 = 36 puts the
+//                    16-byte windows of the 16 environments on disjoint bank groups);
+//                  - contacts keep ascending shell-id order through a wave ballot;
+//                  - contact k lives in the registers of lane k; the Gauss-Seidel sweep visits contacts in order and
+//                    broadcasts the updated site acceleration with DPP row_newbcast (no LDS round trip per row).
+// Per-environment state is read and written once per step as rows of the SoA state block in HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "usim_device.h"
+#include "usim_devmath.h"
 
 namespace usim {
 
-// ------------------------------------------------------------------------------------------------------------
-// small vector helpers
-// ------------------------------------------------------------------------------------------------------------
-struct f3 { float x, y, z; };
-#define DI __device__ __forceinline__
-DI f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
-DI f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
-DI f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
-DI f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
-DI f3 operator*(float s, f3 a) { return mk(a.x * s, a.y * s, a.z * s); }
-DI float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-DI f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-DI f3 madd(f3 a, f3 b, float s) { return mk(fmaf(b.x, s, a.x), fmaf(b.y, s, a.y), fmaf(b.z, s, a.z)); }
-DI float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
-// symmetric 3x3 (xx,xy,xz,yy,yz,zz) times vector
-DI f3 symmul(const float* I, f3 v) {
-    return mk(I[0] * v.x + I[1] * v.y + I[2] * v.z, I[1] * v.x + I[3] * v.y + I[4] * v.z, I[2] * v.x + I[4] * v.y + I[5] * v.z);
-}
+// lattice tables, laid out exactly as their workgroup-resident LDS copy (uploaded once per device by usim_create)
+constexpr int LROW = 100;                             // row stride of the lattice inverse (pad word zero)
+constexpr int TB_LINV = 0;                            // float [99][100]
+constexpr int TB_POS = N_TOP * LROW;                  // float [99][3] nominal surface point rel. torso centre (padded to 300)
+constexpr int TB_AXIS = TB_POS + 300;                 // float [99][3] slide axis
+constexpr int TB_NBR = TB_AXIS + 300;                 // int   [99][4] neighbour element, -1 pinned, -2 none (padded to 400)
+constexpr int TB_SHELL = TB_NBR + 400;                // int   [99]    shell id (contact-pair index convention)
+constexpr int TB_WORDS = TB_SHELL + 100;              // 11000 words
+__constant__ __attribute__((aligned(16))) float c_tables[TB_WORDS];
 
-// ------------------------------------------------------------------------------------------------------------
-// Panda chain (robosuite asset, un-vendored; SURVEY.md Appendix B.4 -- the build's own model definition)
-// link i: fixed translation, fixed rotation about x by ROTX[i]*90 deg, then the joint rotation about z
-// ------------------------------------------------------------------------------------------------------------
-__device__ constexpr float LPOS[NJ][3] = {{0.f, 0.f, 0.333f}, {0.f, 0.f, 0.f}, {0.f, -0.316f, 0.f}, {0.0825f, 0.f, 0.f},
-                                          {-0.0825f, 0.384f, 0.f}, {0.f, 0.f, 0.f}, {0.088f, 0.f, 0.f}};
-__device__ constexpr int ROTX[NJ] = {0, -1, 1, 1, -1, 1, 1};
-__device__ constexpr float LCOM[NJ][3] = {{0.f, 0.f, -0.07f}, {0.f, -0.1f, 0.f}, {0.04f, 0.f, -0.05f}, {-0.04f, 0.05f, 0.f},
-                                          {0.f, 0.f, -0.15f}, {0.06f, 0.f, 0.f}, {0.f, 0.f, 0.f}};   // [6] comes from DevModel
-__device__ constexpr float LMASS[NJ] = {3.f, 3.f, 2.f, 2.f, 2.f, 1.5f, 0.f};                       // [6] comes from DevModel
-__device__ constexpr float LISO[NJ] = {0.3f, 0.3f, 0.2f, 0.2f, 0.2f, 0.1f, 0.f};                     // isotropic inertias
-__device__ constexpr float QMIN[NJ] = {-2.8973f, -1.7628f, -2.8973f, -3.0718f, -2.8973f, -0.0175f, -2.8973f};
-__device__ constexpr float QMAX[NJ] = {2.8973f, 1.7628f, 2.8973f, -0.0698f, 2.8973f, 3.7525f, 2.8973f};
-__device__ constexpr float TAUMAX[NJ] = {80.f, 80.f, 80.f, 80.f, 12.f, 12.f, 12.f};
-__device__ constexpr float INITQ[NJ] = {0.f, 0.19634954084936207f, 0.f, -2.6179938779914944f, 0.f, 2.941592653589793f, 0.7853981633974483f};
-constexpr float JOINT_DAMP = 0.1f;
-constexpr float GRAV = 9.81f;
-constexpr float PROBE_MASS = 1.0f;
-constexpr float ELEM_R = 0.0075f, ELEM_MASS = 0.01f;
-constexpr float TORSO_DROP = 0.0047f;
-// MuJoCo default soft-constraint parameters (solref 0.02 1, solimp 0.9 0.95 0.001 0.5 2) and robosuite's impratio
-constexpr float SR_TC = 0.02f, SI_D0 = 0.9f, SI_DMAX = 0.95f, SI_WIDTH = 0.001f, IMPRATIO = 20.f;
-constexpr float PI_F = 3.14159265358979323846f;
+// per-environment LDS block (word offsets); GE_X must stay 16-byte aligned
+constexpr int GE_X = 0;                               // rhs[100] of the lattice solve
+constexpr int GE_S = 100;                             // s[99]
+constexpr int GE_SD = 200;                            // sdot[99]
+constexpr int GE_A = 300;                             // lattice acceleration a~[99]
+constexpr int CG_WORDS = 8;                           // contact record: n3, r3, element, distance
+constexpr int GE_CG = 400;                            // contact records 8 x 8
+constexpr int GE_WS = 464;                            // per-contact wrench + element impulse 8 x 8
+constexpr int GE_STRIDE = 548;                        // 548 mod 64 = 36: disjoint 16-byte bank windows for 16 environments
+static_assert(GE_WS + MAXC * 8 <= GE_STRIDE, "per-environment LDS block overflow");
 
-// ------------------------------------------------------------------------------------------------------------
-// torso lattice tables (identical for every handle; uploaded once per device by usim_create).  They live in the
-// constant address space so that wave-uniform indices turn into scalar loads (s_load_dword*) and the
-// coefficients are consumed straight from SGPRs.
-// ------------------------------------------------------------------------------------------------------------
-__constant__ float c_el_pos[N_TOP * 3];                       // nominal surface point rel. torso centre
-__constant__ float c_el_axis[N_TOP * 3];                      // slide axis
-__constant__ int c_el_nbr[N_TOP * 4];                         // neighbour element, -1 pinned (side face), -2 none
-__constant__ int c_el_shell[N_TOP];                           // shell id (contact-pair index convention)
-__constant__ float c_linv_blk[LINV_NBLK * N_TOP * LINV_BLK];  // blocked inverse of the lattice normal matrix
-__constant__ float c_linv[N_TOP * N_TOP];                     // same, plain row-major
-
-// ------------------------------------------------------------------------------------------------------------
-// Philox4x32-10 counter-based RNG (Salmon et al. 2011)
-// ------------------------------------------------------------------------------------------------------------
-struct u4 { uint32_t a, b, c, d; };
-DI u4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
-        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    u4 o; o.a = c0; o.b = c1; o.c = c2; o.d = c3; return o;
-}
-DI float u01(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }
-DI float u01_open(uint32_t u) { return (float)((u >> 8) + 1u) * (1.0f / 16777216.0f); }
-DI uint32_t urange(uint32_t u, uint32_t n) { return __umulhi(u, n); }
-
-// ------------------------------------------------------------------------------------------------------------
-// packed-lower Cholesky helpers, fully unrolled (registers only)
-// ------------------------------------------------------------------------------------------------------------
-#define PK(i, j) ((i) * ((i) + 1) / 2 + (j))
-template <int N>
-DI void chol_packed(float* L, float* invd) {
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        float d = L[PK(j, j)];
-#pragma unroll
-        for (int k = 0; k < j; ++k) d = fmaf(-L[PK(j, k)], L[PK(j, k)], d);
-        d = sqrtf(fmaxf(d, 1e-30f));
-        float inv = 1.0f / d;
-        L[PK(j, j)] = d; invd[j] = inv;
-#pragma unroll
-        for (int i = j + 1; i < N; ++i) {
-            float s = L[PK(i, j)];
-#pragma unroll
-            for (int k = 0; k < j; ++k) s = fmaf(-L[PK(i, k)], L[PK(j, k)], s);
-            L[PK(i, j)] = s * inv;
-        }
-    }
-}
-template <int N>
-DI void chol_solve(const float* L, const float* invd, float* b) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        float s = b[i];
-#pragma unroll
-        for (int k = 0; k < i; ++k) s = fmaf(-L[PK(i, k)], b[k], s);
-        b[i] = s * invd[i];
-    }
-#pragma unroll
-    for (int i = N - 1; i >= 0; --i) {
-        float s = b[i];
-#pragma unroll
-        for (int k = i + 1; k < N; ++k) s = fmaf(-L[PK(k, i)], b[k], s);
-        b[i] = s * invd[i];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// arm kinematics + dynamics
-// ------------------------------------------------------------------------------------------------------------
-struct Kin {
-    f3 o[NJ], z[NJ];          // joint origins / axes (base-centred world axes)
-    f3 c[NJ];                 // link COMs
-    f3 r7x, r7y, r7z;         // link-7 rotation columns
-    f3 x, sx, sy, sz;         // eef site position and rotation columns
-    f3 hand;                  // right_hand body origin
+template <int G> struct GroupGeom {
+    static constexpr int EPW = 64 / G;                // environments per wave
+    static constexpr int WAVES = (G >= 4) ? G / 4 : 1;
+    static constexpr int EPB = EPW * WAVES;           // environments per workgroup (64 for G = 1, else 16)
+    static constexpr int NT = 64 * WAVES;
+    static constexpr int LDS_WORDS = TB_WORDS + EPB * GE_STRIDE;
 };
 
-DI void fk(const DevModel& M, const float* q, Kin& K) {
-    f3 px = mk(1.f, 0.f, 0.f), py = mk(0.f, 1.f, 0.f), pz = mk(0.f, 0.f, 1.f), po = mk(0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < NJ; ++i) {
-        f3 o = po + px * LPOS[i][0] + py * LPOS[i][1] + pz * LPOS[i][2];
-        f3 ax = px, ay, az;
-        if (ROTX[i] == 0) { ay = py; az = pz; }
-        else if (ROTX[i] > 0) { ay = pz; az = mk(-py.x, -py.y, -py.z); }
-        else { ay = mk(-pz.x, -pz.y, -pz.z); az = py; }
-        float s, c;
-        sincosf(q[i], &s, &c);
-        f3 nx = ax * c + ay * s, ny = ay * c - ax * s;
-        K.o[i] = o; K.z[i] = az;
-        if (i < NJ - 1) K.c[i] = o + nx * LCOM[i][0] + ny * LCOM[i][1] + az * LCOM[i][2];
-        else K.c[i] = o + nx * M.c7[0] + ny * M.c7[1] + az * M.c7[2];
-        px = nx; py = ny; pz = az; po = o;
+DI void group_sync() {
+    // the lanes of a group exchange data through LDS inside one wave: order the LDS traffic, no s_barrier needed
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// value of lane k (0..7) of every group, delivered to all lanes of the group (DPP row_newbcast, gfx90a+).  k is a
+// compile-time constant after unrolling, so the switch folds to one v_mov_b32_dpp (two for G = 8).
+#define USIM_BCAST_CASE(K)                                                                               \
+    case K:                                                                                              \
+        if (G == 16) iv = __builtin_amdgcn_update_dpp(iv, iv, 0x150 + K, 0xf, 0xf, false);               \
+        else if (G == 8) {                                                                               \
+            int t = __builtin_amdgcn_update_dpp(iv, iv, 0x150 + K, 0xf, 0x3, false);     /* lanes 0-7 of the row <- lane K */   \
+            iv = __builtin_amdgcn_update_dpp(t, iv, 0x150 + 8 + K, 0xf, 0xc, false);     /* lanes 8-15 <- lane 8 + K */          \
+        }                                                                                                \
+        break;
+template <int G>
+DI float group_bcast(float v, int k) {
+    int iv = __float_as_int(v);
+    switch (k) {
+        USIM_BCAST_CASE(0) USIM_BCAST_CASE(1) USIM_BCAST_CASE(2) USIM_BCAST_CASE(3)
+        USIM_BCAST_CASE(4) USIM_BCAST_CASE(5) USIM_BCAST_CASE(6) USIM_BCAST_CASE(7)
+        default: break;
     }
-    K.r7x = px; K.r7y = py; K.r7z = pz;
-    K.x = po + px * M.site7[0] + py * M.site7[1] + pz * M.site7[2];
-    K.hand = po + px * M.hand7[0] + py * M.hand7[1] + pz * M.hand7[2];
-    // site frame = link-7 frame rotated by -45 deg about z (robosuite right_hand quat 0.924 0 0 -0.383)
-    const float h = 0.70710678118654752f;
-    K.sx = (px - py) * h; K.sy = (px + py) * h; K.sz = pz;
+    return __int_as_float(iv);
 }
-
-struct Dyn {
-    float M[28];              // mass matrix, packed lower
-    float bias[NJ];           // qfrc_bias (gravity + Coriolis/centrifugal)
-    f3 w7, al7, a7;           // link 7: angular velocity, bias angular accel., bias accel. of its origin (incl. +g)
-};
-
-// R7 * I7 * R7^T * v for the link-7 frame symmetric inertia I7
-DI f3 rot_inertia_mul(const Kin& K, const float* I, f3 v) {
-    f3 l = mk(dot(K.r7x, v), dot(K.r7y, v), dot(K.r7z, v));
-    f3 t = symmul(I, l);
-    return K.r7x * t.x + K.r7y * t.y + K.r7z * t.z;
-}
-
-DI void dynamics(const DevModel& M, const Kin& K, const float* qd, Dyn& D) {
-    // ---- recursive Newton-Euler with qdd = 0, gravity as base acceleration +g ----
-    f3 F[NJ], Nc[NJ];
-    f3 w = mk(0, 0, 0), al = mk(0, 0, 0), a = mk(0, 0, GRAV), op = mk(0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < NJ; ++i) {
-        f3 r = K.o[i] - op;
-        a = a + cross(al, r) + cross(w, cross(w, r));
-        al = al + cross(w, K.z[i]) * qd[i];
-        w = w + K.z[i] * qd[i];
-        f3 rc = K.c[i] - K.o[i];
-        f3 ac = a + cross(al, rc) + cross(w, cross(w, rc));
-        float mi = (i < NJ - 1) ? LMASS[i] : M.m7;
-        F[i] = ac * mi;
-        f3 N;
-        if (i < NJ - 1) N = al * LISO[i];
-        else N = rot_inertia_mul(K, M.I7, al) + cross(w, rot_inertia_mul(K, M.I7, w));
-        Nc[i] = N + cross(K.c[i], F[i]);        // moment about the base origin
-        op = K.o[i];
-    }
-    D.w7 = w; D.al7 = al; D.a7 = a;
-    // ---- backward pass: bias torques and composite-rigid-body mass matrix (inertia about the base origin) ----
-    f3 vo[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) vo[j] = cross(K.o[j], K.z[j]);
-    f3 fa = mk(0, 0, 0), na = mk(0, 0, 0);
-    float cm = 0.f; f3 ch = mk(0, 0, 0);
-    float Io[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int i = NJ - 1; i >= 0; --i) {
-        fa = fa + F[i]; na = na + Nc[i];
-        D.bias[i] = dot(K.z[i], na - cross(K.o[i], fa));
-        float mi = (i < NJ - 1) ? LMASS[i] : M.m7;
-        f3 c = K.c[i];
-        cm += mi; ch = madd(ch, c, mi);
-        float cc = dot(c, c);
-        if (i < NJ - 1) { Io[0] += LISO[i]; Io[3] += LISO[i]; Io[5] += LISO[i]; }
-        else {
-            // R7 I7 R7^T, six unique entries
-            f3 e0 = rot_inertia_mul(K, M.I7, mk(1, 0, 0)), e1 = rot_inertia_mul(K, M.I7, mk(0, 1, 0)), e2 = rot_inertia_mul(K, M.I7, mk(0, 0, 1));
-            Io[0] += e0.x; Io[1] += e0.y; Io[2] += e0.z; Io[3] += e1.y; Io[4] += e1.z; Io[5] += e2.z;
-        }
-        Io[0] += mi * (cc - c.x * c.x); Io[1] -= mi * c.x * c.y; Io[2] -= mi * c.x * c.z;
-        Io[3] += mi * (cc - c.y * c.y); Io[4] -= mi * c.y * c.z; Io[5] += mi * (cc - c.z * c.z);
-        f3 n = symmul(Io, K.z[i]) + cross(ch, vo[i]);
-        f3 f = vo[i] * cm + cross(K.z[i], ch);
-#pragma unroll
-        for (int j = 0; j <= i; ++j) D.M[PK(i, j)] = dot(K.z[j], n) + dot(vo[j], f);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// quaternion helpers (src/utils/quaternion.py; robosuite transform_utils.mat2quat sign convention w >= 0)
-// ------------------------------------------------------------------------------------------------------------
-DI void mat2quat_xyzw(f3 cx, f3 cy, f3 cz, float* q) {
-    // rotation matrix columns cx, cy, cz: m_rc = (column c).component r
-    float m00 = cx.x, m10 = cx.y, m20 = cx.z, m01 = cy.x, m11 = cy.y, m21 = cy.z, m02 = cz.x, m12 = cz.y, m22 = cz.z;
-    float tr = m00 + m11 + m22, w, x, y, z;
-    if (tr > 0.f) { float s = sqrtf(tr + 1.f) * 2.f; w = 0.25f * s; x = (m21 - m12) / s; y = (m02 - m20) / s; z = (m10 - m01) / s; }
-    else if (m00 > m11 && m00 > m22) { float s = sqrtf(1.f + m00 - m11 - m22) * 2.f; w = (m21 - m12) / s; x = 0.25f * s; y = (m01 + m10) / s; z = (m02 + m20) / s; }
-    else if (m11 > m22) { float s = sqrtf(1.f + m11 - m00 - m22) * 2.f; w = (m02 - m20) / s; x = (m01 + m10) / s; y = 0.25f * s; z = (m12 + m21) / s; }
-    else { float s = sqrtf(1.f + m22 - m00 - m11) * 2.f; w = (m10 - m01) / s; x = (m02 + m20) / s; y = (m12 + m21) / s; z = 0.25f * s; }
-    if (w < 0.f) { w = -w; x = -x; y = -y; z = -z; }
-    q[0] = x; q[1] = y; q[2] = z; q[3] = w;
-}
-// transforms3d qmult(a, qconjugate(b)) with index 0 treated as the scalar part (quaternion.py:23-35)
-DI void difference_quat(const float* a, const float* b, float* o) {
-    float bw = b[0], bx = -b[1], by = -b[2], bz = -b[3];
-    o[0] = a[0] * bw - a[1] * bx - a[2] * by - a[3] * bz;
-    o[1] = a[0] * bx + a[1] * bw + a[2] * bz - a[3] * by;
-    o[2] = a[0] * by - a[1] * bz + a[2] * bw + a[3] * bx;
-    o[3] = a[0] * bz + a[1] * by - a[2] * bx + a[3] * bw;
-}
-// distance_quat(q, goal) (quaternion.py:38-59) for a unit quaternion q (w,x,y,z) and the goal quaternion as written at
-// ultrasound.py:174, whose norm is 1 - eps_g (eps_g = 1.2e-9).  The reference evaluates 2 arccos(clip(w)) with
-// w = q . g and folds distances above pi to |2 pi - d|, i.e. d = 2 arccos(|w|).  arccos loses half the mantissa near
-// |w| = 1 (where the probe spends its life), so 1 - |w| is formed without cancellation from the chord to the unit goal
-// g^:  q . g^ = 1 - |q - g^|^2 / 2  =>  1 - |w| = eps_g + (1 - eps_g) min(|q - g^|^2, |q + g^|^2) / 2,
-// and d = 4 arcsin(sqrt((1 - |w|) / 2)).  Same value as the reference formula, accurate to fp32 rounding.
-DI float distance_quat_goal(const float* q, const float* ghat, float eps_g) {
-    float dm = 0.f, dp = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { float a = q[i] - ghat[i], b = q[i] + ghat[i]; dm = fmaf(a, a, dm); dp = fmaf(b, b, dp); }
-    float m = fminf(dm, dp);
-    if (m == 0.f) return 0.f;                           // q_log: zero vector part (quaternion.py:17-18)
-    float h = eps_g + 0.5f * m * (1.f - eps_g);
-    return 4.f * asinf(sqrtf(fminf(0.5f * h, 1.f)));
-}
-
-// closest point of the segment p1 + s d1 (s in [0,1]) to the point c
-DI f3 seg_point(f3 p1, f3 d1, f3 c) {
-    float s = clampf(dot(d1, c - p1) / dot(d1, d1), 0.f, 1.f);
-    return madd(p1, d1, s);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// LDS plan (words per lane; rows of 64 lanes).  TOP torso only.
-//   S   [0,99)        slide coordinates s[e]           (dead after collision -> contact coupling matrix Kc[8][8])
-//   Y   [99,198)      sdot[e] during the rhs build, then the lattice acceleration a~[e] (live to the end)
-//   X   [198,534)     rhs[e] for the lattice solve (first 99 words), then the contact scratch (8 slots x 42 words)
-// ------------------------------------------------------------------------------------------------------------
-constexpr int L_S = 0, L_Y = N_TOP, L_X = 2 * N_TOP;
-constexpr int CS_WORDS = 42;       // per contact slot: n3 t3 r3 Liw18 g3 aref3 Ad3 Rn1 f3 (ae, elem in registers)
-constexpr int CS_N = 0, CS_T = 3, CS_R = 6, CS_LIW = 9, CS_G = 27, CS_AREF = 30, CS_AD = 33, CS_RN = 36, CS_F = 37, CS_E = 40;
-constexpr int LDS_WORDS_TOP = 2 * N_TOP + MAXC * CS_WORDS;   // 534 words/lane = 136704 B per workgroup
-#define LDSW(base, idx) lds[((base) + (idx)) * WG + lane]
+#undef USIM_BCAST_CASE
 
 struct StepOut {               // results of one forward pass that the env logic needs
     float fc[3];               // net contact force on the probe (cfrc_ext[probe][3:6])
@@ -299,18 +93,49 @@ struct StepOut {               // results of one forward pass that the env logic
     int overflow;
 };
 
-template <int TORSO>
-__global__ __launch_bounds__(WG) void usim_step_kernel(const DevModel M, const DevCfg C, float* __restrict__ st, int n, int npad,
-                                                       const DevIO io, int flags, long long rstep) {
-    extern __shared__ float lds[];
-    const int lane = threadIdx.x;
-    const int env = blockIdx.x * WG + lane;
-    const bool valid = env < n;
-    const int ei = valid ? env : n - 1;           // clamp so that every lane has something to read; stores are guarded
-    const bool reset_only = (flags & LF_RESET_ONLY) != 0;
+// MODE 0: one env.step() per environment; a finished environment takes its next initial state from the reset bank.
+// MODE 1: reset computation (draws, initial-pose IK, zero-torque forward pass) for the environments selected by the mask
+//         or by a refill list, written either to the live state (io.ahead == 0) or to the reset bank (episode + io.ahead).
+template <int TORSO, int G, int MODE>
+__global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevModel M, const DevCfg C, float* __restrict__ st, int n, int npad,
+                                                                      const DevIO io, int flags, long long rstep) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int EPW = GroupGeom<G>::EPW, EPB = GroupGeom<G>::EPB, NT = GroupGeom<G>::NT;
+    static_assert(!TORSO || G >= MAXC, "the contact solver gives every contact its own lane of the group");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = lane % G, ge = lane / G;           // lane within the group, group (= environment) within the wave
+    const int gbase = lane - gl;                      // ballot bit of the group's first lane
+    const int eb = wave * EPW + ge;                   // environment within the workgroup
+    int env = blockIdx.x * EPB + eb;
+    bool valid = env < n;                             // lattice rows are stored by every lane of the group
+    if (MODE == 1 && io.list) {                       // refill launch: environments come from the list the step kernel appended to
+        const int cnt = *io.count;
+        if ((int)blockIdx.x * EPB >= cnt) return;
+        valid = env < cnt;
+        env = valid ? io.list[env] : 0;
+    }
+    const bool store = valid && gl == 0;              // per-environment scalars and outputs by its first lane
+    const int ei = valid ? env : n - 1;               // clamp so that every lane has something to read; stores are guarded
+    constexpr bool reset_only = (MODE == 1);
     const bool auto_reset = (flags & LF_AUTO_RESET) != 0;
 #define ST(f) st[(size_t)(f) * npad + ei]
 #define STI(f) (reinterpret_cast<int*>(st))[(size_t)(f) * npad + ei]
+#define EB(off) lds[TB_WORDS + eb * GE_STRIDE + (off)]
+#define BK(slot, f) st[(size_t)(io.bank_row0 + (slot) * BANK_WORDS + (f)) * npad + ei]
+#define BKI(slot, f) (reinterpret_cast<int*>(st))[(size_t)(io.bank_row0 + (slot) * BANK_WORDS + (f)) * npad + ei]
+    if (TORSO) {
+        // workgroup-resident copy of the lattice tables (inverse 99 x 100, element positions/axes/neighbours/shell ids):
+        // 16-byte loads, all issued before the first LDS store
+        const float4* src = reinterpret_cast<const float4*>(c_tables);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        constexpr int NV = TB_WORDS / 4, PER = (NV + NT - 1) / NT;
+        float4 tmp[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { int idx = threadIdx.x + i * NT; tmp[i] = (idx < NV) ? src[idx] : make_float4(0, 0, 0, 0); }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { int idx = threadIdx.x + i * NT; if (idx < NV) dst[idx] = tmp[i]; }
+        __syncthreads();
+    }
 
     // ---------------- load state ----------------
     float q[NJ], qd[NJ], q0[NJ];
@@ -334,7 +159,7 @@ __global__ __launch_bounds__(WG) void usim_step_kernel(const DevModel M, const D
                 float u = u01(rr[a]);
                 bool sgn = (C.mode == 1) || (C.mode == 2 && a == 6);
                 act[a] = sgn ? 2.f * u - 1.f : u;
-                if (io.act_out && valid && a < C.adim) io.act_out[(size_t)ei * C.adim + a] = act[a];
+                if (io.act_out && store && a < C.adim) io.act_out[(size_t)ei * C.adim + a] = act[a];
             }
         } else {
 #pragma unroll
@@ -346,18 +171,20 @@ __global__ __launch_bounds__(WG) void usim_step_kernel(const DevModel M, const D
     bool done = false;
     const float dt = C.dt;
 
-#pragma nounroll
-    for (int pass = reset_only ? 1 : 0; pass < 2; ++pass) {
+    constexpr int pass = MODE;                        // 0: step from the live state, 1: reset computation
+    int ep_t = episode;                               // episode index the reset draws are keyed on
+    do {
         const bool active = (pass == 0) ? true : need;
         if (pass == 1) {
             if (!__any(need)) break;
             if (need) {
                 // ================= reset draws (ultrasound.py:416-478) =================
-                episode += 1;
+                ep_t = episode + (io.ahead > 0 ? io.ahead : 1);
+                if (io.ahead == 0) episode = ep_t;
                 uint32_t gid = (uint32_t)(C.env_offset + ei);
-                u4 A = philox(gid, (uint32_t)episode, 0u, 0u, C.key0, C.key1);
-                u4 B = philox(gid, (uint32_t)episode, 1u, 0u, C.key0, C.key1);
-                u4 Cc = philox(gid, (uint32_t)episode, 2u, 0u, C.key0, C.key1);
+                u4 A = philox(gid, (uint32_t)ep_t, 0u, 0u, C.key0, C.key1);
+                u4 B = philox(gid, (uint32_t)ep_t, 1u, 0u, C.key0, C.key1);
+                u4 Cc = philox(gid, (uint32_t)ep_t, 2u, 0u, C.key0, C.key1);
                 const float tz = M.torso[2] + M.base[2] + 0.039f;          // ultrasound.py:184,807
                 f3 noise = mk(0, 0, 0);
                 kst = C.stiffness; kdmp = C.damping;
@@ -574,6 +401,8 @@ __global__ __launch_bounds__(WG) void usim_step_kernel(const DevModel M, const D
 
             float W[6] = {0, 0, 0, 0, 0, 0};          // site-space wrench of the contact forces
             if (TORSO) {
+                const int* tb_nbr = reinterpret_cast<const int*>(lds + TB_NBR);
+                const int* tb_shell = reinterpret_cast<const int*>(lds + TB_SHELL);
                 // prescribed torso base motion: free fall over the 4.7 mm spawn gap, then rest
                 const int tsim = (t > 0) ? t - 1 : 0;
                 float dz = -TORSO_DROP, vz = 0.f, az = 0.f;
@@ -581,89 +410,95 @@ __global__ __launch_bounds__(WG) void usim_step_kernel(const DevModel M, const D
                     float tt = (float)tsim * dt, zf = -0.5f * GRAV * tt * tt;
                     if (zf > -TORSO_DROP) { dz = zf; vz = -GRAV * tt; az = -GRAV; }
                 }
-                // ---- stage s, sdot (coalesced rows) ----
-                if (pass == 0) {
-                    for (int e = 0; e < N_TOP; ++e) { LDSW(L_S, e) = ST(F_S + e); LDSW(L_Y, e) = ST(F_SD + e); }
-                } else {
-                    for (int e = 0; e < N_TOP; ++e) { LDSW(L_S, e) = 0.f; LDSW(L_Y, e) = 0.f; }
+                // ---- stage s, sdot: lane gl of the group owns elements gl, gl+G, ... ----
+                for (int e = gl; e < N_TOP; e += G) {
+                    float se = 0.f, sde = 0.f;
+                    if (pass == 0) { se = ST(F_S + e); sde = ST(F_SD + e); }
+                    EB(GE_S + e) = se; EB(GE_SD + e) = sde;
                 }
+                group_sync();
                 // ---- lattice right-hand side: a_s + w_fix aref_fix + w_ten sum_j aref_ij ----
                 const float kfix = 1.0f / (SI_DMAX * SR_TC * SR_TC), bfix = 2.0f / (SI_DMAX * SR_TC);
                 const float kten = kst / SI_DMAX, bten = kdmp / SI_DMAX;
-                for (int e = 0; e < N_TOP; ++e) {
-                    float se = LDSW(L_S, e), sde = LDSW(L_Y, e);
-                    float r = -(GRAV + az) * c_el_axis[3 * e + 2] + M.wfix * (-bfix * sde - kfix * se);
+                for (int e = gl; e < N_TOP; e += G) {
+                    float se = EB(GE_S + e), sde = EB(GE_SD + e);
+                    float r = -(GRAV + az) * lds[TB_AXIS + 3 * e + 2] + M.wfix * (-bfix * sde - kfix * se);
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
-                        int j = c_el_nbr[4 * e + d];
+                        int j = tb_nbr[4 * e + d];
                         if (j >= -1) {
-                            float sj = (j >= 0) ? LDSW(L_S, j) : 0.f, sdj = (j >= 0) ? LDSW(L_Y, j) : 0.f;
+                            float sj = (j >= 0) ? EB(GE_S + j) : 0.f, sdj = (j >= 0) ? EB(GE_SD + j) : 0.f;
                             r += M.wten * (-bten * (sde - sdj) - kten * (se - sj));
                         }
                     }
-                    LDSW(L_X, e) = r;
+                    EB(GE_X + e) = r;
                 }
-                // ---- a~ = Linv * rhs: 13 row blocks of 8, coefficients wave-uniform (scalar loads) ----
-                for (int blk = 0; blk < LINV_NBLK; ++blk) {
-                    float acc[LINV_BLK] = {0, 0, 0, 0, 0, 0, 0, 0};
-                    const float* lb = c_linv_blk + blk * N_TOP * LINV_BLK;
-                    for (int j = 0; j < N_TOP; ++j) {
-                        float xj = LDSW(L_X, j);
-#pragma unroll
-                        for (int k = 0; k < LINV_BLK; ++k) acc[k] = fmaf(lb[j * LINV_BLK + k], xj, acc[k]);
+                if (gl == 0) EB(GE_X + N_TOP) = 0.f;          // pad word read by the 16-byte row chunks
+                group_sync();
+                // ---- a~ = Linv * rhs: lane gl computes rows gl, gl+G, ...; Linv rows and rhs are read as 16-byte chunks ----
+                {
+                    const float4* xv = reinterpret_cast<const float4*>(&EB(GE_X));
+                    for (int r0 = gl; r0 < N_TOP; r0 += 2 * G) {
+                        const int r1 = (r0 + G < N_TOP) ? r0 + G : r0;
+                        const float4* l0 = reinterpret_cast<const float4*>(&lds[TB_LINV + r0 * LROW]);
+                        const float4* l1 = reinterpret_cast<const float4*>(&lds[TB_LINV + r1 * LROW]);
+                        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+#pragma unroll 5
+                        for (int c = 0; c < LROW / 4; ++c) {
+                            float4 x = xv[c], u = l0[c], v = l1[c];
+                            a0 = fmaf(u.x, x.x, a0); b0 = fmaf(u.y, x.y, b0); a0 = fmaf(u.z, x.z, a0); b0 = fmaf(u.w, x.w, b0);
+                            a1 = fmaf(v.x, x.x, a1); b1 = fmaf(v.y, x.y, b1); a1 = fmaf(v.z, x.z, a1); b1 = fmaf(v.w, x.w, b1);
+                        }
+                        EB(GE_A + r0) = a0 + b0;
+                        if (r0 + G < N_TOP) EB(GE_A + r1) = a1 + b1;
                     }
-#pragma unroll
-                    for (int k = 0; k < LINV_BLK; ++k) if (blk * LINV_BLK + k < N_TOP) LDSW(L_Y, blk * LINV_BLK + k) = acc[k];
                 }
-                // ---- collision: probe capsule vs the 99 element capsules, ascending shell id ----
+                // ---- collision: probe capsule vs the 99 cap spheres; the G lanes test G consecutive elements at a time, the
+                //      wave ballot gives every hit its slot so that the contact list stays sorted by ascending shell id ----
                 f3 cc = K.x - K.sz * C.probe_r;                       // capsule centre one radius behind the tip
                 f3 p1 = cc - K.sy * C.probe_hl, d1 = K.sy * (2.f * C.probe_hl);
                 int nc = 0;
-                int cel[MAXC];
-                float cdist[MAXC];
-#pragma unroll
-                for (int k = 0; k < MAXC; ++k) { cel[k] = 0; cdist[k] = 0.f; }
-                for (int e = 0; e < N_TOP; ++e) {
-                    f3 ax = mk(c_el_axis[3 * e], c_el_axis[3 * e + 1], c_el_axis[3 * e + 2]);
-                    float se = LDSW(L_S, e);
-                    f3 tip = mk(M.torso[0] + c_el_pos[3 * e], M.torso[1] + c_el_pos[3 * e + 1], M.torso[2] + c_el_pos[3 * e + 2] + dz) + ax * (se - ELEM_R);
-                    // element collision geometry = the cap sphere (centre `tip`, radius ELEM_R); DESIGN.md section 2
-                    f3 c2 = tip, c1 = seg_point(p1, d1, tip);
-                    f3 dd = c1 - c2;
-                    float len = sqrtf(dot(dd, dd)), dist = len - (C.probe_r + ELEM_R);
-                    if (dist < 0.f) {
-                        if (nc < MAXC) {
-                            f3 nn = (len > 1e-9f) ? dd * (1.f / len) : mk(0, 0, 1);
-                            f3 pc = c2 + nn * (ELEM_R + 0.5f * dist);
-                            f3 rr = pc - K.x;
-                            f3 ref = (fabsf(nn.x) > 0.9f) ? mk(0, 1, 0) : mk(1, 0, 0);
-                            f3 t1 = cross(nn, ref); t1 = t1 * (1.f / sqrtf(dot(t1, t1)));
-                            const int b = L_X + nc * CS_WORDS;
-                            LDSW(b, CS_N) = nn.x; LDSW(b, CS_N + 1) = nn.y; LDSW(b, CS_N + 2) = nn.z;
-                            LDSW(b, CS_T) = t1.x; LDSW(b, CS_T + 1) = t1.y; LDSW(b, CS_T + 2) = t1.z;
-                            LDSW(b, CS_R) = rr.x; LDSW(b, CS_R + 1) = rr.y; LDSW(b, CS_R + 2) = rr.z;
-                            LDSW(b, CS_E) = __int_as_float(e);
-                            LDSW(b, CS_E + 1) = dist;
-#pragma unroll
-                            for (int k = 0; k < MAXC; ++k) if (k == nc) { cel[k] = e; cdist[k] = dist; }
-                            nc += 1;
-                        } else R.overflow = 1;
+                for (int e0 = 0; e0 < N_TOP; e0 += G) {
+                    const int e = e0 + gl;
+                    bool hit = false;
+                    f3 nn = mk(0, 0, 1), rr = mk(0, 0, 0); float dist = 0.f;
+                    if (e < N_TOP) {
+                        f3 ax = mk(lds[TB_AXIS + 3 * e], lds[TB_AXIS + 3 * e + 1], lds[TB_AXIS + 3 * e + 2]);
+                        float se = EB(GE_S + e);
+                        // element collision geometry = the cap sphere (centre `tip`, radius ELEM_R); DESIGN.md section 2
+                        f3 tip = mk(M.torso[0] + lds[TB_POS + 3 * e], M.torso[1] + lds[TB_POS + 3 * e + 1], M.torso[2] + lds[TB_POS + 3 * e + 2] + dz) + ax * (se - ELEM_R);
+                        f3 c1 = seg_point(p1, d1, tip);
+                        f3 dd = c1 - tip;
+                        float len = sqrtf(dot(dd, dd));
+                        dist = len - (C.probe_r + ELEM_R);
+                        hit = dist < 0.f;
+                        if (hit) {
+                            nn = (len > 1e-9f) ? dd * (1.f / len) : mk(0, 0, 1);
+                            rr = tip + nn * (ELEM_R + 0.5f * dist) - K.x;
+                        }
                     }
+                    const unsigned long long bal = __ballot(hit);
+                    const unsigned gm = (unsigned)(bal >> gbase) & ((1u << G) - 1u);
+                    const int slot = nc + __popc(gm & ((1u << gl) - 1u));
+                    if (hit && slot < MAXC) {
+                        const int b = GE_CG + slot * CG_WORDS;
+                        EB(b + 0) = nn.x; EB(b + 1) = nn.y; EB(b + 2) = nn.z;
+                        EB(b + 3) = rr.x; EB(b + 4) = rr.y; EB(b + 5) = rr.z;
+                        EB(b + 6) = __int_as_float(e); EB(b + 7) = dist;
+                    }
+                    nc += __popc(gm);
                 }
+                if (nc > MAXC) { R.overflow = 1; nc = MAXC; }
                 R.ncon = nc;
+                group_sync();
                 int ncmax = 0;                                       // wave-uniform bound on the contact count
 #pragma unroll
                 for (int k = MAXC; k >= 1; --k) if (ncmax == 0 && __any(nc >= k)) ncmax = k;
                 float gf[MAXC];
+                int cel[MAXC];
 #pragma unroll
-                for (int k = 0; k < MAXC; ++k) gf[k] = 0.f;
+                for (int k = 0; k < MAXC; ++k) { gf[k] = 0.f; cel[k] = (k < nc) ? __float_as_int(EB(GE_CG + k * CG_WORDS + 6)) : 0; }
                 if (ncmax > 0) {
-                    // contact coupling through the lattice: Kc[c2][k] = Linv[e_c2][e_k] / m   (S region is dead now)
-#pragma unroll
-                    for (int k = 0; k < MAXC; ++k)
-#pragma unroll
-                        for (int c2 = 0; c2 < MAXC; ++c2)
-                            if (k < ncmax && c2 < ncmax) LDSW(L_S, k * MAXC + c2) = (k < nc && c2 < nc) ? c_linv[cel[c2] * N_TOP + cel[k]] * (1.0f / ELEM_MASS) : 0.f;
                     float alpha[6], vs[6];
 #pragma unroll
                     for (int a = 0; a < 6; ++a) {
@@ -672,141 +507,143 @@ __global__ __launch_bounds__(WG) void usim_step_kernel(const DevModel M, const D
                         for (int j = 0; j < NJ; ++j) { s = fmaf(J[a][j], qs[j], s); u = fmaf(J[a][j], qd[j], u); }
                         alpha[a] = s; vs[a] = u;
                     }
-                    float ae[MAXC];
-                    const float bcon = 2.0f / (SI_DMAX * SR_TC);
-                    // ---- per-contact row data ----
+                    // ---- contact k lives in the registers of lane k of its group: row directions w, Lambda^-1 w, element
+                    //      coupling g, reference acceleration, regulariser, force; Km[c] = Linv[e_own][e_c] / m ----
+                    const bool own = gl < nc;
+                    float w[3][6], Liw[3][6], g[3], aref[3], invD[3], Rd[3], f[3] = {0.f, 0.f, 0.f}, ae = 0.f, Km[MAXC];
 #pragma unroll
-                    for (int k = 0; k < MAXC; ++k) {
-                        ae[k] = 0.f;
-                        if (k < ncmax && k < nc) {
-                            const int b = L_X + k * CS_WORDS;
-                            const bool on = true;
-                            f3 nn = mk(LDSW(b, CS_N), LDSW(b, CS_N + 1), LDSW(b, CS_N + 2));
-                            f3 t1 = mk(LDSW(b, CS_T), LDSW(b, CS_T + 1), LDSW(b, CS_T + 2));
-                            f3 rr = mk(LDSW(b, CS_R), LDSW(b, CS_R + 1), LDSW(b, CS_R + 2));
-                            f3 t2 = cross(nn, t1);
-                            const int e = on ? cel[k] : 0;
-                            f3 ax = mk(c_el_axis[3 * e], c_el_axis[3 * e + 1], c_el_axis[3 * e + 2]);
-                            float sde = on ? ST(F_SD + e) : 0.f;
-                            if (pass == 1) sde = 0.f;
-                            ae[k] = on ? LDSW(L_Y, e) : 0.f;
-                            float dist = cdist[k];
-                            float xx = fminf(-dist / SI_WIDTH, 1.f);
-                            float yy = (xx < 0.5f) ? 2.f * xx * xx : 1.f - 2.f * (1.f - xx) * (1.f - xx);
-                            float dimp = SI_D0 + yy * (SI_DMAX - SI_D0);
-                            float kk = dimp / (SI_DMAX * SI_DMAX * SR_TC * SR_TC);
-                            float Rn = (1.f - dimp) / dimp * M.invw;
-                            float linv_ee = on ? LDSW(L_S, k * MAXC + k) : 0.f;      // Linv[e][e]/m
-                            LDSW(b, CS_RN) = Rn;
+                    for (int c = 0; c < MAXC; ++c) Km[c] = 0.f;
 #pragma unroll
-                            for (int d = 0; d < 3; ++d) {
-                                f3 dir = (d == 0) ? nn : (d == 1 ? t1 : t2);
-                                f3 rx = cross(rr, dir);
-                                float w[6] = {dir.x, dir.y, dir.z, rx.x, rx.y, rx.z};
-                                float g = -dot(dir, ax);
-                                float vrel = g * sde - dir.z * vz;
-                                float Aii = g * g * linv_ee;
+                    for (int d = 0; d < 3; ++d) {
+                        g[d] = 0.f; aref[d] = 0.f; invD[d] = 0.f; Rd[d] = 0.f;
 #pragma unroll
-                                for (int a = 0; a < 6; ++a) {
-                                    float s = 0.f;
+                        for (int a = 0; a < 6; ++a) { w[d][a] = 0.f; Liw[d][a] = 0.f; }
+                    }
+                    if (own) {
+                        const int b = GE_CG + gl * CG_WORDS;
+                        f3 nn = mk(EB(b + 0), EB(b + 1), EB(b + 2)), rr = mk(EB(b + 3), EB(b + 4), EB(b + 5));
+                        const int e = __float_as_int(EB(b + 6));
+                        const float dist = EB(b + 7);
+                        f3 ref = (fabsf(nn.x) > 0.9f) ? mk(0, 1, 0) : mk(1, 0, 0);
+                        f3 t1 = cross(nn, ref); t1 = t1 * (1.f / sqrtf(dot(t1, t1)));
+                        f3 t2 = cross(nn, t1);
+                        f3 ax = mk(lds[TB_AXIS + 3 * e], lds[TB_AXIS + 3 * e + 1], lds[TB_AXIS + 3 * e + 2]);
+                        const float sde = EB(GE_SD + e);
+                        const float bcon = 2.0f / (SI_DMAX * SR_TC);
+                        float xx = fminf(-dist / SI_WIDTH, 1.f);
+                        float yy = (xx < 0.5f) ? 2.f * xx * xx : 1.f - 2.f * (1.f - xx) * (1.f - xx);
+                        float dimp = SI_D0 + yy * (SI_DMAX - SI_D0);
+                        float kk = dimp / (SI_DMAX * SI_DMAX * SR_TC * SR_TC);
+                        float Rn = (1.f - dimp) / dimp * M.invw;
 #pragma unroll
-                                    for (int bb = 0; bb < 6; ++bb) s = fmaf((a >= bb) ? Li[PK(a, bb)] : Li[PK(bb, a)], w[bb], s);
-                                    LDSW(b, CS_LIW + d * 6 + a) = s;
-                                    Aii = fmaf(w[a], s, Aii);
-                                    vrel = fmaf(w[a], vs[a], vrel);
-                                }
-                                LDSW(b, CS_G + d) = g;
-                                LDSW(b, CS_AREF + d) = -bcon * vrel - (d == 0 ? kk * dist : 0.f);
-                                LDSW(b, CS_AD + d) = Aii;
-                                LDSW(b, CS_F + d) = 0.f;
+                        for (int c = 0; c < MAXC; ++c) if (c < nc) Km[c] = lds[TB_LINV + e * LROW + cel[c]] * (1.0f / ELEM_MASS);
+                        float linv_ee = lds[TB_LINV + e * LROW + e] * (1.0f / ELEM_MASS);
+                        ae = EB(GE_A + e);
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            f3 dir = (d == 0) ? nn : (d == 1 ? t1 : t2);
+                            f3 rx = cross(rr, dir);
+                            w[d][0] = dir.x; w[d][1] = dir.y; w[d][2] = dir.z; w[d][3] = rx.x; w[d][4] = rx.y; w[d][5] = rx.z;
+                            g[d] = -dot(dir, ax);
+                            float vrel = g[d] * sde - dir.z * vz;
+                            float Aii = g[d] * g[d] * linv_ee;
+#pragma unroll
+                            for (int a = 0; a < 6; ++a) {
+                                float s = 0.f;
+#pragma unroll
+                                for (int bb = 0; bb < 6; ++bb) s = fmaf((a >= bb) ? Li[PK(a, bb)] : Li[PK(bb, a)], w[d][bb], s);
+                                Liw[d][a] = s;
+                                Aii = fmaf(w[d][a], s, Aii);
+                                vrel = fmaf(w[d][a], vs[a], vrel);
                             }
+                            aref[d] = -bcon * vrel - (d == 0 ? kk * dist : 0.f);
+                            Rd[d] = (d == 0) ? Rn : Rn * (1.0f / IMPRATIO);
+                            invD[d] = 1.0f / (Aii + Rd[d]);
                         }
                     }
-                    // ---- projected Gauss-Seidel on the dual over the contact rows (fixed sweeps, cold start) ----
+                    // ---- projected Gauss-Seidel on the dual over the contact rows (fixed sweeps, cold start).  Contacts are
+                    //      visited in ascending order; the owner lane updates its three rows and the cone projection, then
+                    //      the new site acceleration and the element impulse are broadcast to the group through DPP ----
                     for (int it = 0; it < C.pgs_iters; ++it) {
 #pragma unroll
                         for (int k = 0; k < MAXC; ++k) {
-                            if (k < ncmax && k < nc) {
-                                const int b = L_X + k * CS_WORDS;
-                                const bool on = true;
-                                f3 nn = mk(LDSW(b, CS_N), LDSW(b, CS_N + 1), LDSW(b, CS_N + 2));
-                                f3 t1 = mk(LDSW(b, CS_T), LDSW(b, CS_T + 1), LDSW(b, CS_T + 2));
-                                f3 rr = mk(LDSW(b, CS_R), LDSW(b, CS_R + 1), LDSW(b, CS_R + 2));
-                                f3 t2 = cross(nn, t1);
-                                float Rn = LDSW(b, CS_RN);
-                                float f[3] = {LDSW(b, CS_F), LDSW(b, CS_F + 1), LDSW(b, CS_F + 2)};
-                                float g[3] = {LDSW(b, CS_G), LDSW(b, CS_G + 1), LDSW(b, CS_G + 2)};
+                            if (k < ncmax) {
+                                float Gk = 0.f;
+                                if (gl == k && own) {
 #pragma unroll
-                                for (int d = 0; d < 3; ++d) {
-                                    f3 dir = (d == 0) ? nn : (d == 1 ? t1 : t2);
-                                    f3 rx = cross(rr, dir);
-                                    float Rd = (d == 0) ? Rn : Rn * (1.0f / IMPRATIO);
-                                    float res = g[d] * ae[k] - LDSW(b, CS_AREF + d) + Rd * f[d];
-                                    res += dir.x * alpha[0] + dir.y * alpha[1] + dir.z * alpha[2] + rx.x * alpha[3] + rx.y * alpha[4] + rx.z * alpha[5];
-                                    float fn = f[d] - res / (LDSW(b, CS_AD + d) + Rd);
-                                    if (d == 0) fn = fmaxf(fn, 0.f);
-                                    float df = on ? fn - f[d] : 0.f;
-                                    f[d] += df;
+                                    for (int d = 0; d < 3; ++d) {
+                                        float res = g[d] * ae - aref[d] + Rd[d] * f[d];
 #pragma unroll
-                                    for (int a = 0; a < 6; ++a) alpha[a] = fmaf(LDSW(b, CS_LIW + d * 6 + a), df, alpha[a]);
-                                    float gd = g[d] * df;
+                                        for (int a = 0; a < 6; ++a) res = fmaf(w[d][a], alpha[a], res);
+                                        float fn = f[d] - res * invD[d];
+                                        if (d == 0) fn = fmaxf(fn, 0.f);
+                                        float df = fn - f[d];
+                                        f[d] = fn;
 #pragma unroll
-                                    for (int c2 = 0; c2 < MAXC; ++c2) if (c2 < ncmax) ae[c2] = fmaf(LDSW(L_S, k * MAXC + c2), gd, ae[c2]);
-                                }
-                                // elliptic cone: |f_t| <= mu f_n
-                                float ft = sqrtf(f[1] * f[1] + f[2] * f[2]), lim = mu * f[0];
-                                if (on && ft > lim) {
-                                    float sc = (ft > 0.f) ? lim / ft : 0.f;
-#pragma unroll
-                                    for (int d = 1; d < 3; ++d) {
-                                        float df = f[d] * sc - f[d];
-                                        f[d] += df;
-#pragma unroll
-                                        for (int a = 0; a < 6; ++a) alpha[a] = fmaf(LDSW(b, CS_LIW + d * 6 + a), df, alpha[a]);
+                                        for (int a = 0; a < 6; ++a) alpha[a] = fmaf(Liw[d][a], df, alpha[a]);
                                         float gd = g[d] * df;
+                                        ae = fmaf(Km[k], gd, ae);
+                                        Gk += gd;
+                                    }
+                                    // elliptic cone: |f_t| <= mu f_n
+                                    float ft = sqrtf(f[1] * f[1] + f[2] * f[2]), lim = mu * f[0];
+                                    if (ft > lim) {
+                                        float sc = (ft > 0.f) ? lim / ft : 0.f;
 #pragma unroll
-                                        for (int c2 = 0; c2 < MAXC; ++c2) if (c2 < ncmax) ae[c2] = fmaf(LDSW(L_S, k * MAXC + c2), gd, ae[c2]);
+                                        for (int d = 1; d < 3; ++d) {
+                                            float df = f[d] * sc - f[d];
+                                            f[d] += df;
+#pragma unroll
+                                            for (int a = 0; a < 6; ++a) alpha[a] = fmaf(Liw[d][a], df, alpha[a]);
+                                            float gd = g[d] * df;
+                                            ae = fmaf(Km[k], gd, ae);
+                                            Gk += gd;
+                                        }
                                     }
                                 }
-                                LDSW(b, CS_F) = f[0]; LDSW(b, CS_F + 1) = f[1]; LDSW(b, CS_F + 2) = f[2];
+#pragma unroll
+                                for (int a = 0; a < 6; ++a) alpha[a] = group_bcast<G>(alpha[a], k);
+                                Gk = group_bcast<G>(Gk, k);
+                                if (own && gl != k) ae = fmaf(Km[k], Gk, ae);
                             }
                         }
                     }
-                    // ---- contact wrench on the site, force along each element axis ----
+                    // ---- contact wrench on the site and impulse along each element axis: owners publish, everyone sums ----
+                    if (own) {
+                        f3 Fw = mk(w[0][0] * f[0] + w[1][0] * f[1] + w[2][0] * f[2], w[0][1] * f[0] + w[1][1] * f[1] + w[2][1] * f[2],
+                                   w[0][2] * f[0] + w[1][2] * f[1] + w[2][2] * f[2]);
+                        f3 Tw = mk(w[0][3] * f[0] + w[1][3] * f[1] + w[2][3] * f[2], w[0][4] * f[0] + w[1][4] * f[1] + w[2][4] * f[2],
+                                   w[0][5] * f[0] + w[1][5] * f[1] + w[2][5] * f[2]);
+                        const int b = GE_WS + gl * 8;
+                        EB(b + 0) = Fw.x; EB(b + 1) = Fw.y; EB(b + 2) = Fw.z; EB(b + 3) = Tw.x; EB(b + 4) = Tw.y; EB(b + 5) = Tw.z;
+                        EB(b + 6) = (g[0] * f[0] + g[1] * f[1] + g[2] * f[2]) * (1.0f / ELEM_MASS);
+                    }
+                    group_sync();
 #pragma unroll
                     for (int k = 0; k < MAXC; ++k) {
                         if (k < ncmax && k < nc) {
-                            const int b = L_X + k * CS_WORDS;
-                            const bool on = true;
-                            f3 nn = mk(LDSW(b, CS_N), LDSW(b, CS_N + 1), LDSW(b, CS_N + 2));
-                            f3 t1 = mk(LDSW(b, CS_T), LDSW(b, CS_T + 1), LDSW(b, CS_T + 2));
-                            f3 rr = mk(LDSW(b, CS_R), LDSW(b, CS_R + 1), LDSW(b, CS_R + 2));
-                            f3 t2 = cross(nn, t1);
-                            float f0 = on ? LDSW(b, CS_F) : 0.f, f1 = on ? LDSW(b, CS_F + 1) : 0.f, f2 = on ? LDSW(b, CS_F + 2) : 0.f;
-                            f3 Fw = nn * f0 + t1 * f1 + t2 * f2;
-                            f3 Tw = cross(rr, Fw);
-                            W[0] += Fw.x; W[1] += Fw.y; W[2] += Fw.z; W[3] += Tw.x; W[4] += Tw.y; W[5] += Tw.z;
-                            gf[k] = LDSW(b, CS_G) * f0 + LDSW(b, CS_G + 1) * f1 + LDSW(b, CS_G + 2) * f2;
-                            if (!on) gf[k] = 0.f;
+                            const int b = GE_WS + k * 8;
+#pragma unroll
+                            for (int a = 0; a < 6; ++a) W[a] += EB(b + a);
+                            gf[k] = EB(b + 6);
                         }
                     }
                 }
-                // ---- element accelerations a = a~ + Linv[:, e_c] gf_c / m, semi-implicit Euler, write back ----
-                if (pass == 0) {
-                    for (int e = 0; e < N_TOP; ++e) {
-                        float a = LDSW(L_Y, e);
+                // ---- element accelerations a = a~ + Linv[:, e_c] gf_c, semi-implicit Euler, write back ----
+                for (int e = gl; e < N_TOP; e += G) {
+                    float sdn = 0.f, sn = 0.f;
+                    if (pass == 0) {
+                        float a = EB(GE_A + e);
 #pragma unroll
                         for (int k = 0; k < MAXC; ++k)
-                            if (k < ncmax && k < nc) a = fmaf(c_linv[cel[k] * N_TOP + e] * (1.0f / ELEM_MASS), gf[k], a);   // Linv symmetric: row cel[k]
-                        float sdn = ST(F_SD + e) + dt * a;
-                        float sn = ST(F_S + e) + dt * sdn;
-                        if (valid) { ST(F_SD + e) = sdn; ST(F_S + e) = sn; }
+                            if (k < ncmax && k < nc) a = fmaf(lds[TB_LINV + e * LROW + cel[k]], gf[k], a);
+                        sdn = EB(GE_SD + e) + dt * a;
+                        sn = EB(GE_S + e) + dt * sdn;
                     }
-                } else if (valid) {
-                    for (int e = 0; e < N_TOP; ++e) { ST(F_SD + e) = 0.f; ST(F_S + e) = 0.f; }
+                    if (valid && (pass == 0 || io.ahead == 0)) { ST(F_SD + e) = sdn; ST(F_S + e) = sn; }
                 }
 #pragma unroll
-                for (int k = 0; k < MAXC; ++k) R.con_shell[k] = (k < nc) ? c_el_shell[cel[k]] : -1;
+                for (int k = 0; k < MAXC; ++k) R.con_shell[k] = (k < nc) ? tb_shell[cel[k]] : -1;
             } else {
 #pragma unroll
                 for (int k = 0; k < MAXC; ++k) R.con_shell[k] = -1;
@@ -912,7 +749,7 @@ __global__ __launch_bounds__(WG) void usim_step_kernel(const DevModel M, const D
                     }
                     epret += reward;
                     if (R.overflow) status |= 1;
-                    if (valid) {
+                    if (store) {
                         io.rew[ei] = reward;
                         io.done[ei] = done ? 1 : 0;
                         if (io.contacts) {
@@ -931,16 +768,47 @@ __global__ __launch_bounds__(WG) void usim_step_kernel(const DevModel M, const D
                     }
                     need = done && auto_reset;
                 }
-                if (valid && io.obs && (pass == 1 || !need)) {
+                if (pass == 1 && io.ahead > 0) {
+                    // reset computed ahead of time: park it in the bank slot of episode ep_t
+                    if (store && need) {
+                        const int sl = ep_t & 1;
+#pragma unroll
+                        for (int i = 0; i < NJ; ++i) BK(sl, BQ0 + i) = q[i];
+                        BK(sl, BTS) = ts.x; BK(sl, BTS + 1) = ts.y; BK(sl, BTS + 2) = ts.z; BK(sl, BTE) = te.x; BK(sl, BTE + 1) = te.y; BK(sl, BTE + 2) = te.z;
+                        BK(sl, BU0) = u0; BK(sl, BKST) = kst; BK(sl, BKDMP) = kdmp; BK(sl, BMU) = mu; BK(sl, BFZ) = fzbar;
+#pragma unroll
+                        for (int a = 0; a < OBS_DIM; ++a) BK(sl, BOBS + a) = obs[a];
+                        BKI(sl, BSTATUS) = R.overflow ? 1 : 0;
+                    }
+                } else if (store && io.obs && (pass == 1 ? need : !need)) {
 #pragma unroll
                     for (int a = 0; a < OBS_DIM; ++a) io.obs[(size_t)ei * OBS_DIM + a] = obs[a];
                 }
+                if (pass == 1 && R.overflow) status |= 1;
             }
         }
+    } while (0);
+
+    if (MODE == 0 && need) {
+        // ================= auto-reset: adopt the initial state prepared in the reset bank (SB3 VecEnv semantics: the
+        // observation returned for a finished environment is its reset observation) and queue the slot for refill ==========
+        episode += 1;
+        const int sl = episode & 1;
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) { q[i] = BK(sl, BQ0 + i); q0[i] = q[i]; qd[i] = 0.f; }
+        ts = mk(BK(sl, BTS), BK(sl, BTS + 1), BK(sl, BTS + 2)); te = mk(BK(sl, BTE), BK(sl, BTE + 1), BK(sl, BTE + 2));
+        u0 = BK(sl, BU0); kst = BK(sl, BKST); kdmp = BK(sl, BKDMP); mu = BK(sl, BMU); fzbar = BK(sl, BFZ);
+        t = 0; touched = 0; fzprev = 0.f; dfz = 0.f; vbar = 0.f; epret = 0.f; status = BKI(sl, BSTATUS);
+        if (store && io.obs) {
+#pragma unroll
+            for (int a = 0; a < OBS_DIM; ++a) io.obs[(size_t)ei * OBS_DIM + a] = BK(sl, BOBS + a);
+        }
+        if (TORSO && valid) for (int e = gl; e < N_TOP; e += G) { ST(F_S + e) = 0.f; ST(F_SD + e) = 0.f; }
+        if (store && io.list_out) { const int idx = atomicAdd(io.count, 1); io.list_out[idx] = env; }
     }
 
     // ---------------- store state ----------------
-    if (valid) {
+    if (store && !(MODE == 1 && (io.ahead > 0 || !need))) {
 #pragma unroll
         for (int i = 0; i < NJ; ++i) { ST(F_Q + i) = q[i]; ST(F_QD + i) = qd[i]; ST(F_Q0 + i) = q0[i]; }
         ST(F_TS) = ts.x; ST(F_TS + 1) = ts.y; ST(F_TS + 2) = ts.z; ST(F_TE) = te.x; ST(F_TE + 1) = te.y; ST(F_TE + 2) = te.z;
@@ -950,7 +818,11 @@ __global__ __launch_bounds__(WG) void usim_step_kernel(const DevModel M, const D
     }
 #undef ST
 #undef STI
+#undef EB
+#undef BK
+#undef BKI
 }
+
 
 // synthetic actions of BASELINE.md section 4 (same stream as the in-kernel LF_RANDOM_ACT path)
 __global__ void usim_random_actions_kernel(const DevCfg C, int n, long long rstep, float* __restrict__ act) {

@@ -9,12 +9,12 @@ from oracle_lib import Oracle
 usim = importlib.import_module("robotic-ultrasound-imaging_amd")
 np.set_printoptions(precision=6, suppress=True, linewidth=220)
 
-def compare(n=256, steps=200, torso="soft", mode="tracking", seed=3):
+def compare(n=256, steps=200, torso="soft", mode="tracking", seed=3, lpe=0):
     kw = usim.default_robosuite_kwargs(); kw["controller_configs"]["impedance_mode"] = mode
-    env = usim.UltrasoundVecEnv(n, seed=seed, torso=torso, **kw)
+    env = usim.UltrasoundVecEnv(n, seed=seed, torso=torso, lanes_per_env=lpe, **kw)
     ora = Oracle(n, precision="f64", mode=mode, torso="top" if torso == "soft" else "none", seed=seed)
     og = env.reset(); oo = ora.reset()
-    print(f"[{torso}/{mode}] reset obs max abs diff", np.abs(og - oo).max(), "per-channel", np.abs(og - oo).max(0))
+    print(f"[{torso}/{mode}/lpe{lpe}] reset obs max abs diff", np.abs(og - oo).max(), "per-channel", np.abs(og - oo).max(0))
     sg = env.get_state(); so = ora.get_state()
     for k in ("q", "q0", "traj_start", "traj_end", "u0", "fzbar", "stiffness", "damping", "mu"):
         print("   reset", k, np.abs(np.asarray(sg[k], dtype=np.float64) - so[k]).max())
@@ -51,18 +51,20 @@ def compare(n=256, steps=200, torso="soft", mode="tracking", seed=3):
     print("   worst per-channel rel diff over run", W.max(0))
     env.close()
 
-def bench(n=4096, steps=200, torso="soft"):
-    env = usim.UltrasoundVecEnv(n, torso=torso, **usim.default_robosuite_kwargs())
+def bench(n=4096, steps=200, torso="soft", lpe=0):
+    env = usim.UltrasoundVecEnv(n, torso=torso, lanes_per_env=lpe, **usim.default_robosuite_kwargs())
     env.reset_tensor(); env.rollout_random(0, 50); torch.cuda.synchronize()
     ms = env.time_steps(50, steps)
-    print(f"[bench {torso}] n={n} {ms / steps * 1e3:.1f} us/step  {n * steps / ms * 1e3:.3e} env-steps/s")
+    print(f"[bench {torso} lpe{lpe}] n={n} {ms / steps * 1e3:.1f} us/step  {n * steps / ms * 1e3:.3e} env-steps/s")
     env.close()
 
 if __name__ == "__main__":
     t0 = time.time()
     print(torch.cuda.get_device_name(0))
-    compare(256, 200, "rigid")
-    compare(256, 200, "soft")
-    compare(64, 100, "soft", mode="fixed")
-    bench(4096, 200, "rigid"); bench(4096, 200, "soft"); bench(8192, 200, "soft"); bench(16384, 100, "soft")
+    for lpe in (8, 16):
+        compare(80, 120, "soft", lpe=lpe)
+    compare(80, 60, "rigid")
+    for lpe in (8, 16):
+        bench(4096, 300, "soft", lpe)
+    bench(4096, 300, "rigid"); bench(8192, 300, "soft", 8); bench(8192, 300, "soft", 16); bench(16384, 200, "soft", 8)
     print("total", time.time() - t0)
