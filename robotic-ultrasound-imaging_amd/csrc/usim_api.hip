@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -25,13 +26,10 @@ struct usim_handle {
     DevCfg C;
     float* state = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // reset bank machinery: refill kernels run on a side stream, one step behind the step kernels
-    hipStream_t side = nullptr;
-    hipEvent_t ev_step[2] = {nullptr, nullptr}, ev_refill[2] = {nullptr, nullptr};
-    int* d_list = nullptr;            // [2][npad] environments that consumed a bank slot at step s (ring = s & 1)
-    int* d_count = nullptr;           // [2]
-    long long step_index = 0;
-    bool refill_pending[2] = {false, false};
+    // reset bank machinery
+    int2* d_items = nullptr;          // refill work list, capacity 2 * n * BANK_DEPTH
+    int* d_count = nullptr;           // [0] items, [1] finished workgroups of the running refill
+    long long steps_since_refill = 0;
     int bank_row0 = 0;
     size_t lds_bytes = 0;
     std::string hip_err;
@@ -235,19 +233,14 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
     C.probe_r = (float)cfg->probe_radius; C.probe_hl = (float)cfg->probe_halflen;
     h->nfields = h->n_el ? F_TOTAL_TOP : F_NSCALAR;
     h->bank_row0 = h->nfields;                                  // two reset-bank slots follow the live state rows
-    size_t bytes = (size_t)(h->nfields + 2 * BANK_WORDS) * h->npad * sizeof(float);
+    size_t bytes = (size_t)(h->nfields + BANK_ROWS) * h->npad * sizeof(float);
     HIPCHK(h, hipMalloc(&h->state, bytes));
     HIPCHK(h, hipMemset(h->state, 0, bytes));
-    HIPCHK(h, hipMalloc(&h->d_list, 2 * (size_t)h->npad * sizeof(int)));
+    HIPCHK(h, hipMalloc(&h->d_items, 2 * (size_t)h->n * BANK_DEPTH * sizeof(int2)));
     HIPCHK(h, hipMalloc(&h->d_count, 2 * sizeof(int)));
     HIPCHK(h, hipMemset(h->d_count, 0, 2 * sizeof(int)));
     HIPCHK(h, hipEventCreate(&h->ev0));
     HIPCHK(h, hipEventCreate(&h->ev1));
-    HIPCHK(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-    for (int r = 0; r < 2; ++r) {
-        HIPCHK(h, hipEventCreateWithFlags(&h->ev_step[r], hipEventDisableTiming));
-        HIPCHK(h, hipEventCreateWithFlags(&h->ev_refill[r], hipEventDisableTiming));
-    }
     // kernel mapping: rigid torso -> one environment per lane; soft torso -> 8 or 16 lanes per
     // environment (auto = 16, which puts one 4-wave workgroup on every CU at 4096 envs/GPU)
     h->lpe = h->n_el ? (cfg->lanes_per_env == 0 ? 16 : cfg->lanes_per_env) : 1;
@@ -279,10 +272,9 @@ void usim_destroy(usim_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     if (h->state) (void)hipFree(h->state);
-    if (h->d_list) (void)hipFree(h->d_list);
+    if (h->d_items) (void)hipFree(h->d_items);
     if (h->d_count) (void)hipFree(h->d_count);
-    if (h->side) (void)hipStreamDestroy(h->side);
-    for (int r = 0; r < 2; ++r) { if (h->ev_step[r]) (void)hipEventDestroy(h->ev_step[r]); if (h->ev_refill[r]) (void)hipEventDestroy(h->ev_refill[r]); }
+
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -292,19 +284,28 @@ int usim_num_envs(const usim_handle* h) { return h ? h->n : USIM_ERR_INVALID; }
 int usim_action_dim(const usim_handle* h) { return h ? h->adim : USIM_ERR_INVALID; }
 int usim_num_elements(const usim_handle* h) { return h ? h->n_el : USIM_ERR_INVALID; }
 
-// direct reset of the selected environments followed by the two bank fills (episodes +1 and +2), all on `stream`
+// compute every episode on the refill work list into the reset bank (grid-stride over the list, one launch)
+static int bank_refill(usim_handle* h, hipStream_t s) {
+    DevIO b{}; b.items = h->d_items; b.count = h->d_count; b.refill = 1;
+    h->steps_since_refill = 0;
+    return launch<1>(h, b, 0, 0, s);
+}
+
+// order episodes +1..+BANK_DEPTH for the selected environments and compute them
+static int bank_fill(usim_handle* h, const uint8_t* mask_dev, hipStream_t s) {
+    const int total = h->n * BANK_DEPTH;
+    hipLaunchKernelGGL(usim_bank_items_kernel, dim3((total + 255) / 256), dim3(256), 0, s, h->state, h->n, h->npad, mask_dev, h->d_items, h->d_count);
+    HIPCHK(h, hipGetLastError());
+    return bank_refill(h, s);
+}
+
+// direct reset of the selected environments followed by the fill of their bank rings, all on `stream`
 static int reset_common(usim_handle* h, const uint8_t* mask_dev, const float* params_dev, float* obs_dev, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    // outstanding refills target bank slots this reset is about to recompute
-    for (int r = 0; r < 2; ++r)
-        if (h->refill_pending[r]) { HIPCHK(h, hipStreamWaitEvent(s, h->ev_refill[r], 0)); h->refill_pending[r] = false; }
-    DevIO io{}; io.mask = mask_dev; io.obs = obs_dev; io.reset_params = params_dev; io.ahead = 0;
+    DevIO io{}; io.mask = mask_dev; io.obs = obs_dev; io.reset_params = params_dev; io.refill = 0;
     int rc = launch<1>(h, io, 0, 0, s);
-    for (int ahead = 1; ahead <= 2 && rc == USIM_OK; ++ahead) {
-        DevIO b{}; b.mask = mask_dev; b.ahead = ahead;
-        rc = launch<1>(h, b, 0, 0, s);
-    }
-    return rc;
+    if (rc) return rc;
+    return bank_fill(h, mask_dev, s);
 }
 
 int usim_reset(usim_handle* h, const uint8_t* mask_dev, float* obs_dev, void* stream) {
@@ -325,27 +326,18 @@ static int fill_io(const usim_step_io* s, DevIO& io, bool need_act) {
     return USIM_OK;
 }
 
-// One step on `stream`.  With auto-reset the step kernel of step s appends the environments that consumed a bank slot to
-// list[s & 1]; the refill kernel for that list runs on the side stream and only has to be finished before step s + 2
-// (an environment reset at step s can finish again at s + 1 at the earliest, which takes the OTHER slot).
+// One step on `stream`.  A finished environment adopts its next episode from the reset bank inside the step kernel (a copy
+// of 38 words) and orders the episode that will reuse the slot.  An environment consumes at most one slot per step, so a
+// refill launch every BANK_DEPTH steps keeps every ring valid by construction; in that launch the initial-pose IK and the
+// zero-torque forward pass of all environments that finished during the period run side by side.
 static int step_common(usim_handle* h, DevIO io, int flags, long long rstep, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!(flags & LF_AUTO_RESET)) return launch<0>(h, io, flags, rstep, s);
-    const int ring = (int)(h->step_index & 1);
-    if (h->refill_pending[ring]) { HIPCHK(h, hipStreamWaitEvent(s, h->ev_refill[ring], 0)); h->refill_pending[ring] = false; }
-    io.list_out = h->d_list + (size_t)ring * h->npad; io.count = h->d_count + ring;
+    io.items = h->d_items; io.count = h->d_count;
     int rc = launch<0>(h, io, flags, rstep, s);
     if (rc) return rc;
-    HIPCHK(h, hipEventRecord(h->ev_step[ring], s));
-    HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_step[ring], 0));
-    DevIO b{}; b.list = h->d_list + (size_t)ring * h->npad; b.count = h->d_count + ring; b.ahead = 2;
-    rc = launch<1>(h, b, 0, 0, h->side);
-    if (rc) return rc;
-    HIPCHK(h, hipMemsetAsync(h->d_count + ring, 0, sizeof(int), h->side));
-    HIPCHK(h, hipEventRecord(h->ev_refill[ring], h->side));
-    h->refill_pending[ring] = true;
-    h->step_index += 1;
-    return USIM_OK;
+    if (++h->steps_since_refill >= BANK_DEPTH) rc = bank_refill(h, s);
+    return rc;
 }
 
 int usim_step(usim_handle* h, const usim_step_io* s, int auto_reset, void* stream) {
@@ -437,12 +429,10 @@ int usim_set_state(usim_handle* h, const float* scalars, const float* lattice) {
             }
     }
     HIPCHK(h, hipMemcpy(h->state, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice));
-    // the bank is a pure function of (seed, env, episode): rebuild both slots for the restored episode counters
-    h->refill_pending[0] = h->refill_pending[1] = false;
+    // the bank is a pure function of (seed, env, episode): rebuild every ring for the restored episode counters
     HIPCHK(h, hipMemset(h->d_count, 0, 2 * sizeof(int)));
-    for (int ahead = 1; ahead <= 2; ++ahead) {
-        DevIO b{}; b.ahead = ahead;
-        int rc = launch<1>(h, b, 0, 0, nullptr);
+    {
+        int rc = bank_fill(h, nullptr, nullptr);
         if (rc) return rc;
     }
     HIPCHK(h, hipDeviceSynchronize());

@@ -58,16 +58,18 @@ struct DevIO {
     float* act_out;                 // [n][A] drawn actions (LF_RANDOM_ACT) or nullptr
     const uint8_t* mask;            // reset mask (reset-only launches)
     const float* reset_params;      // [n][13] explicit reset draws or nullptr
-    const int* list;                // refill launches: environments to recompute (nullptr: use mask / all)
-    int* list_out;                  // step launches: environments that consumed a bank slot are appended here
-    int* count;                     // length of list / list_out
+    int2* items;                    // refill work list of (env, episode): appended by step kernels, consumed by refill launches
+    int* count;                     // [0] number of items, [1] finished workgroups of the running refill launch
     int bank_row0;                  // first row of the reset bank inside the state block
-    int ahead;                      // reset launches: 0 = reset the live state, k > 0 = fill the bank slot of episode + k
+    int refill;                     // reset launches: 0 = reset the live state of the masked envs, 1 = compute the listed bank episodes
 };
 
 enum LaunchFlags : int { LF_AUTO_RESET = 1, LF_RANDOM_ACT = 4 };
 
-// reset bank: two slots per environment (episode parity), each holding a ready-made initial state + reset observation
+// reset bank: BANK_DEPTH ring slots per environment (slot = episode mod depth), each holding a ready-made initial state and
+// the reset observation of one future episode (a pure function of seed, global env id and episode index)
 enum BankField : int { BQ0 = 0, BTS = 7, BTE = 10, BU0 = 13, BKST = 14, BKDMP = 15, BMU = 16, BFZ = 17, BOBS = 18, BSTATUS = 37, BANK_WORDS = 38 };
+constexpr int BANK_DEPTH = 32;
+constexpr int BANK_ROWS = BANK_DEPTH * BANK_WORDS;
 
 }  // namespace usim

@@ -95,27 +95,33 @@ struct StepOut {               // results of one forward pass that the env logic
 
 // MODE 0: one env.step() per environment; a finished environment takes its next initial state from the reset bank.
 // MODE 1: reset computation (draws, initial-pose IK, zero-torque forward pass) for the environments selected by the mask
-//         or by a refill list, written either to the live state (io.ahead == 0) or to the reset bank (episode + io.ahead).
+//         (written to the live state) or for the (env, episode) items of the refill work list (written to the reset bank).
 template <int TORSO, int G, int MODE>
 __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevModel M, const DevCfg C, float* __restrict__ st, int n, int npad,
                                                                       const DevIO io, int flags, long long rstep) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // step waves outrank the background refill waves that may share their SIMD (priority, then age, arbitrates VALU issue)
+    __builtin_amdgcn_s_setprio(MODE == 0 ? 3 : 0);
     constexpr int EPW = GroupGeom<G>::EPW, EPB = GroupGeom<G>::EPB, NT = GroupGeom<G>::NT;
     static_assert(!TORSO || G >= MAXC, "the contact solver gives every contact its own lane of the group");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gl = lane % G, ge = lane / G;           // lane within the group, group (= environment) within the wave
     const int gbase = lane - gl;                      // ballot bit of the group's first lane
     const int eb = wave * EPW + ge;                   // environment within the workgroup
+    // refill launches walk the work list with a grid-stride loop; every other launch runs the body once
+    const bool refill = (MODE == 1) && io.refill != 0;
+    const int item_cnt = refill ? io.count[0] : 1;
+    for (int item0 = refill ? (int)blockIdx.x * EPB : 0; item0 < item_cnt; item0 += refill ? (int)gridDim.x * EPB : 1) {
     int env = blockIdx.x * EPB + eb;
     bool valid = env < n;                             // lattice rows are stored by every lane of the group
-    if (MODE == 1 && io.list) {                       // refill launch: environments come from the list the step kernel appended to
-        const int cnt = *io.count;
-        if ((int)blockIdx.x * EPB >= cnt) return;
-        valid = env < cnt;
-        env = valid ? io.list[env] : 0;
+    int item_ep = 0;
+    if (refill) {
+        valid = item0 + eb < item_cnt;
+        const int2 it = valid ? io.items[item0 + eb] : make_int2(0, 0);
+        env = it.x; item_ep = it.y;
     }
     const bool store = valid && gl == 0;              // per-environment scalars and outputs by its first lane
-    const int ei = valid ? env : n - 1;               // clamp so that every lane has something to read; stores are guarded
+    const int ei = valid ? env : (refill ? 0 : n - 1);               // clamp so that every lane has something to read; stores are guarded
     constexpr bool reset_only = (MODE == 1);
     const bool auto_reset = (flags & LF_AUTO_RESET) != 0;
 #define ST(f) st[(size_t)(f) * npad + ei]
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
 #define EB(off) lds[TB_WORDS + eb * GE_STRIDE + (off)]
 #define BK(slot, f) st[(size_t)(io.bank_row0 + (slot) * BANK_WORDS + (f)) * npad + ei]
 #define BKI(slot, f) (reinterpret_cast<int*>(st))[(size_t)(io.bank_row0 + (slot) * BANK_WORDS + (f)) * npad + ei]
-    if (TORSO) {
+    if (TORSO && item0 == (refill ? (int)blockIdx.x * EPB : 0)) {
         // workgroup-resident copy of the lattice tables (inverse 99 x 100, element positions/axes/neighbours/shell ids):
         // 16-byte loads, all issued before the first LDS store
         const float4* src = reinterpret_cast<const float4*>(c_tables);
@@ -168,6 +174,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
     }
 
     bool need = reset_only ? (io.mask ? io.mask[ei] != 0 : true) : false;   // lanes that (re)initialise in pass 1
+    if (refill) need = valid;
     bool done = false;
     const float dt = C.dt;
 
@@ -179,8 +186,8 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
             if (!__any(need)) break;
             if (need) {
                 // ================= reset draws (ultrasound.py:416-478) =================
-                ep_t = episode + (io.ahead > 0 ? io.ahead : 1);
-                if (io.ahead == 0) episode = ep_t;
+                ep_t = refill ? item_ep : episode + 1;                   // listed bank episode, or the live reset
+                if (!refill) episode = ep_t;
                 uint32_t gid = (uint32_t)(C.env_offset + ei);
                 u4 A = philox(gid, (uint32_t)ep_t, 0u, 0u, C.key0, C.key1);
                 u4 B = philox(gid, (uint32_t)ep_t, 1u, 0u, C.key0, C.key1);
@@ -640,7 +647,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                         sdn = EB(GE_SD + e) + dt * a;
                         sn = EB(GE_S + e) + dt * sdn;
                     }
-                    if (valid && (pass == 0 || io.ahead == 0)) { ST(F_SD + e) = sdn; ST(F_S + e) = sn; }
+                    if (valid && (pass == 0 || !refill)) { ST(F_SD + e) = sdn; ST(F_S + e) = sn; }
                 }
 #pragma unroll
                 for (int k = 0; k < MAXC; ++k) R.con_shell[k] = (k < nc) ? tb_shell[cel[k]] : -1;
@@ -768,10 +775,10 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                     }
                     need = done && auto_reset;
                 }
-                if (pass == 1 && io.ahead > 0) {
+                if (pass == 1 && refill) {
                     // reset computed ahead of time: park it in the bank slot of episode ep_t
                     if (store && need) {
-                        const int sl = ep_t & 1;
+                        const int sl = ep_t & (BANK_DEPTH - 1);
 #pragma unroll
                         for (int i = 0; i < NJ; ++i) BK(sl, BQ0 + i) = q[i];
                         BK(sl, BTS) = ts.x; BK(sl, BTS + 1) = ts.y; BK(sl, BTS + 2) = ts.z; BK(sl, BTE) = te.x; BK(sl, BTE + 1) = te.y; BK(sl, BTE + 2) = te.z;
@@ -793,7 +800,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
         // ================= auto-reset: adopt the initial state prepared in the reset bank (SB3 VecEnv semantics: the
         // observation returned for a finished environment is its reset observation) and queue the slot for refill ==========
         episode += 1;
-        const int sl = episode & 1;
+        const int sl = episode & (BANK_DEPTH - 1);
 #pragma unroll
         for (int i = 0; i < NJ; ++i) { q[i] = BK(sl, BQ0 + i); q0[i] = q[i]; qd[i] = 0.f; }
         ts = mk(BK(sl, BTS), BK(sl, BTS + 1), BK(sl, BTS + 2)); te = mk(BK(sl, BTE), BK(sl, BTE + 1), BK(sl, BTE + 2));
@@ -804,11 +811,13 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
             for (int a = 0; a < OBS_DIM; ++a) io.obs[(size_t)ei * OBS_DIM + a] = BK(sl, BOBS + a);
         }
         if (TORSO && valid) for (int e = gl; e < N_TOP; e += G) { ST(F_S + e) = 0.f; ST(F_SD + e) = 0.f; }
-        if (store && io.list_out) { const int idx = atomicAdd(io.count, 1); io.list_out[idx] = env; }
+        // the slot just consumed is free again: order the episode that will occupy it (computed by the next bulk refill,
+        // which runs at least every BANK_DEPTH steps, i.e. before this environment can come round to the slot again)
+        if (store) { const int idx = atomicAdd(io.count, 1); io.items[idx] = make_int2(env, episode + BANK_DEPTH); }
     }
 
     // ---------------- store state ----------------
-    if (store && !(MODE == 1 && (io.ahead > 0 || !need))) {
+    if (store && !(MODE == 1 && (refill || !need))) {
 #pragma unroll
         for (int i = 0; i < NJ; ++i) { ST(F_Q + i) = q[i]; ST(F_QD + i) = qd[i]; ST(F_Q0 + i) = q0[i]; }
         ST(F_TS) = ts.x; ST(F_TS + 1) = ts.y; ST(F_TS + 2) = ts.z; ST(F_TE) = te.x; ST(F_TE + 1) = te.y; ST(F_TE + 2) = te.z;
@@ -819,8 +828,28 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
 #undef ST
 #undef STI
 #undef EB
+    if (refill) group_sync();                         // next item reuses the per-environment LDS block
+    }   // item loop
+    if (MODE == 1 && refill) {
+        // the last workgroup to finish empties the work list for the step kernels that follow on the stream
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(io.count + 1, 1) == (int)gridDim.x - 1) { io.count[0] = 0; io.count[1] = 0; }
+        }
+    }
 #undef BK
 #undef BKI
+}
+
+// work items (env, episode + k), k = 1..BANK_DEPTH, for the environments selected by mask (reset / set_state paths)
+__global__ void usim_bank_items_kernel(const float* __restrict__ st, int n, int npad, const uint8_t* __restrict__ mask, int2* items, int* count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * BANK_DEPTH) return;
+    const int env = i / BANK_DEPTH, k = i % BANK_DEPTH + 1;
+    if (mask && !mask[env]) return;
+    const int episode = reinterpret_cast<const int*>(st)[(size_t)F_EPISODE * npad + env];
+    items[atomicAdd(count, 1)] = make_int2(env, episode + k);
 }
 
 
