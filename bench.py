@@ -138,6 +138,16 @@ def main():
     achieved_gbs = ALGO_BYTES[args.workload] * n / avg_kernel_s / 1e9
     valu_tflops = ALGO_FLOPS[args.workload] * n / avg_kernel_s / 1e12
 
+    traffic = None
+    tfile = ROOT / "profiles" / "r01" / "traffic.json"
+    if tfile.exists() and n == 4096:
+        try:
+            tj = json.loads(tfile.read_text()).get(args.workload)
+            if tj:
+                traffic = (tj["fetch_kb"] + tj["write_kb"]) * 1024.0      # bytes per launch, committed PMC profile of this command
+        except Exception:
+            traffic = None
+
     if rank == 0:
         total_steps = args.steps * n * world
         out = {
@@ -149,10 +159,11 @@ def main():
                        "controller": "OSC_POSE impedance_mode=tracking", "rollout_block": T,
                        "parallelism": f"env-shard x{world}" + (" + RCCL all-gather of transition blocks" if gather is not None else "")},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_env_step": ALGO_BYTES[args.workload],
+                         "traffic": traffic, "traffic_source": "profiles/r01/traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch)" if traffic else None,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES[args.workload] * n, "algorithmic_bytes_per_env_step": ALGO_BYTES[args.workload],
                          "avg_kernel_us": avg_kernel_s * 1e6, "kernel": "usim_step_kernel",
                          "valu_fp32_tflops": valu_tflops, "valu_frac": valu_tflops / FP32_VALU_PEAK_TFLOPS,
-                         "note": "kernel is FP32-VALU/latency bound at 4096 envs (64 waves on 256 CUs), not HBM bound; see DESIGN.md section 5"},
+                         "note": "kernel is FP32-VALU/latency bound at 4096 envs (one wave per SIMD), not HBM bound; see DESIGN.md section 5"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, n)
