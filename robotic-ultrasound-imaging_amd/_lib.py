@@ -53,6 +53,7 @@ SYMBOLS = {
     "usim_time_steps": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(UsimStepIO), C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "usim_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "usim_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "usim_profile_step": (C.c_int, [C.c_void_p, C.POINTER(UsimStepIO), C.c_int64, C.POINTER(C.c_uint64), C.c_int]),
     "usim_strerror": (C.c_char_p, [C.c_int]),
     "usim_last_hip_error": (C.c_char_p, [C.c_void_p]),
     "usim_version": (C.c_char_p, []),

@@ -439,6 +439,25 @@ int usim_set_state(usim_handle* h, const float* scalars, const float* lattice) {
     return USIM_OK;
 }
 
+int usim_profile_step(usim_handle* h, const usim_step_io* s, int64_t step, uint64_t* ticks, int max_ticks) {
+    if (!h || !ticks || max_ticks < 17) return USIM_ERR_INVALID;
+    DevIO io; int rc = fill_io(s, io, false);
+    if (rc) return rc;
+    io.act = nullptr;
+    unsigned long long* d = nullptr;
+    HIPCHK(h, hipMalloc(&d, 32 * sizeof(unsigned long long)));
+    HIPCHK(h, hipMemset(d, 0, 32 * sizeof(unsigned long long)));
+    io.dbg = d; io.items = h->d_items; io.count = h->d_count;
+    rc = launch<0>(h, io, LF_AUTO_RESET | LF_RANDOM_ACT, (long long)step, nullptr);
+    if (rc == USIM_OK && ++h->steps_since_refill >= BANK_DEPTH) rc = bank_refill(h, nullptr);
+    HIPCHK(h, hipDeviceSynchronize());
+    unsigned long long host[32];
+    HIPCHK(h, hipMemcpy(host, d, sizeof host, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipFree(d));
+    for (int i = 0; i < 17; ++i) ticks[i] = host[i];
+    return rc;
+}
+
 const char* usim_strerror(int status) {
     switch (status) {
         case USIM_OK: return "ok";

@@ -61,6 +61,7 @@ struct DevIO {
     int2* items;                    // refill work list of (env, episode): appended by step kernels, consumed by refill launches
     int* count;                     // [0] number of items, [1] finished workgroups of the running refill launch
     int bank_row0;                  // first row of the reset bank inside the state block
+    unsigned long long* dbg;        // phase timeline probe (diagnostics; nullptr in production launches)
     int refill;                     // reset launches: 0 = reset the live state of the masked envs, 1 = compute the listed bank episodes
 };
 

@@ -94,6 +94,16 @@ DI void chol_packed(float* L, float* invd) {
     }
 }
 template <int N>
+DI void chol_forward(const float* L, const float* invd, float* b) {      // b <- L^-1 b
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s = fmaf(-L[PK(i, k)], b[k], s);
+        b[i] = s * invd[i];
+    }
+}
+template <int N>
 DI void chol_solve(const float* L, const float* invd, float* b) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {

@@ -127,6 +127,8 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
 #define ST(f) st[(size_t)(f) * npad + ei]
 #define STI(f) (reinterpret_cast<int*>(st))[(size_t)(f) * npad + ei]
 #define EB(off) lds[TB_WORDS + eb * GE_STRIDE + (off)]
+// phase timeline probe (diagnostics only): wave 0 of workgroup 0 stamps the shader clock when io.dbg is set
+#define TSTAMP(k) do { if (io.dbg && blockIdx.x == 0 && threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); io.dbg[k] = __builtin_readcyclecounter(); } } while (0)
 #define BK(slot, f) st[(size_t)(io.bank_row0 + (slot) * BANK_WORDS + (f)) * npad + ei]
 #define BKI(slot, f) (reinterpret_cast<int*>(st))[(size_t)(io.bank_row0 + (slot) * BANK_WORDS + (f)) * npad + ei]
     if (TORSO && item0 == (refill ? (int)blockIdx.x * EPB : 0)) {
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
         __syncthreads();
     }
 
+    TSTAMP(0);
     // ---------------- load state ----------------
     float q[NJ], qd[NJ], q0[NJ];
 #pragma unroll
@@ -151,7 +154,17 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
     float u0 = ST(F_U0), vbar = ST(F_VBAR), fzbar = ST(F_FZBAR), fzprev = ST(F_FZPREV), dfz = ST(F_DFZ);
     float kst = ST(F_KST), kdmp = ST(F_KDMP), mu = ST(F_MU), epret = ST(F_EPRET);
     int t = STI(F_T), touched = STI(F_TOUCH), episode = STI(F_EPISODE), status = STI(F_STATUS);
+    // lattice rows of this lane (elements gl, gl+G, ...): prefetched now, consumed after the arm phase
+    constexpr int NE = TORSO ? (N_TOP + G - 1) / G : 1;
+    float s_pre[NE], sd_pre[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = gl + i * G;
+        s_pre[i] = 0.f; sd_pre[i] = 0.f;
+        if (TORSO && MODE == 0 && e < N_TOP) { s_pre[i] = ST(F_S + e); sd_pre[i] = ST(F_SD + e); }
+    }
 
+    TSTAMP(1);
     // ---------------- action ----------------
     float act[7] = {0, 0, 0, 0, 0, 0, 0};
     if (!reset_only) {
@@ -289,24 +302,27 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
 #pragma unroll
             for (int k = 0; k < 28; ++k) Lm[k] = D.M[k];
             chol_packed<NJ>(Lm, idm);
-            // B = M^-1 J^T (column a = M^-1 J[a]), Li = J B  (6x6, packed lower) = Lambda^-1
-            float Bm[6][NJ];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) Bm[a][j] = J[a][j];
-                chol_solve<NJ>(Lm, idm, Bm[a]);
-            }
+            // Lambda^-1 = J M^-1 J^T = Y^T Y with Y = Lm^-1 J^T (six forward substitutions only; packed lower 6x6)
             float Li[21];
+            {
+                float Y[6][NJ];
 #pragma unroll
-            for (int a = 0; a < 6; ++a)
+                for (int a = 0; a < 6; ++a) {
 #pragma unroll
-                for (int b = 0; b <= a; ++b) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) s = fmaf(J[a][j], Bm[b][j], s);
-                    Li[PK(a, b)] = s;
+                    for (int j = 0; j < NJ; ++j) Y[a][j] = J[a][j];
+                    chol_forward<NJ>(Lm, idm, Y[a]);
                 }
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int b = 0; b <= a; ++b) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) s = fmaf(Y[a][j], Y[b][j], s);
+                        Li[PK(a, b)] = s;
+                    }
+            }
+            TSTAMP(2);
             // ---------------- OSC_POSE torque (robosuite osc.py run_controller; rl_config.yaml:33-51) ----------------
             float tau[NJ];
             if (pass == 0) {
@@ -380,7 +396,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                 for (int a = 0; a < 6; ++a) {
                     float s = 0.f;
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) s = fmaf(Bm[a][j], y[j], s);
+                    for (int j = 0; j < NJ; ++j) s = fmaf(J[a][j], pt[j], s);      // (M^-1 J^T)^T (M pt) = J pt
                     jb[a] = s;
                 }
                 {
@@ -400,6 +416,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
 #pragma unroll
                 for (int i = 0; i < NJ; ++i) tau[i] = 0.f;      // reset: sim.forward() with zero ctrl
             }
+            TSTAMP(3);
             // ---------------- smooth acceleration ----------------
             float qs[NJ];
 #pragma unroll
@@ -417,17 +434,23 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                     float tt = (float)tsim * dt, zf = -0.5f * GRAV * tt * tt;
                     if (zf > -TORSO_DROP) { dz = zf; vz = -GRAV * tt; az = -GRAV; }
                 }
+                TSTAMP(4);
                 // ---- stage s, sdot: lane gl of the group owns elements gl, gl+G, ... ----
-                for (int e = gl; e < N_TOP; e += G) {
-                    float se = 0.f, sde = 0.f;
-                    if (pass == 0) { se = ST(F_S + e); sde = ST(F_SD + e); }
-                    EB(GE_S + e) = se; EB(GE_SD + e) = sde;
+                // (the loads were issued together with the scalar state at the top of the kernel)
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    const int e = gl + i * G;
+                    if (e < N_TOP) { EB(GE_S + e) = (pass == 0) ? s_pre[i] : 0.f; EB(GE_SD + e) = (pass == 0) ? sd_pre[i] : 0.f; }
                 }
                 group_sync();
+                TSTAMP(5);
                 // ---- lattice right-hand side: a_s + w_fix aref_fix + w_ten sum_j aref_ij ----
                 const float kfix = 1.0f / (SI_DMAX * SR_TC * SR_TC), bfix = 2.0f / (SI_DMAX * SR_TC);
                 const float kten = kst / SI_DMAX, bten = kdmp / SI_DMAX;
-                for (int e = gl; e < N_TOP; e += G) {
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    const int e = gl + i * G;
+                    if (e >= N_TOP) continue;
                     float se = EB(GE_S + e), sde = EB(GE_SD + e);
                     float r = -(GRAV + az) * lds[TB_AXIS + 3 * e + 2] + M.wfix * (-bfix * sde - kfix * se);
 #pragma unroll
@@ -442,31 +465,48 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                 }
                 if (gl == 0) EB(GE_X + N_TOP) = 0.f;          // pad word read by the 16-byte row chunks
                 group_sync();
+                TSTAMP(6);
                 // ---- a~ = Linv * rhs: lane gl computes rows gl, gl+G, ...; Linv rows and rhs are read as 16-byte chunks ----
                 {
                     const float4* xv = reinterpret_cast<const float4*>(&EB(GE_X));
-                    for (int r0 = gl; r0 < N_TOP; r0 += 2 * G) {
-                        const int r1 = (r0 + G < N_TOP) ? r0 + G : r0;
-                        const float4* l0 = reinterpret_cast<const float4*>(&lds[TB_LINV + r0 * LROW]);
-                        const float4* l1 = reinterpret_cast<const float4*>(&lds[TB_LINV + r1 * LROW]);
-                        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+                    constexpr int RB = 4;                              // rows per pass share one read of the rhs chunk
+#pragma unroll
+                    for (int i0 = 0; i0 < NE; i0 += RB) {
+                        const float4* lr[RB];
+                        float acc[RB], bcc[RB];
+#pragma unroll
+                        for (int j = 0; j < RB; ++j) {
+                            int r = gl + (i0 + j) * G; if (r >= N_TOP) r = N_TOP - 1;
+                            lr[j] = reinterpret_cast<const float4*>(&lds[TB_LINV + r * LROW]);
+                            acc[j] = 0.f; bcc[j] = 0.f;
+                        }
 #pragma unroll 5
                         for (int c = 0; c < LROW / 4; ++c) {
-                            float4 x = xv[c], u = l0[c], v = l1[c];
-                            a0 = fmaf(u.x, x.x, a0); b0 = fmaf(u.y, x.y, b0); a0 = fmaf(u.z, x.z, a0); b0 = fmaf(u.w, x.w, b0);
-                            a1 = fmaf(v.x, x.x, a1); b1 = fmaf(v.y, x.y, b1); a1 = fmaf(v.z, x.z, a1); b1 = fmaf(v.w, x.w, b1);
+                            const float4 x = xv[c];
+#pragma unroll
+                            for (int j = 0; j < RB; ++j) {
+                                const float4 u = lr[j][c];
+                                acc[j] = fmaf(u.x, x.x, acc[j]); bcc[j] = fmaf(u.y, x.y, bcc[j]);
+                                acc[j] = fmaf(u.z, x.z, acc[j]); bcc[j] = fmaf(u.w, x.w, bcc[j]);
+                            }
                         }
-                        EB(GE_A + r0) = a0 + b0;
-                        if (r0 + G < N_TOP) EB(GE_A + r1) = a1 + b1;
+#pragma unroll
+                        for (int j = 0; j < RB; ++j) {
+                            const int r = gl + (i0 + j) * G;
+                            if (i0 + j < NE && r < N_TOP) EB(GE_A + r) = acc[j] + bcc[j];
+                        }
                     }
                 }
+                TSTAMP(7);
                 // ---- collision: probe capsule vs the 99 cap spheres; the G lanes test G consecutive elements at a time, the
                 //      wave ballot gives every hit its slot so that the contact list stays sorted by ascending shell id ----
                 f3 cc = K.x - K.sz * C.probe_r;                       // capsule centre one radius behind the tip
                 f3 p1 = cc - K.sy * C.probe_hl, d1 = K.sy * (2.f * C.probe_hl);
+                const float inv_dd = 1.0f / dot(d1, d1);
                 int nc = 0;
-                for (int e0 = 0; e0 < N_TOP; e0 += G) {
-                    const int e = e0 + gl;
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    const int e = i * G + gl;
                     bool hit = false;
                     f3 nn = mk(0, 0, 1), rr = mk(0, 0, 0); float dist = 0.f;
                     if (e < N_TOP) {
@@ -474,7 +514,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                         float se = EB(GE_S + e);
                         // element collision geometry = the cap sphere (centre `tip`, radius ELEM_R); DESIGN.md section 2
                         f3 tip = mk(M.torso[0] + lds[TB_POS + 3 * e], M.torso[1] + lds[TB_POS + 3 * e + 1], M.torso[2] + lds[TB_POS + 3 * e + 2] + dz) + ax * (se - ELEM_R);
-                        f3 c1 = seg_point(p1, d1, tip);
+                        f3 c1 = madd(p1, d1, clampf(dot(d1, tip - p1) * inv_dd, 0.f, 1.f));      // closest point of the probe segment
                         f3 dd = c1 - tip;
                         float len = sqrtf(dot(dd, dd));
                         dist = len - (C.probe_r + ELEM_R);
@@ -514,6 +554,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                         for (int j = 0; j < NJ; ++j) { s = fmaf(J[a][j], qs[j], s); u = fmaf(J[a][j], qd[j], u); }
                         alpha[a] = s; vs[a] = u;
                     }
+                    TSTAMP(8);
                     // ---- contact k lives in the registers of lane k of its group: row directions w, Lambda^-1 w, element
                     //      coupling g, reference acceleration, regulariser, force; Km[c] = Linv[e_own][e_c] / m ----
                     const bool own = gl < nc;
@@ -568,6 +609,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                             invD[d] = 1.0f / (Aii + Rd[d]);
                         }
                     }
+                    TSTAMP(9);
                     // ---- projected Gauss-Seidel on the dual over the contact rows (fixed sweeps, cold start).  Contacts are
                     //      visited in ascending order; the owner lane updates its three rows and the cone projection, then
                     //      the new site acceleration and the element impulse are broadcast to the group through DPP ----
@@ -579,9 +621,11 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                                 if (gl == k && own) {
 #pragma unroll
                                     for (int d = 0; d < 3; ++d) {
-                                        float res = g[d] * ae - aref[d] + Rd[d] * f[d];
-#pragma unroll
-                                        for (int a = 0; a < 6; ++a) res = fmaf(w[d][a], alpha[a], res);
+                                        // three independent partial sums keep the dependent chain short (one wave per SIMD)
+                                        float r0 = fmaf(Rd[d], f[d], fmaf(g[d], ae, -aref[d]));
+                                        float r1 = fmaf(w[d][2], alpha[2], fmaf(w[d][1], alpha[1], w[d][0] * alpha[0]));
+                                        float r2 = fmaf(w[d][5], alpha[5], fmaf(w[d][4], alpha[4], w[d][3] * alpha[3]));
+                                        float res = r0 + (r1 + r2);
                                         float fn = f[d] - res * invD[d];
                                         if (d == 0) fn = fmaxf(fn, 0.f);
                                         float df = fn - f[d];
@@ -593,9 +637,9 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                                         Gk += gd;
                                     }
                                     // elliptic cone: |f_t| <= mu f_n
-                                    float ft = sqrtf(f[1] * f[1] + f[2] * f[2]), lim = mu * f[0];
-                                    if (ft > lim) {
-                                        float sc = (ft > 0.f) ? lim / ft : 0.f;
+                                    float ft2 = f[1] * f[1] + f[2] * f[2], lim = mu * f[0];
+                                    if (ft2 > lim * lim) {
+                                        float sc = lim * rsqrtf(ft2);
 #pragma unroll
                                         for (int d = 1; d < 3; ++d) {
                                             float df = f[d] * sc - f[d];
@@ -615,6 +659,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                             }
                         }
                     }
+                    TSTAMP(10);
                     // ---- contact wrench on the site and impulse along each element axis: owners publish, everyone sums ----
                     if (own) {
                         f3 Fw = mk(w[0][0] * f[0] + w[1][0] * f[1] + w[2][0] * f[2], w[0][1] * f[0] + w[1][1] * f[1] + w[2][1] * f[2],
@@ -636,8 +681,12 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                         }
                     }
                 }
+                TSTAMP(11);
                 // ---- element accelerations a = a~ + Linv[:, e_c] gf_c, semi-implicit Euler, write back ----
-                for (int e = gl; e < N_TOP; e += G) {
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    const int e = gl + i * G;
+                    if (e >= N_TOP) continue;
                     float sdn = 0.f, sn = 0.f;
                     if (pass == 0) {
                         float a = EB(GE_A + e);
@@ -655,13 +704,22 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
 #pragma unroll
                 for (int k = 0; k < MAXC; ++k) R.con_shell[k] = -1;
             }
+            TSTAMP(12);
             // ---------------- constrained arm acceleration: qacc = qs + M^-1 J^T W ----------------
 #pragma unroll
-            for (int i = 0; i < NJ; ++i) {
-                float s = qs[i];
+            for (int i = 0; i < NJ; ++i) qacc[i] = qs[i];
+            if (TORSO) {
+                float z[NJ];
 #pragma unroll
-                for (int a = 0; a < 6; ++a) s = fmaf(Bm[a][i], W[a], s);
-                qacc[i] = s;
+                for (int i = 0; i < NJ; ++i) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) s = fmaf(J[a][i], W[a], s);
+                    z[i] = s;
+                }
+                chol_solve<NJ>(Lm, idm, z);
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) qacc[i] += z[i];
             }
             R.fc[0] = W[0]; R.fc[1] = W[1]; R.fc[2] = W[2];
             // ---------------- torque sensor at ft_frame (MuJoCo cfrc_int of the probe body, site frame) ----------------
@@ -679,6 +737,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                 f3 tw = N + cross(K.o[NJ - 1] + rc - K.x, Fp) - mk(W[3], W[4], W[5]);
                 R.tq[0] = dot(K.sx, tw); R.tq[1] = dot(K.sy, tw); R.tq[2] = dot(K.sz, tw);
             }
+            TSTAMP(13);
             // ---------------- integrate the arm: mj_Euler with implicit joint damping ----------------
             if (pass == 0) {
                 float rhs[NJ], Ld[28], idd[NJ];
@@ -707,6 +766,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                 }
                 hv = mk(vs2[0], vs2[1], vs2[2]) + cross(mk(vs2[3], vs2[4], vs2[5]), K.hand - K.x);
             }
+            TSTAMP(14);
             // ---------------- observation (ultrasound.py:363-401) ----------------
             {
                 const int tprev = (pass == 0) ? t - 1 : 0;
@@ -816,6 +876,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
         if (store) { const int idx = atomicAdd(io.count, 1); io.items[idx] = make_int2(env, episode + BANK_DEPTH); }
     }
 
+    TSTAMP(15);
     // ---------------- store state ----------------
     if (store && !(MODE == 1 && (refill || !need))) {
 #pragma unroll
@@ -838,8 +899,10 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
             if (atomicAdd(io.count + 1, 1) == (int)gridDim.x - 1) { io.count[0] = 0; io.count[1] = 0; }
         }
     }
+    TSTAMP(16);
 #undef BK
 #undef BKI
+#undef TSTAMP
 }
 
 // work items (env, episode + k), k = 1..BANK_DEPTH, for the environments selected by mask (reset / set_state paths)
