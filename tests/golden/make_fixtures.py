@@ -69,6 +69,12 @@ def main():
             "clip_obs": float(v["clip_obs"]), "clip_reward": float(v["clip_reward"]),
             "gamma": float(v["gamma"]), "epsilon": float(v["epsilon"]),
         })
+    # policy weights of the `tracking` checkpoint (policy.pth inside the zip is a plain tensor state dict): data for the
+    # policy-replay test; stored as float16-exact? no -- float32 as shipped
+    import io, torch
+    with zipfile.ZipFile(REF / "tracking.zip") as z:
+        sd = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=True)
+    np.savez_compressed(OUT / "tracking_policy.npz", **{k: v.numpy() for k, v in sd.items()})
     np.savez_compressed(OUT / "reference_pins.npz", **arrays)
     (OUT / "reference_pins.json").write_text(json.dumps(meta, indent=1, sort_keys=True))
     for k, a in arrays.items():

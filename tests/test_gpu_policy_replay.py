@@ -1,0 +1,66 @@
+"""Distribution-level tie to the real reference: the reference's own trained PPO policy
+(`trained_rl_models/tracking.zip`, weights committed as a data fixture) is replayed on the batched simulator with the
+reference's VecNormalize statistics, exactly as src/rl.py:171-192 evaluates it, and the reward rate / episode statistics /
+observation statistics are compared with what the checkpoints recorded on MuJoCo.  No step-exact trajectory exists, so the
+bands are wide; a wrong controller convention, sign, frame, reward term or contact scale would miss them by far (random
+actions give 5.6 reward per step instead of 8.1)."""
+import importlib
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_reference_trained_policy_transfers(usim, pins):
+    pol = importlib.import_module("robotic-ultrasound-imaging_amd.policy")
+    meta = json.loads((ROOT / "tests/golden/reference_pins.json").read_text())["tracking"]
+    sd = {k: torch.from_numpy(v) for k, v in np.load(ROOT / "tests/golden/tracking_policy.npz").items()}
+    stats = {"obs_mean": pins["tracking_obs_rms_mean"], "obs_var": pins["tracking_obs_rms_var"], "count": meta["obs_rms_count"],
+             "ret_mean": meta["ret_rms_mean"], "ret_var": meta["ret_rms_var"], "clip_obs": meta["clip_obs"], "clip_reward": meta["clip_reward"],
+             "gamma": meta["gamma"], "epsilon": meta["epsilon"]}
+    n, steps = 2048, 2500
+    env = usim.UltrasoundVecEnv(n, device="cuda:0", seed=3, **usim.default_robosuite_kwargs())
+    policy = pol.MlpActorCritic.from_sb3_state_dict(sd).to(env.device)
+    assert sum(p.numel() for p in policy.parameters()) == 19 * 256 * 2 + 256 * 2 + 256 * 128 * 2 + 128 * 2 + 128 * 6 + 6 + 128 + 1 + 6
+    vn = pol.DeviceVecNormalize.from_stats(stats, n, device=env.device, training=False, norm_reward=False)
+    out = pol.policy_rollout(env, policy, vn, steps, deterministic=False)      # stochastic, as during the reference's training
+    ref_rate = meta["ep_mean_return"] / meta["ep_mean_length"]                  # 8.12 reward per step on MuJoCo
+    assert abs(out["reward_per_step"] - ref_rate) < 0.6, (out["reward_per_step"], ref_rate)
+    assert 0.6 * meta["ep_mean_length"] < out["mean_episode_length"] < 1.4 * meta["ep_mean_length"]
+    assert 0.7 * meta["ep_mean_return"] < out["mean_episode_return"] < 1.4 * meta["ep_mean_return"]
+    m, s = out["obs_mean"], np.sqrt(out["obs_var"])
+    rm, rs = pins["tracking_obs_rms_mean"], np.sqrt(pins["tracking_obs_rms_var"])
+    assert 2.0 < m[2] < 15.0                          # the policy holds a contact force of the order of the 5 N goal (ref mean 10.6)
+    assert abs(m[3] - rm[3]) < 0.1                    # torque sensor about x: -0.21 in both
+    assert 0.5 * rs[10] < s[10] < 2.0 * rs[10]        # derivative of the contact force: std 1307 N/s on MuJoCo
+    assert np.all(np.abs(m[6:9]) < 0.01) and np.all(s[6:9] < 3 * rs[6:9]) and np.all(s[6:9] > rs[6:9] / 3)   # eef velocity
+    assert abs(m[14] - rm[14]) < 0.005                # probe sits ~1 cm above the trajectory depth (0.0102 on MuJoCo)
+    assert m[15] < -0.8 and 0.2 < s[15] < 0.6         # quaternion channel: -1 with occasional sign flips (ref mean -0.95, std 0.30)
+    # the same environments under uniformly random gains earn far less
+    env.reset_tensor()
+    acc = 0.0
+    for k in range(300):
+        _, rew, _ = env.step_tensor(env.random_actions_tensor(k))
+        acc += float(rew.mean())
+    assert acc / 300 < out["reward_per_step"] - 1.5
+    env.close()
+
+
+def test_device_vecnormalize_matches_running_statistics():
+    pol = importlib.import_module("robotic-ultrasound-imaging_amd.policy")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    vn = pol.DeviceVecNormalize(64, obs_dim=19, device="cuda:0")
+    chunks = [torch.randn(64, 19, device="cuda", generator=g) * 3 + 1 for _ in range(50)]
+    for c in chunks:
+        out = vn.normalize_obs(c)
+    allx = torch.cat(chunks).double()
+    assert torch.allclose(vn.obs_mean, allx.mean(0), atol=1e-3) and torch.allclose(vn.obs_var, allx.var(0, unbiased=False), rtol=1e-3)
+    assert out.abs().max() <= 10.0 and out.dtype == torch.float32
+    rew = torch.ones(64, device="cuda"); done = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    r = vn.normalize_reward(rew, done)
+    assert r.shape == (64,) and torch.isfinite(r).all()
