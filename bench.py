@@ -79,8 +79,10 @@ def main():
         raise SystemExit("bench.py needs an AMD GPU: the simulator has no CPU path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("USIM_BENCH_FORCE_GATHER") == "1"      # the env var exercises the RCCL path on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
@@ -92,7 +94,7 @@ def main():
     env = usim.UltrasoundVecEnv(n, device=device, seed=3, env_offset=rank * n, torso=args.workload, **usim.default_robosuite_kwargs())
     T = max(1, min(args.block, args.steps))
     blocks = [env.alloc_block(T), env.alloc_block(T)]      # double-buffered: gather block b while simulating b^1
-    gather = dmod.RolloutGather(device=device) if (world > 1 and not args.no_gather) else None
+    gather = dmod.RolloutGather(device=device) if (use_dist and not args.no_gather) else None
 
     env.reset_tensor()
     step = 0
@@ -105,7 +107,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -116,22 +118,26 @@ def main():
         k = min(T, args.steps - done_s)
         dev_ms += env.time_steps(step, k, blocks[b]) if gather is None else 0.0
         if gather is not None:
-            gather.wait()                                  # previous block's gather (overlapped with this block's launch queue)
-            env.rollout_random(step, k, blocks[b])
+            env.rollout_random(step, k, blocks[b])         # simulate block b while the gather of block b^1 is in flight
+            gather.wait()                                  # block b^1 is gathered before the next iteration overwrites it
             gather.gather_async(blocks[b])
         step += k; done_s += k; b ^= 1
     if gather is not None:
         gather.wait()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # kernel-duration leg of the roofline: HIP events around the same launches on the launch stream (rank 0, N == 1 path)
     if gather is not None:
-        dev_ms = env.time_steps(step, min(256, args.steps), blocks[0]); kern_steps = min(256, args.steps)
+        kern_steps = min(2 * T, args.steps)
+        dev_ms, done_k = 0.0, 0
+        while done_k < kern_steps:                          # never more than T slices into a T-slice block
+            k = min(T, kern_steps - done_k)
+            dev_ms += env.time_steps(step + done_k, k, blocks[0]); done_k += k
     else:
         kern_steps = args.steps
     avg_kernel_s = dev_ms * 1e-3 / kern_steps
@@ -167,10 +173,21 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, n)
-        print(json.dumps(out))
+        result = json.dumps(out)
+    else:
+        result = None
     env.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    if result is not None:
+        # RCCL writes its version banner through C stdio; flush that first so that the JSON record is the last line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(result, flush=True)
 
 
 if __name__ == "__main__":

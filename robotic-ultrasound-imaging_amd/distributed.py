@@ -54,7 +54,7 @@ class RolloutGather:
 
     def gather(self, block):
         packed = pack_block(block)
-        if self.world == 1:
+        if self.world == 1 and not dist.is_initialized():
             return packed.unsqueeze(0)
         # concatenated-along-dim-0 output layout is accepted by both RCCL and gloo; viewed as [world, T, n, C]
         out = torch.empty((self.world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)

@@ -40,8 +40,8 @@ def _razor_edge(inf, i):
             abs(inf["ori_err"][i] - 0.10) < MARGIN["ori"] or abs(inf["joint_margin"][i]) < MARGIN["joint"])
 
 
-def _run_parity(usim, n, steps, torso, mode):
-    env, ora = _mk(usim, n, torso, mode)
+def _run_parity(usim, n, steps, torso, mode, **extra):
+    env, ora = _mk(usim, n, torso, mode, **extra)
     og, oo = env.reset(), ora.reset()
     assert np.allclose(og[:, 12:19], oo[:, 12:19], atol=2e-6)          # pose channels at reset
     assert np.allclose(og[:, :6], oo[:, :6], atol=5e-3, rtol=1e-3)      # contact force / torque sensor
@@ -108,6 +108,20 @@ def test_rigid_torso_parity_200_steps(usim, mode):
 def test_soft_torso_parity_200_steps(usim, mode):
     """BASELINE configs[2]: soft-torso contact + force/velocity-tracking reward"""
     _run_parity(usim, 256, 200, "soft", mode)
+
+
+def test_eight_lanes_per_env_mapping(usim):
+    """the G = 8 instantiation of the grouped kernel (two-instruction DPP broadcast) gives the same results"""
+    env, ora = _mk(usim, 96, "soft", "tracking")
+    env8 = usim.UltrasoundVecEnv(96, device="cuda:0", seed=3, torso="soft", lanes_per_env=8, **usim.default_robosuite_kwargs())
+    o16, o8 = env.reset(), env8.reset()
+    assert np.array_equal(o16, o8)
+    for k in range(60):
+        a = ora.random_actions(k).astype(np.float32)
+        r16, r8 = env.step(a), env8.step(a)
+        assert np.array_equal(r16[2], r8[2]) and np.allclose(r16[0], r8[0], rtol=1e-4, atol=1e-4) and np.allclose(r16[1], r8[1], atol=1e-3)
+        assert np.array_equal(env.contacts.cpu().numpy(), env8.contacts.cpu().numpy())
+    env.close(); env8.close()
 
 
 def test_single_env_and_ragged_batch(usim):
