@@ -85,6 +85,127 @@ DI float group_bcast(float v, int k) {
 }
 #undef USIM_BCAST_CASE
 
+// prescribed torso base motion: free fall over the 4.7 mm spawn gap, then rest (ultrasound.py:313)
+DI void torso_motion(const DevCfg& C, int tsim, float& dz, float& vz, float& az) {
+    dz = -TORSO_DROP; vz = 0.f; az = 0.f;
+    if (C.torso_drop) {
+        float tt = (float)tsim * C.dt, zf = -0.5f * GRAV * tt * tt;
+        if (zf > -TORSO_DROP) { dz = zf; vz = -GRAV * tt; az = -GRAV; }
+    }
+}
+
+// Lattice front end of one forward pass, executed by the G lanes of a group on the group's LDS block: stage (s, sdot), build
+// the right-hand side of the soft-equality system, a~ = Linv rhs, collide the probe capsule with the 99 cap spheres and
+// leave the contact records (ascending shell id) in LDS.  Returns the number of contacts found (may exceed MAXC).
+template <int G, int NE>
+DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, const DevModel& M, const DevCfg& C, const int tsim,
+                     const float kst, const float kdmp, const bool live, const float* s_pre, const float* sd_pre,
+                     const f3 Kx, const f3 Ksy, const f3 Ksz) {
+#define EBF(off) lds[TB_WORDS + eb * GE_STRIDE + (off)]
+    const int* tb_nbr = reinterpret_cast<const int*>(lds + TB_NBR);
+    float dz, vz, az;
+    torso_motion(C, tsim, dz, vz, az);
+                                    // ---- stage s, sdot: lane gl of the group owns elements gl, gl+G, ... ----
+                    // (the loads were issued together with the scalar state at the top of the kernel)
+    #pragma unroll
+                    for (int i = 0; i < NE; ++i) {
+                        const int e = gl + i * G;
+                        if (e < N_TOP) { EBF(GE_S + e) = live ? s_pre[i] : 0.f; EBF(GE_SD + e) = live ? sd_pre[i] : 0.f; }
+                    }
+                    group_sync();
+                                    // ---- lattice right-hand side: a_s + w_fix aref_fix + w_ten sum_j aref_ij ----
+                    const float kfix = 1.0f / (SI_DMAX * SR_TC * SR_TC), bfix = 2.0f / (SI_DMAX * SR_TC);
+                    const float kten = kst / SI_DMAX, bten = kdmp / SI_DMAX;
+    #pragma unroll
+                    for (int i = 0; i < NE; ++i) {
+                        const int e = gl + i * G;
+                        if (e >= N_TOP) continue;
+                        float se = EBF(GE_S + e), sde = EBF(GE_SD + e);
+                        float r = -(GRAV + az) * lds[TB_AXIS + 3 * e + 2] + M.wfix * (-bfix * sde - kfix * se);
+    #pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            int j = tb_nbr[4 * e + d];
+                            if (j >= -1) {
+                                float sj = (j >= 0) ? EBF(GE_S + j) : 0.f, sdj = (j >= 0) ? EBF(GE_SD + j) : 0.f;
+                                r += M.wten * (-bten * (sde - sdj) - kten * (se - sj));
+                            }
+                        }
+                        EBF(GE_X + e) = r;
+                    }
+                    if (gl == 0) EBF(GE_X + N_TOP) = 0.f;          // pad word read by the 16-byte row chunks
+                    group_sync();
+                                    // ---- a~ = Linv * rhs: lane gl computes rows gl, gl+G, ...; Linv rows and rhs are read as 16-byte chunks ----
+                    {
+                        const float4* xv = reinterpret_cast<const float4*>(&EBF(GE_X));
+                        constexpr int RB = 4;                              // rows per pass share one read of the rhs chunk
+    #pragma unroll
+                        for (int i0 = 0; i0 < NE; i0 += RB) {
+                            const float4* lr[RB];
+                            float acc[RB], bcc[RB];
+    #pragma unroll
+                            for (int j = 0; j < RB; ++j) {
+                                int r = gl + (i0 + j) * G; if (r >= N_TOP) r = N_TOP - 1;
+                                lr[j] = reinterpret_cast<const float4*>(&lds[TB_LINV + r * LROW]);
+                                acc[j] = 0.f; bcc[j] = 0.f;
+                            }
+    #pragma unroll 5
+                            for (int c = 0; c < LROW / 4; ++c) {
+                                const float4 x = xv[c];
+    #pragma unroll
+                                for (int j = 0; j < RB; ++j) {
+                                    const float4 u = lr[j][c];
+                                    acc[j] = fmaf(u.x, x.x, acc[j]); bcc[j] = fmaf(u.y, x.y, bcc[j]);
+                                    acc[j] = fmaf(u.z, x.z, acc[j]); bcc[j] = fmaf(u.w, x.w, bcc[j]);
+                                }
+                            }
+    #pragma unroll
+                            for (int j = 0; j < RB; ++j) {
+                                const int r = gl + (i0 + j) * G;
+                                if (i0 + j < NE && r < N_TOP) EBF(GE_A + r) = acc[j] + bcc[j];
+                            }
+                        }
+                    }
+                                    // ---- collision: probe capsule vs the 99 cap spheres; the G lanes test G consecutive elements at a time, the
+                    //      wave ballot gives every hit its slot so that the contact list stays sorted by ascending shell id ----
+                    f3 cc = Kx - Ksz * C.probe_r;                       // capsule centre one radius behind the tip
+                    f3 p1 = cc - Ksy * C.probe_hl, d1 = Ksy * (2.f * C.probe_hl);
+                    const float inv_dd = 1.0f / dot(d1, d1);
+                    int nc = 0;
+    #pragma unroll
+                    for (int i = 0; i < NE; ++i) {
+                        const int e = i * G + gl;
+                        bool hit = false;
+                        f3 nn = mk(0, 0, 1), rr = mk(0, 0, 0); float dist = 0.f;
+                        if (e < N_TOP) {
+                            f3 ax = mk(lds[TB_AXIS + 3 * e], lds[TB_AXIS + 3 * e + 1], lds[TB_AXIS + 3 * e + 2]);
+                            float se = EBF(GE_S + e);
+                            // element collision geometry = the cap sphere (centre `tip`, radius ELEM_R); DESIGN.md section 2
+                            f3 tip = mk(M.torso[0] + lds[TB_POS + 3 * e], M.torso[1] + lds[TB_POS + 3 * e + 1], M.torso[2] + lds[TB_POS + 3 * e + 2] + dz) + ax * (se - ELEM_R);
+                            f3 c1 = madd(p1, d1, clampf(dot(d1, tip - p1) * inv_dd, 0.f, 1.f));      // closest point of the probe segment
+                            f3 dd = c1 - tip;
+                            float len = sqrtf(dot(dd, dd));
+                            dist = len - (C.probe_r + ELEM_R);
+                            hit = dist < 0.f;
+                            if (hit) {
+                                nn = (len > 1e-9f) ? dd * (1.f / len) : mk(0, 0, 1);
+                                rr = tip + nn * (ELEM_R + 0.5f * dist) - Kx;
+                            }
+                        }
+                        const unsigned long long bal = __ballot(hit);
+                        const unsigned gm = (unsigned)(bal >> gbase) & ((1u << G) - 1u);
+                        const int slot = nc + __popc(gm & ((1u << gl) - 1u));
+                        if (hit && slot < MAXC) {
+                            const int b = GE_CG + slot * CG_WORDS;
+                            EBF(b + 0) = nn.x; EBF(b + 1) = nn.y; EBF(b + 2) = nn.z;
+                            EBF(b + 3) = rr.x; EBF(b + 4) = rr.y; EBF(b + 5) = rr.z;
+                            EBF(b + 6) = __int_as_float(e); EBF(b + 7) = dist;
+                        }
+                        nc += __popc(gm);
+                    }
+    return nc;
+#undef EBF
+}
+
 struct StepOut {               // results of one forward pass that the env logic needs
     float fc[3];               // net contact force on the probe (cfrc_ext[probe][3:6])
     float tq[3];               // torque sensor at ft_frame (site frame)
@@ -103,6 +224,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
     // step waves outrank the background refill waves that may share their SIMD (priority, then age, arbitrates VALU issue)
     __builtin_amdgcn_s_setprio(MODE == 0 ? 3 : 0);
     constexpr int EPW = GroupGeom<G>::EPW, EPB = GroupGeom<G>::EPB, NT = GroupGeom<G>::NT;
+    constexpr int NTT = NT;
     static_assert(!TORSO || G >= MAXC, "the contact solver gives every contact its own lane of the group");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gl = lane % G, ge = lane / G;           // lane within the group, group (= environment) within the wave
@@ -136,12 +258,12 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
         // 16-byte loads, all issued before the first LDS store
         const float4* src = reinterpret_cast<const float4*>(c_tables);
         float4* dst = reinterpret_cast<float4*>(lds);
-        constexpr int NV = TB_WORDS / 4, PER = (NV + NT - 1) / NT;
+        constexpr int NV = TB_WORDS / 4, PER = (NV + NTT - 1) / NTT;
         float4 tmp[PER];
 #pragma unroll
-        for (int i = 0; i < PER; ++i) { int idx = threadIdx.x + i * NT; tmp[i] = (idx < NV) ? src[idx] : make_float4(0, 0, 0, 0); }
+        for (int i = 0; i < PER; ++i) { int idx = threadIdx.x + i * NTT; tmp[i] = (idx < NV) ? src[idx] : make_float4(0, 0, 0, 0); }
 #pragma unroll
-        for (int i = 0; i < PER; ++i) { int idx = threadIdx.x + i * NT; if (idx < NV) dst[idx] = tmp[i]; }
+        for (int i = 0; i < PER; ++i) { int idx = threadIdx.x + i * NTT; if (idx < NV) dst[idx] = tmp[i]; }
         __syncthreads();
     }
 
@@ -425,116 +547,13 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
 
             float W[6] = {0, 0, 0, 0, 0, 0};          // site-space wrench of the contact forces
             if (TORSO) {
-                const int* tb_nbr = reinterpret_cast<const int*>(lds + TB_NBR);
                 const int* tb_shell = reinterpret_cast<const int*>(lds + TB_SHELL);
-                // prescribed torso base motion: free fall over the 4.7 mm spawn gap, then rest
                 const int tsim = (t > 0) ? t - 1 : 0;
-                float dz = -TORSO_DROP, vz = 0.f, az = 0.f;
-                if (C.torso_drop) {
-                    float tt = (float)tsim * dt, zf = -0.5f * GRAV * tt * tt;
-                    if (zf > -TORSO_DROP) { dz = zf; vz = -GRAV * tt; az = -GRAV; }
-                }
+                float dz, vz, az;
+                torso_motion(C, tsim, dz, vz, az);
                 TSTAMP(4);
-                // ---- stage s, sdot: lane gl of the group owns elements gl, gl+G, ... ----
-                // (the loads were issued together with the scalar state at the top of the kernel)
-#pragma unroll
-                for (int i = 0; i < NE; ++i) {
-                    const int e = gl + i * G;
-                    if (e < N_TOP) { EB(GE_S + e) = (pass == 0) ? s_pre[i] : 0.f; EB(GE_SD + e) = (pass == 0) ? sd_pre[i] : 0.f; }
-                }
-                group_sync();
-                TSTAMP(5);
-                // ---- lattice right-hand side: a_s + w_fix aref_fix + w_ten sum_j aref_ij ----
-                const float kfix = 1.0f / (SI_DMAX * SR_TC * SR_TC), bfix = 2.0f / (SI_DMAX * SR_TC);
-                const float kten = kst / SI_DMAX, bten = kdmp / SI_DMAX;
-#pragma unroll
-                for (int i = 0; i < NE; ++i) {
-                    const int e = gl + i * G;
-                    if (e >= N_TOP) continue;
-                    float se = EB(GE_S + e), sde = EB(GE_SD + e);
-                    float r = -(GRAV + az) * lds[TB_AXIS + 3 * e + 2] + M.wfix * (-bfix * sde - kfix * se);
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        int j = tb_nbr[4 * e + d];
-                        if (j >= -1) {
-                            float sj = (j >= 0) ? EB(GE_S + j) : 0.f, sdj = (j >= 0) ? EB(GE_SD + j) : 0.f;
-                            r += M.wten * (-bten * (sde - sdj) - kten * (se - sj));
-                        }
-                    }
-                    EB(GE_X + e) = r;
-                }
-                if (gl == 0) EB(GE_X + N_TOP) = 0.f;          // pad word read by the 16-byte row chunks
-                group_sync();
-                TSTAMP(6);
-                // ---- a~ = Linv * rhs: lane gl computes rows gl, gl+G, ...; Linv rows and rhs are read as 16-byte chunks ----
-                {
-                    const float4* xv = reinterpret_cast<const float4*>(&EB(GE_X));
-                    constexpr int RB = 4;                              // rows per pass share one read of the rhs chunk
-#pragma unroll
-                    for (int i0 = 0; i0 < NE; i0 += RB) {
-                        const float4* lr[RB];
-                        float acc[RB], bcc[RB];
-#pragma unroll
-                        for (int j = 0; j < RB; ++j) {
-                            int r = gl + (i0 + j) * G; if (r >= N_TOP) r = N_TOP - 1;
-                            lr[j] = reinterpret_cast<const float4*>(&lds[TB_LINV + r * LROW]);
-                            acc[j] = 0.f; bcc[j] = 0.f;
-                        }
-#pragma unroll 5
-                        for (int c = 0; c < LROW / 4; ++c) {
-                            const float4 x = xv[c];
-#pragma unroll
-                            for (int j = 0; j < RB; ++j) {
-                                const float4 u = lr[j][c];
-                                acc[j] = fmaf(u.x, x.x, acc[j]); bcc[j] = fmaf(u.y, x.y, bcc[j]);
-                                acc[j] = fmaf(u.z, x.z, acc[j]); bcc[j] = fmaf(u.w, x.w, bcc[j]);
-                            }
-                        }
-#pragma unroll
-                        for (int j = 0; j < RB; ++j) {
-                            const int r = gl + (i0 + j) * G;
-                            if (i0 + j < NE && r < N_TOP) EB(GE_A + r) = acc[j] + bcc[j];
-                        }
-                    }
-                }
+                int nc = lattice_front<G, NE>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, pass == 0, s_pre, sd_pre, K.x, K.sy, K.sz);
                 TSTAMP(7);
-                // ---- collision: probe capsule vs the 99 cap spheres; the G lanes test G consecutive elements at a time, the
-                //      wave ballot gives every hit its slot so that the contact list stays sorted by ascending shell id ----
-                f3 cc = K.x - K.sz * C.probe_r;                       // capsule centre one radius behind the tip
-                f3 p1 = cc - K.sy * C.probe_hl, d1 = K.sy * (2.f * C.probe_hl);
-                const float inv_dd = 1.0f / dot(d1, d1);
-                int nc = 0;
-#pragma unroll
-                for (int i = 0; i < NE; ++i) {
-                    const int e = i * G + gl;
-                    bool hit = false;
-                    f3 nn = mk(0, 0, 1), rr = mk(0, 0, 0); float dist = 0.f;
-                    if (e < N_TOP) {
-                        f3 ax = mk(lds[TB_AXIS + 3 * e], lds[TB_AXIS + 3 * e + 1], lds[TB_AXIS + 3 * e + 2]);
-                        float se = EB(GE_S + e);
-                        // element collision geometry = the cap sphere (centre `tip`, radius ELEM_R); DESIGN.md section 2
-                        f3 tip = mk(M.torso[0] + lds[TB_POS + 3 * e], M.torso[1] + lds[TB_POS + 3 * e + 1], M.torso[2] + lds[TB_POS + 3 * e + 2] + dz) + ax * (se - ELEM_R);
-                        f3 c1 = madd(p1, d1, clampf(dot(d1, tip - p1) * inv_dd, 0.f, 1.f));      // closest point of the probe segment
-                        f3 dd = c1 - tip;
-                        float len = sqrtf(dot(dd, dd));
-                        dist = len - (C.probe_r + ELEM_R);
-                        hit = dist < 0.f;
-                        if (hit) {
-                            nn = (len > 1e-9f) ? dd * (1.f / len) : mk(0, 0, 1);
-                            rr = tip + nn * (ELEM_R + 0.5f * dist) - K.x;
-                        }
-                    }
-                    const unsigned long long bal = __ballot(hit);
-                    const unsigned gm = (unsigned)(bal >> gbase) & ((1u << G) - 1u);
-                    const int slot = nc + __popc(gm & ((1u << gl) - 1u));
-                    if (hit && slot < MAXC) {
-                        const int b = GE_CG + slot * CG_WORDS;
-                        EB(b + 0) = nn.x; EB(b + 1) = nn.y; EB(b + 2) = nn.z;
-                        EB(b + 3) = rr.x; EB(b + 4) = rr.y; EB(b + 5) = rr.z;
-                        EB(b + 6) = __int_as_float(e); EB(b + 7) = dist;
-                    }
-                    nc += __popc(gm);
-                }
                 if (nc > MAXC) { R.overflow = 1; nc = MAXC; }
                 R.ncon = nc;
                 group_sync();
