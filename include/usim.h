@@ -43,8 +43,8 @@ typedef enum usim_status {
 } usim_status;
 
 /* impedance_mode of the OSC_POSE controller: rl_config.yaml:41 ("tracking"), main.py:33 ("fixed"),
- * utils/plot.py:208-211,303-313 ("variable_z") */
-enum { USIM_MODE_TRACKING = 0, USIM_MODE_FIXED = 1, USIM_MODE_VARIABLE_Z = 2 };
+ * utils/plot.py:208-211,303-313 ("variable_z"), utils/plot.py:267-268 ("wrench": the action, +-10, replaces desired_force/desired_torque of the OSC law) */
+enum { USIM_MODE_TRACKING = 0, USIM_MODE_FIXED = 1, USIM_MODE_VARIABLE_Z = 2, USIM_MODE_WRENCH = 3 };
 /* torso model: BASELINE.json configs[1] (rigid, contact solver off) / configs[2] (soft torso) */
 enum { USIM_TORSO_NONE = 0, USIM_TORSO_TOP = 1 };
 

@@ -515,7 +515,7 @@ static int inv_spd(real* a, int n) {   /* in-place inverse of an SPD matrix (np.
 }
 
 static void osc_torque(const Sim* S, const KinDyn* k, const real* q, const real* qd, const real* q0,
-                       const real* goal_pos, const real* goal_rot, const real* kp, const real* kd, real* tau) {
+                       const real* goal_pos, const real* goal_rot, const real* kp, const real* kd, const real* direct_wrench, real* tau) {
     /* site velocity */
     real v[6];
     for (int a = 0; a < 6; a++) { real s = 0; for (int i = 0; i < NJ; i++) s += k->J[a][i] * qd[i]; v[a] = s; }
@@ -536,6 +536,8 @@ static void osc_torque(const Sim* S, const KinDyn* k, const real* q, const real*
     inv_spd(lam_full, 6); inv_spd(lam_pos, 3); inv_spd(lam_ori, 3);
     real wr[6];
     (void)S;
+    /* fork-only "wrench" baseline (plot.py:267-268): the action replaces desired_force / desired_torque [INFERRED, DESIGN.md] */
+    if (direct_wrench) for (int a = 0; a < 3; a++) { F[a] = direct_wrench[a]; T[a] = direct_wrench[3 + a]; }
     m3mulv(wr, lam_pos, F); m3mulv(wr + 3, lam_ori, T);       /* uncouple_pos_ori: True (rl_config.yaml:48) */
     for (int i = 0; i < NJ; i++) { real s = k->bias[i]; for (int a = 0; a < 6; a++) s += k->J[a][i] * wr[a]; tau[i] = s; }
     /* nullspace: tau += N^T M (10 (q0-q) - 2 sqrt(10) qd),  N = I - Jbar J, Jbar = M^-1 J^T lam_full */
@@ -858,6 +860,7 @@ static void forward_pass(const Sim* S, const Env* E, const real* act, int zero_t
             /* fork-only "tracking"/"variable_z" (SURVEY C.3): action -> kp in kp_limits, kd = 2 sqrt(kp), goal = trajectory */
             for (int a = 0; a < 6; a++) {
                 real v = act[a]; if (v > 1) v = 1; if (v < 0) v = 0;
+                if (c->mode == USO_MODE_WRENCH) v = 0;
                 kp[a] = (real)c->kp_min + v * (real)(c->kp_max - c->kp_min);
                 kd[a] = 2 * (real)sqrt((double)kp[a]) * (real)c->damping_ratio;
             }
@@ -865,7 +868,11 @@ static void forward_pass(const Sim* S, const Env* E, const real* act, int zero_t
             if (c->mode == USO_MODE_VARIABLE_Z) { real v = act[6]; if (v > 1) v = 1; if (v < -1) v = -1; gpos[2] += v * (real)c->out_max_pos; }
             memcpy(grot, S->m.goal_rot, sizeof grot);
         }
-        osc_torque(S, &P->k, E->q, E->qd, E->q0, gpos, grot, kp, kd, P->tau);
+        real dw[6];
+        if (c->mode == USO_MODE_WRENCH) {   /* action = desired eef wrench, checkpoint action box [-10,10]^6 */
+            for (int a = 0; a < 6; a++) { real v = act[a]; if (v > 10) v = 10; if (v < -10) v = -10; dw[a] = v; kp[a] = 0; kd[a] = 0; }
+        }
+        osc_torque(S, &P->k, E->q, E->qd, E->q0, gpos, grot, kp, kd, c->mode == USO_MODE_WRENCH ? dw : 0, P->tau);
     }
     constrained_forward(S, E, &P->k, P->tau, &P->f);
     torque_sensor(S, E, &P->k, P->f.qacc, P->f.tq_sensor, P->tq);
@@ -1109,8 +1116,9 @@ int uso_random_actions(void* h, int64_t step, double* act) {
         philox4x32((uint32_t)(c->env_offset + i), (uint32_t)step, (uint32_t)((uint64_t)step >> 32), 2, k0, k1, r + 4);
         for (int a = 0; a < S->adim; a++) {
             double u = u01(r[a]);
-            int signedbox = (c->mode == USO_MODE_FIXED) || (c->mode == USO_MODE_VARIABLE_Z && a == 6);
-            act[(size_t)i * S->adim + a] = signedbox ? 2.0 * u - 1.0 : u;
+            int signedbox = (c->mode == USO_MODE_FIXED) || (c->mode == USO_MODE_WRENCH) || (c->mode == USO_MODE_VARIABLE_Z && a == 6);
+            double v = signedbox ? 2.0 * u - 1.0 : u;
+            act[(size_t)i * S->adim + a] = (c->mode == USO_MODE_WRENCH) ? 10.0 * v : v;
         }
     }
     return 0;

@@ -30,7 +30,7 @@ extern "C" {
 #define USO_NSCALAR 40      /* scalar state words per env exported by uso_get_state */
 
 /* impedance_mode of the OSC controller (rl_config.yaml:41, main.py:33, utils/plot.py:203-211,303-313) */
-enum { USO_MODE_TRACKING = 0, USO_MODE_FIXED = 1, USO_MODE_VARIABLE_Z = 2 };
+enum { USO_MODE_TRACKING = 0, USO_MODE_FIXED = 1, USO_MODE_VARIABLE_Z = 2, USO_MODE_WRENCH = 3 };
 /* torso model: 0 = rigid/absent (BASELINE config #2), 1 = 99 top-face elements dynamic (config #3) */
 enum { USO_TORSO_NONE = 0, USO_TORSO_TOP = 1 };
 

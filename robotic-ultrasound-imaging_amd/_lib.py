@@ -15,7 +15,7 @@ MAXC = 8
 NSCALAR = 40
 RESET_PARAMS = 13
 
-MODE = {"tracking": 0, "fixed": 1, "variable_z": 2}
+MODE = {"tracking": 0, "fixed": 1, "variable_z": 2, "wrench": 3}
 TORSO = {"none": 0, "rigid": 0, "top": 1, "soft": 1}
 
 

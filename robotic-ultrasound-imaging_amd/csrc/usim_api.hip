@@ -210,7 +210,7 @@ int usim_default_config(usim_config* c) {
 
 int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** out) {
     if (!cfg || !out || n_envs <= 0) return USIM_ERR_INVALID;
-    if (cfg->mode < 0 || cfg->mode > 2 || cfg->torso < 0 || cfg->torso > 1 || cfg->horizon <= 0 || cfg->control_dt <= 0 ||
+    if (cfg->mode < 0 || cfg->mode > 3 || cfg->torso < 0 || cfg->torso > 1 || cfg->horizon <= 0 || cfg->control_dt <= 0 ||
         cfg->probe_halflen < 1e-4 || cfg->probe_radius <= 0 || cfg->pgs_iters < 0 || cfg->ik_iters < 0) return USIM_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return USIM_ERR_NO_DEVICE;

@@ -50,6 +50,7 @@ constexpr float TORSO_DROP = 0.0047f;
 // MuJoCo default soft-constraint parameters (solref 0.02 1, solimp 0.9 0.95 0.001 0.5 2) and robosuite's impratio
 constexpr float SR_TC = 0.02f, SI_D0 = 0.9f, SI_DMAX = 0.95f, SI_WIDTH = 0.001f, IMPRATIO = 20.f;
 constexpr float PI_F = 3.14159265358979323846f;
+constexpr float WRENCH_MAX = 10.f;           // action box of the `wrench` checkpoint
 
 // ------------------------------------------------------------------------------------------------------------
 // Philox4x32-10 counter-based RNG (Salmon et al. 2011)

@@ -298,8 +298,9 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
 #pragma unroll
             for (int a = 0; a < 7; ++a) {
                 float u = u01(rr[a]);
-                bool sgn = (C.mode == 1) || (C.mode == 2 && a == 6);
+                bool sgn = (C.mode == 1) || (C.mode == 3) || (C.mode == 2 && a == 6);
                 act[a] = sgn ? 2.f * u - 1.f : u;
+                if (C.mode == 3) act[a] *= WRENCH_MAX;
                 if (io.act_out && store && a < C.adim) io.act_out[(size_t)ei * C.adim + a] = act[a];
             }
         } else {
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                 } else {
 #pragma unroll
                     for (int a = 0; a < 6; ++a) {
-                        float v = clampf(act[a], 0.f, 1.f);
+                        float v = (C.mode == 3) ? 0.f : clampf(act[a], 0.f, 1.f);     // wrench mode: no impedance term
                         kp[a] = C.kp_min + v * (C.kp_max - C.kp_min);
                         kd[a] = 2.f * sqrtf(kp[a]) * C.damping_ratio;
                     }
@@ -494,6 +495,14 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                 f3 ep = gpos - K.x;
                 float Fp[3] = {ep.x * kp[0] - v6[0] * kd[0], ep.y * kp[1] - v6[1] * kd[1], ep.z * kp[2] - v6[2] * kd[2]};
                 float Tp[3] = {eo.x * kp[3] - v6[3] * kd[3], eo.y * kp[4] - v6[4] * kd[4], eo.z * kp[5] - v6[5] * kd[5]};
+                if (C.mode == 3) {
+                    // fork-only "wrench" baseline (utils/plot.py:267-268; checkpoint action box [-10,10]^6): the action takes the place
+                    // of desired_force / desired_torque in the OSC law, i.e. wrench = [Lambda_pos a_f; Lambda_ori a_t].  Inferred; the
+                    // shipped `wrench` policy replayed under this reading earns 9.2 reward/step (8.6 on MuJoCo), under "action =
+                    // wrench" it fails within 80 steps (tests/test_gpu_policy_replay.py)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) { Fp[a] = clampf(act[a], -WRENCH_MAX, WRENCH_MAX); Tp[a] = clampf(act[3 + a], -WRENCH_MAX, WRENCH_MAX); }
+                }
                 // lambda_pos F, lambda_ori T : solves with the 3x3 diagonal blocks of Li (uncouple_pos_ori, rl_config.yaml:48)
                 {
                     float P3[6] = {Li[PK(0, 0)], Li[PK(1, 0)], Li[PK(1, 1)], Li[PK(2, 0)], Li[PK(2, 1)], Li[PK(2, 2)]}, ip[3];
@@ -945,8 +954,9 @@ __global__ void usim_random_actions_kernel(const DevCfg C, int n, long long rste
     uint32_t rr[8] = {r1.a, r1.b, r1.c, r1.d, r2.a, r2.b, r2.c, r2.d};
     for (int a = 0; a < C.adim; ++a) {
         float u = u01(rr[a]);
-        bool sgn = (C.mode == 1) || (C.mode == 2 && a == 6);
-        act[(size_t)i * C.adim + a] = sgn ? 2.f * u - 1.f : u;
+        bool sgn = (C.mode == 1) || (C.mode == 3) || (C.mode == 2 && a == 6);
+        float v = sgn ? 2.f * u - 1.f : u;
+        act[(size_t)i * C.adim + a] = (C.mode == 3) ? v * WRENCH_MAX : v;
     }
 }
 

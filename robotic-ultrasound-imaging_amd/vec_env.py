@@ -21,6 +21,7 @@ _ACTION_BOX = {  # SURVEY.md Appendix D.1 (decoded from the reference checkpoint
     0: ([0.0] * 6, [1.0] * 6),
     1: ([-1.0] * 6, [1.0] * 6),
     2: ([0.0] * 6 + [-1.0], [1.0] * 7),
+    3: ([-10.0] * 6, [10.0] * 6),
 }
 
 

@@ -72,9 +72,10 @@ def main():
     # policy weights of the `tracking` checkpoint (policy.pth inside the zip is a plain tensor state dict): data for the
     # policy-replay test; stored as float16-exact? no -- float32 as shipped
     import io, torch
-    with zipfile.ZipFile(REF / "tracking.zip") as z:
-        sd = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=True)
-    np.savez_compressed(OUT / "tracking_policy.npz", **{k: v.numpy() for k, v in sd.items()})
+    for m in MODELS:
+        with zipfile.ZipFile(REF / f"{m}.zip") as z:
+            sd = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=True)
+        np.savez_compressed(OUT / f"{m}_policy.npz", **{k: v.numpy() for k, v in sd.items()})
     np.savez_compressed(OUT / "reference_pins.npz", **arrays)
     (OUT / "reference_pins.json").write_text(json.dumps(meta, indent=1, sort_keys=True))
     for k, a in arrays.items():

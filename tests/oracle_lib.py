@@ -10,7 +10,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 ORACLE_DIR = ROOT / "oracle"
 OBS_DIM, MAXC, NSCALAR = 19, 8, 40
-MODE = {"tracking": 0, "fixed": 1, "variable_z": 2}
+MODE = {"tracking": 0, "fixed": 1, "variable_z": 2, "wrench": 3}
 TORSO = {"none": 0, "top": 1}
 
 SCALAR_FIELDS = {  # name -> slice in the uso_get_state scalar block

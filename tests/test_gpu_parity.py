@@ -98,13 +98,13 @@ def _run_parity(usim, n, steps, torso, mode, **extra):
     return explained
 
 
-@pytest.mark.parametrize("mode", ["tracking", "fixed", "variable_z"])
+@pytest.mark.parametrize("mode", ["tracking", "fixed", "variable_z", "wrench"])
 def test_rigid_torso_parity_200_steps(usim, mode):
     """BASELINE configs[1]: contact solver off, OSC controller only"""
     _run_parity(usim, 256, 200, "rigid", mode)
 
 
-@pytest.mark.parametrize("mode", ["tracking", "fixed"])
+@pytest.mark.parametrize("mode", ["tracking", "fixed", "wrench"])
 def test_soft_torso_parity_200_steps(usim, mode):
     """BASELINE configs[2]: soft-torso contact + force/velocity-tracking reward"""
     _run_parity(usim, 256, 200, "soft", mode)

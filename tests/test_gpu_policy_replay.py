@@ -51,6 +51,27 @@ def test_reference_trained_policy_transfers(usim, pins):
     env.close()
 
 
+@pytest.mark.parametrize("name,lo,hi", [("variable_z", 7.2, 8.6), ("wrench", 8.0, 9.8)])
+def test_other_checkpoints_confirm_the_inferred_controller_modes(usim, pins, name, lo, hi):
+    """The fork-only controller modes are inferred from plotting code.  Replaying the checkpoint that was trained
+    in each mode is the available evidence for the inference: reward rate on MuJoCo 8.03 (variable_z) and 8.61 (wrench)."""
+    pol = importlib.import_module("robotic-ultrasound-imaging_amd.policy")
+    meta = json.loads((ROOT / "tests/golden/reference_pins.json").read_text())[name]
+    sd = {k: torch.from_numpy(v) for k, v in np.load(ROOT / f"tests/golden/{name}_policy.npz").items()}
+    stats = {"obs_mean": pins[name + "_obs_rms_mean"], "obs_var": pins[name + "_obs_rms_var"], "count": meta["obs_rms_count"],
+             "ret_mean": meta["ret_rms_mean"], "ret_var": meta["ret_rms_var"], "clip_obs": meta["clip_obs"], "clip_reward": meta["clip_reward"],
+             "gamma": meta["gamma"], "epsilon": meta["epsilon"]}
+    kw = usim.default_robosuite_kwargs(); kw["controller_configs"] = dict(kw["controller_configs"], impedance_mode=name)
+    env = usim.UltrasoundVecEnv(1024, device="cuda:0", seed=3, **kw)
+    assert np.array_equal(env.action_space.low, pins[name + "_action_low"]) and np.array_equal(env.action_space.high, pins[name + "_action_high"])
+    policy = pol.MlpActorCritic.from_sb3_state_dict(sd).to(env.device)
+    vn = pol.DeviceVecNormalize.from_stats(stats, 1024, device=env.device, training=False, norm_reward=False)
+    out = pol.policy_rollout(env, policy, vn, 2500, deterministic=False)
+    assert lo < out["reward_per_step"] < hi, out["reward_per_step"]
+    assert out["mean_episode_length"] > 0.9 * meta["ep_mean_length"]
+    env.close()
+
+
 def test_device_vecnormalize_matches_running_statistics():
     pol = importlib.import_module("robotic-ultrasound-imaging_amd.policy")
     g = torch.Generator(device="cuda").manual_seed(0)

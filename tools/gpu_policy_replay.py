@@ -7,24 +7,20 @@ usim = importlib.import_module("robotic-ultrasound-imaging_amd")
 pol = importlib.import_module("robotic-ultrasound-imaging_amd.policy")
 np.set_printoptions(precision=4, suppress=True, linewidth=200)
 pins = np.load(ROOT / "tests/golden/reference_pins.npz")
-meta = json.loads((ROOT / "tests/golden/reference_pins.json").read_text())["tracking"]
-sd = {k: torch.from_numpy(v) for k, v in np.load(ROOT / "tests/golden/tracking_policy.npz").items()}
-stats = {"obs_mean": pins["tracking_obs_rms_mean"], "obs_var": pins["tracking_obs_rms_var"], "count": meta["obs_rms_count"], "ret_mean": meta["ret_rms_mean"],
+NAME = sys.argv[1] if len(sys.argv) > 1 else "tracking"
+meta = json.loads((ROOT / "tests/golden/reference_pins.json").read_text())[NAME]
+sd = {k: torch.from_numpy(v) for k, v in np.load(ROOT / f"tests/golden/{NAME}_policy.npz").items()}
+stats = {"obs_mean": pins[NAME + "_obs_rms_mean"], "obs_var": pins[NAME + "_obs_rms_var"], "count": meta["obs_rms_count"], "ret_mean": meta["ret_rms_mean"],
          "ret_var": meta["ret_rms_var"], "clip_obs": meta["clip_obs"], "clip_reward": meta["clip_reward"], "gamma": meta["gamma"], "epsilon": meta["epsilon"]}
 n, steps = 2048, 3000
-env = usim.UltrasoundVecEnv(n, seed=3, **usim.default_robosuite_kwargs())
+kw = usim.default_robosuite_kwargs(); kw["controller_configs"] = dict(kw["controller_configs"], impedance_mode=NAME)
+env = usim.UltrasoundVecEnv(n, seed=3, **kw)
 policy = pol.MlpActorCritic.from_sb3_state_dict(sd).to(env.device)
 for det in (False, True):
     vn = pol.DeviceVecNormalize.from_stats(stats, n, device=env.device, training=False, norm_reward=False)
     out = pol.policy_rollout(env, policy, vn, steps, deterministic=det)
-    print("== trained `tracking` policy, deterministic =", det)
+    print(f"== trained `{NAME}` policy, deterministic =", det)
     print("reward/step", out["reward_per_step"], " reference (ep return / ep length):", meta["ep_mean_return"] / meta["ep_mean_length"])
     print("episodes", out["episodes"], "mean return", out["mean_episode_return"], "mean length", out["mean_episode_length"], " reference:", meta["ep_mean_return"], meta["ep_mean_length"])
-    print("obs mean ours", out["obs_mean"]); print("obs mean ref ", pins["tracking_obs_rms_mean"])
-    print("obs std  ours", np.sqrt(out["obs_var"])); print("obs std  ref ", np.sqrt(pins["tracking_obs_rms_var"]))
-# random-action baseline for contrast
-env.reset_tensor()
-s1 = torch.zeros(19, dtype=torch.float64, device=env.device); rs = 0.0
-for k in range(1000):
-    obs, rew, done = env.step_tensor(env.random_actions_tensor(k)); s1 += obs.double().sum(0); rs += float(rew.mean())
-print("== random actions: reward/step", rs / 1000, "obs mean", (s1 / (1000 * n)).cpu().numpy())
+    print("obs mean ours", out["obs_mean"]); print("obs mean ref ", pins[NAME + "_obs_rms_mean"])
+    print("obs std  ours", np.sqrt(out["obs_var"])); print("obs std  ref ", np.sqrt(pins[NAME + "_obs_rms_var"]))
