@@ -242,8 +242,9 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
     HIPCHK(h, hipEventCreate(&h->ev0));
     HIPCHK(h, hipEventCreate(&h->ev1));
     // kernel mapping: rigid torso -> one environment per lane; soft torso -> 8 or 16 lanes per
-    // environment (auto = 16, which puts one 4-wave workgroup on every CU at 4096 envs/GPU)
-    h->lpe = h->n_el ? (cfg->lanes_per_env == 0 ? 16 : cfg->lanes_per_env) : 1;
+    // environment.  The step kernel needs the whole register file of a SIMD (one wave per SIMD), so the mapping that
+    // yields about 1024 waves wins: 16 lanes up to 4096 envs/GPU (one 4-wave workgroup per CU), 8 lanes beyond.
+    h->lpe = h->n_el ? (cfg->lanes_per_env == 0 ? (n_envs <= 4096 ? 16 : 8) : cfg->lanes_per_env) : 1;
     if (h->n_el && h->lpe != 8 && h->lpe != 16) return USIM_ERR_INVALID;
     h->lds_bytes = 0;
     if (h->n_el) {
