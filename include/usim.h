@@ -32,6 +32,7 @@ extern "C" {
 #define USIM_MAXC 8       /* contact slots per environment */
 #define USIM_NSCALAR 40   /* scalar state words per environment in usim_get_state/usim_set_state */
 #define USIM_RESET_PARAMS 13
+#define USIM_LOG_WIDTH 53
 
 typedef enum usim_status {
     USIM_OK = 0,
@@ -88,6 +89,9 @@ typedef struct usim_step_io {
     float* ep_return_dev;      /* [n]      SB3 Monitor infos[i]["episode"]["r"]; written where done */
     int32_t* ep_length_dev;    /* [n]      SB3 Monitor infos[i]["episode"]["l"]; written where done */
     float* act_out_dev;        /* [n][A]   usim_rollout_random only: the actions drawn in-kernel (completes the transition) */
+    float* log_dev;            /* [n][USIM_LOG_WIDTH] per-step episode record, the channels of the reference's save_data CSV dump
+                                *          (ultrasound.py:552-614): ee_pos3 goal_pos3 ee_vel3 goal_vel vbar ee_quat4 goal_quat4 quat_dist Fz goal_Fz
+                                *          Fz_mean dFz goal_dFz is_contact q7 torques7 time% pos/ori/vel/force/dforce reward action7 */
 } usim_step_io;
 
 /* fills *c with the shipped configuration (src/rl_config.yaml) */

@@ -14,6 +14,7 @@ OBS_DIM = 19
 MAXC = 8
 NSCALAR = 40
 RESET_PARAMS = 13
+LOG_WIDTH = 53
 
 MODE = {"tracking": 0, "fixed": 1, "variable_z": 2, "wrench": 3}
 TORSO = {"none": 0, "rigid": 0, "top": 1, "soft": 1}
@@ -34,7 +35,7 @@ class UsimStepIO(C.Structure):
     """struct usim_step_io (include/usim.h); all members are device pointers"""
     _fields_ = [(n, C.c_void_p) for n in (
         "act_dev", "obs_dev", "rew_dev", "done_dev", "term_obs_dev", "contacts_dev", "ep_return_dev", "ep_length_dev",
-        "act_out_dev")]
+        "act_out_dev", "log_dev")]
 
 
 # every exported symbol of include/usim.h: name -> (restype, argtypes)

@@ -58,8 +58,7 @@ def make_config(seed=3, env_offset=0, **kw):
         raise ValueError("Tried to specify gripper other than UltrasoundProbeGripper in Ultrasound environment!")
     if not kw.pop("use_box_torso", True):
         raise ValueError("cylinder torso (soft_human_torso.xml) is not implemented (SURVEY.md 8f)")
-    if kw.pop("save_data", False):
-        raise ValueError("save_data CSV dump is not implemented (SURVEY.md 8f)")
+    kw.pop("save_data", False)          # handled by the host classes (episode_log.EpisodeLogger), not by the simulator config
     if kw.pop("use_object_obs", False):
         raise ValueError("use_object_obs=True is not implemented (rl_config.yaml:22 uses False)")
     cc = kw.pop("controller_configs", None) or default_robosuite_kwargs()["controller_configs"]

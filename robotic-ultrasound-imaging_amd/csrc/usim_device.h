@@ -18,6 +18,7 @@ constexpr int LAT_NA = 9;         // lattice ix count (outer index of the shell 
 constexpr int LAT_NC = 11;        // lattice iz count (inner index)
 constexpr int LINV_BLK = 8;       // row block of the blocked lattice inverse
 constexpr int LINV_NBLK = 13;     // ceil(99 / 8)
+constexpr int LOG_WIDTH = 53;      // words per environment of the optional episode record
 constexpr int WG = 64;            // one wave64 per workgroup: one environment per lane
 
 // scalar state fields (same order as usim_get_state's [n][USIM_NSCALAR] block)
@@ -56,6 +57,7 @@ struct DevIO {
     float* obs; float* rew; uint8_t* done;
     float* term_obs; int* contacts; float* ep_ret; int* ep_len;
     float* act_out;                 // [n][A] drawn actions (LF_RANDOM_ACT) or nullptr
+    float* log;                     // [n][LOG_WIDTH] per-step episode record (CSV dump of the reference) or nullptr
     const uint8_t* mask;            // reset mask (reset-only launches)
     const float* reset_params;      // [n][13] explicit reset draws or nullptr
     int2* items;                    // refill work list of (env, episode): appended by step kernels, consumed by refill launches

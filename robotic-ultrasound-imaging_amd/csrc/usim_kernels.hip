@@ -843,6 +843,24 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                         done = done || term;
                     }
                     epret += reward;
+                    if (store && io.log) {
+                        // per-step episode record in the order of the reference's CSV dump (ultrasound.py:552-614)
+                        float* L = io.log + (size_t)ei * LOG_WIDTH;
+                        const float upn = clampf((float)t / (float)C.horizon + u0, 0.f, 1.f);
+                        const f3 tpn = ts + (te - ts) * upn;                                    // trajectory point after this step's update (:532)
+                        L[0] = xw.x; L[1] = xw.y; L[2] = xw.z; L[3] = tpn.x; L[4] = tpn.y; L[5] = tpn.z;
+                        L[6] = hv.x; L[7] = hv.y; L[8] = hv.z; L[9] = 0.04f; L[10] = vbar;
+                        L[11] = qe[0]; L[12] = qe[1]; L[13] = qe[2]; L[14] = qe[3];
+                        L[15] = M.gquat[0]; L[16] = M.gquat[1]; L[17] = M.gquat[2]; L[18] = M.gquat[3];
+                        L[19] = ori_err * 5.0f;                                                 // distance_quat (ori_err = 0.2 * distance)
+                        L[20] = fz; L[21] = 5.0f; L[22] = fzbar; L[23] = dfz; L[24] = 0.f; L[25] = contact ? 1.f : 0.f;
+#pragma unroll
+                        for (int i = 0; i < NJ; ++i) { L[26 + i] = q[i]; L[33 + i] = tau[i]; }
+                        L[40] = (float)(t - 1) / (float)C.horizon * 100.f;
+                        L[41] = pos_rew; L[42] = ori_rew; L[43] = vel_rew; L[44] = force_rew; L[45] = dforce_rew;
+#pragma unroll
+                        for (int a = 0; a < 7; ++a) L[46 + a] = act[a];
+                    }
                     if (R.overflow) status |= 1;
                     if (store) {
                         io.rew[ei] = reward;

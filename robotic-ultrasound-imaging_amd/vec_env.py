@@ -69,7 +69,7 @@ class UltrasoundVecEnv:
             self._ep_ret = torch.zeros(n, dtype=torch.float32, device=self.device)
             self._ep_len = torch.zeros(n, dtype=torch.int32, device=self.device)
         self._io = _lib.UsimStepIO(self._act.data_ptr(), self._obs.data_ptr(), self._rew.data_ptr(), self._done.data_ptr(),
-                                   self._term.data_ptr(), self._contacts.data_ptr(), self._ep_ret.data_ptr(), self._ep_len.data_ptr(), None)
+                                   self._term.data_ptr(), self._contacts.data_ptr(), self._ep_ret.data_ptr(), self._ep_len.data_ptr(), None, None)
         self._t_start = time.time()
         self._pending = False
         self.horizon = int(self.cfg.horizon)
@@ -151,7 +151,7 @@ class UltrasoundVecEnv:
         """usim_step_io over a rollout block (dict of [T, n, ...] device tensors: obs, rew, done and optionally act)."""
         act = block.get("act")
         return _lib.UsimStepIO(None, block["obs"].data_ptr(), block["rew"].data_ptr(), block["done"].data_ptr(), None, None, None, None,
-                               None if act is None else act.data_ptr())
+                               None if act is None else act.data_ptr(), None)
 
     def rollout_random(self, first_step, nsteps, block=None):
         """Enqueue nsteps steps with in-kernel synthetic actions.  With `block`, step k
@@ -185,6 +185,20 @@ class UltrasoundVecEnv:
         if with_actions:
             blk["act"] = torch.zeros((T, n, self.action_dim), dtype=torch.float32, device=self.device)
         return blk
+
+    def enable_step_log(self, enable=True):
+        """Allocate (or drop) the [n, 53] per-step episode record the step kernel fills (channels of the reference's save_data dump)."""
+        if enable:
+            self._log = torch.zeros((self.num_envs, _lib.LOG_WIDTH), dtype=torch.float32, device=self.device)
+            self._io.log_dev = self._log.data_ptr()
+        else:
+            self._log = None
+            self._io.log_dev = None
+        return getattr(self, "_log", None)
+
+    @property
+    def step_log(self):
+        return getattr(self, "_log", None)
 
     @property
     def terminal_obs(self):
@@ -307,7 +321,12 @@ class UltrasoundEnv:
     No auto-reset: stepping a finished episode raises ValueError like robosuite's MujocoEnv.step."""
 
     def __init__(self, device="cuda:0", seed=3, **robosuite_kwargs):
+        save_data = bool(robosuite_kwargs.get("save_data", False))
         self._vec = UltrasoundVecEnv(1, device=device, seed=seed, monitor=False, **robosuite_kwargs)
+        self._logger = None
+        if save_data:                                   # ultrasound.py:479-509: per-episode CSV dump of the single environment
+            from .episode_log import EpisodeLogger
+            self._logger = EpisodeLogger(self._vec, 0, root=".")
         self.action_space = self._vec.action_space
         self.observation_space = self._vec.observation_space
         self.horizon = self._vec.horizon
@@ -335,6 +354,8 @@ class UltrasoundEnv:
         torch.cuda.synchronize(self._vec.device)
         self.done = bool(done[0].item())
         self._last_reward = float(rew[0].item())
+        if self._logger is not None:
+            self._logger.after_step(self.done)
         return obs[0].cpu().numpy().copy(), self._last_reward, self.done, {}
 
     def reward(self, action=None):

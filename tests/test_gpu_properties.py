@@ -172,3 +172,35 @@ def test_long_random_rollout_stays_finite_at_full_size(usim):
     assert np.isfinite(st["q"]).all() and np.abs(st["s"]).max() < 0.03
     assert (st["status"] != 0).mean() < 0.2        # contact-slot overflow (bit 0) stays rare
     env.close()
+
+
+def test_episode_csv_dump_matches_reference_wire_format(usim, tmp_path, monkeypatch):
+    """save_data=True (ultrasound.py:479-509, 552-614, 890-910): 23 files in three folders, `horizon` rows, no header, `_<idx>` suffix,
+    channels consistent with the step outputs."""
+    monkeypatch.chdir(tmp_path)
+    kw = usim.default_robosuite_kwargs(); kw["horizon"] = 40; kw["early_termination"] = False; kw["save_data"] = True
+    env = usim.UltrasoundEnv(device="cuda:0", seed=5, **kw)
+    for ep in range(2):
+        obs = env.reset()
+        rewards, forces = [], []
+        for t in range(40):
+            obs, r, done, _ = env.step(np.full(6, 0.6, dtype=np.float32))
+            rewards.append(r); forces.append(obs[2])
+        assert done
+    sim, rew, pol = tmp_path / "simulation_data", tmp_path / "reward_data", tmp_path / "policy_data"
+    assert len(list(sim.glob("*_1.csv"))) == 17 and len(list(rew.glob("*_2.csv"))) == 5 and (pol / "action_2.csv").exists()
+    load = lambda p: np.loadtxt(p, delimiter=",", ndmin=2)
+    ee_pos, goal = load(sim / "ee_pos_2.csv"), load(sim / "ee_goal_pos_2.csv")
+    assert ee_pos.shape == (40, 3) and goal.shape == (40, 3) and load(sim / "q_pos_2.csv").shape == (40, 7)
+    assert load(sim / "ee_quat_2.csv").shape == (40, 4) and load(pol / "action_2.csv").shape == (40, 6)
+    terms = sum(load(rew / f"{n}_2.csv")[:, 0] for n in ("pos", "ori", "vel", "force", "derivative_force"))
+    assert np.allclose(terms, rewards, atol=1e-5)                                   # the five shaped terms add up to the step reward
+    assert np.allclose(load(sim / "ee_z_contact_force_2.csv")[:, 0], forces, atol=1e-5)
+    assert np.allclose(load(sim / "time_2.csv")[:, 0], np.arange(40) / 40 * 100, atol=1e-4)
+    assert np.all(np.abs(load(sim / "q_torques_2.csv")) <= np.array([80, 80, 80, 80, 12, 12, 12]) + 1e-4)
+    assert np.allclose(load(sim / "ee_goal_vel_2.csv"), 0.04) and np.allclose(load(sim / "ee_z_goal_contact_force_2.csv"), 5.0)
+    assert np.allclose(np.linalg.norm(load(sim / "ee_quat_2.csv"), axis=1), 1.0, atol=1e-5)
+    assert np.allclose(goal[:, 2], 0.8572 + 0.039, atol=1e-5)                       # trajectory height (ultrasound.py:807)
+    assert np.allclose(load(pol / "action_2.csv"), 0.6)
+    assert set(np.unique(load(sim / "is_contact_2.csv"))) <= {0.0, 1.0}
+    env.close()
