@@ -752,12 +752,18 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
             R.fc[0] = W[0]; R.fc[1] = W[1]; R.fc[2] = W[2];
             // ---------------- torque sensor at ft_frame (MuJoCo cfrc_int of the probe body, site frame) ----------------
             {
-                f3 al = D.al7, a7 = D.a7;
+                // link-7 accelerations from the site Jacobian: alpha = alpha_bias + Jw qacc, a(o7) = a_bias + Jv qacc - (Jw qacc) x (x - o7)
+                float aq[6];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    al = madd(al, K.z[j], qacc[j]);
-                    a7 = madd(a7, cross(K.z[j], K.o[NJ - 1] - K.o[j]), qacc[j]);
+                for (int a = 0; a < 6; ++a) {
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) sacc = fmaf(J[a][j], qacc[j], sacc);
+                    aq[a] = sacc;
                 }
+                const f3 alq = mk(aq[3], aq[4], aq[5]);
+                f3 al = D.al7 + alq;
+                f3 a7 = D.a7 + mk(aq[0], aq[1], aq[2]) - cross(alq, K.x - K.o[NJ - 1]);
                 f3 rc = K.r7x * M.pcom7[0] + K.r7y * M.pcom7[1] + K.r7z * M.pcom7[2];
                 f3 ac = a7 + cross(al, rc) + cross(D.w7, cross(D.w7, rc));
                 f3 N = rot_inertia_mul(K, M.pI7, al) + cross(D.w7, rot_inertia_mul(K, M.pI7, D.w7));
@@ -768,19 +774,18 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
             TSTAMP(13);
             // ---------------- integrate the arm: mj_Euler with implicit joint damping ----------------
             if (pass == 0) {
-                float rhs[NJ], Ld[28], idd[NJ];
+                // (M + h D) x = M qacc with D = 0.1 I and h D = 2e-4 I << M: two steps of the fixed point x <- qacc - h d M^-1 x on the
+                // existing Cholesky factor contract by (h d / lambda_min(M))^3 < 3e-8, i.e. to fp32 rounding of the exact solve
+                float rhs[NJ], yk[NJ];
+                const float hd = dt * JOINT_DAMP;
 #pragma unroll
-                for (int i = 0; i < NJ; ++i) {
-                    float s = 0.f;
+                for (int i = 0; i < NJ; ++i) yk[i] = qacc[i];
+                chol_solve<NJ>(Lm, idm, yk);
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) s = fmaf((i >= j) ? D.M[PK(i, j)] : D.M[PK(j, i)], qacc[j], s);
-                    rhs[i] = s;
-                }
+                for (int i = 0; i < NJ; ++i) { rhs[i] = fmaf(-hd, yk[i], qacc[i]); yk[i] = rhs[i]; }
+                chol_solve<NJ>(Lm, idm, yk);
 #pragma unroll
-                for (int k = 0; k < 28; ++k) Ld[k] = D.M[k];
-#pragma unroll
-                for (int i = 0; i < NJ; ++i) Ld[PK(i, i)] += dt * JOINT_DAMP;
-                chol_packed<NJ>(Ld, idd); chol_solve<NJ>(Ld, idd, rhs);
+                for (int i = 0; i < NJ; ++i) rhs[i] = fmaf(-hd, yk[i], qacc[i]);
 #pragma unroll
                 for (int i = 0; i < NJ; ++i) { qd[i] = fmaf(dt, rhs[i], qd[i]); q[i] = fmaf(dt, qd[i], q[i]); }
                 // hand velocity: Jacobian from before the integration, qvel from after (mj_step data semantics)
