@@ -16,7 +16,12 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def usim():
-    """the product package (directory name has hyphens, so it is imported through importlib)"""
+    """the product package (directory name has hyphens, so it is imported through importlib); built on demand like
+    __graft_entry__.build() does, so that a fresh checkout can run the suite directly"""
+    lib = ROOT / "robotic-ultrasound-imaging_amd" / "lib" / "libusim.so"
+    if not lib.exists():
+        import subprocess
+        subprocess.run(["make", "-s", "-C", str(ROOT / "robotic-ultrasound-imaging_amd" / "csrc")], check=True)
     return importlib.import_module("robotic-ultrasound-imaging_amd")
 
 
