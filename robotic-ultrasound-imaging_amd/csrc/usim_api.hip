@@ -35,6 +35,13 @@ struct usim_handle {
     std::string hip_err;
 };
 
+// every entry point runs on the handle's device and restores the caller's current device afterwards
+struct DeviceGuard {
+    int prev = -1; bool switched = false;
+    explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = (hipSetDevice(dev) == hipSuccess); }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
 #define HIPCHK(h, call)                                                                                     \
     do {                                                                                                    \
         hipError_t e_ = (call);                                                                             \
@@ -219,7 +226,7 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
     *out = h;                       // returned even on failure so that usim_last_hip_error can be read; caller destroys
     h->cfg = *cfg; h->n = n_envs; h->npad = (n_envs + WG - 1) / WG * WG; h->device = device;
     h->adim = (cfg->mode == USIM_MODE_VARIABLE_Z) ? 7 : 6;
-    HIPCHK(h, hipSetDevice(device));
+    DeviceGuard guard(device);
     int rc = build_model(h);
     if (rc != USIM_OK) return rc;
     DevCfg& C = h->C;
@@ -270,7 +277,7 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
 
 void usim_destroy(usim_handle* h) {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);
     (void)hipDeviceSynchronize();
     if (h->state) (void)hipFree(h->state);
     if (h->d_items) (void)hipFree(h->d_items);
@@ -311,11 +318,13 @@ static int reset_common(usim_handle* h, const uint8_t* mask_dev, const float* pa
 
 int usim_reset(usim_handle* h, const uint8_t* mask_dev, float* obs_dev, void* stream) {
     if (!h) return USIM_ERR_INVALID;
+    DeviceGuard guard(h->device);
     return reset_common(h, mask_dev, nullptr, obs_dev, stream);
 }
 
 int usim_reset_explicit(usim_handle* h, const uint8_t* mask_dev, const float* params_dev, float* obs_dev, void* stream) {
     if (!h || !params_dev) return USIM_ERR_INVALID;
+    DeviceGuard guard(h->device);
     return reset_common(h, mask_dev, params_dev, obs_dev, stream);
 }
 
@@ -343,6 +352,7 @@ static int step_common(usim_handle* h, DevIO io, int flags, long long rstep, voi
 
 int usim_step(usim_handle* h, const usim_step_io* s, int auto_reset, void* stream) {
     if (!h) return USIM_ERR_INVALID;
+    DeviceGuard guard(h->device);
     DevIO io; int rc = fill_io(s, io, true);
     if (rc) return rc;
     return step_common(h, io, auto_reset ? LF_AUTO_RESET : 0, 0, stream);
@@ -350,6 +360,7 @@ int usim_step(usim_handle* h, const usim_step_io* s, int auto_reset, void* strea
 
 int usim_random_actions(usim_handle* h, int64_t step, float* act_dev, void* stream) {
     if (!h || !act_dev) return USIM_ERR_INVALID;
+    DeviceGuard guard(h->device);
     hipLaunchKernelGGL(usim_random_actions_kernel, dim3((h->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->C, h->n, (long long)step, act_dev);
     HIPCHK(h, hipGetLastError());
     return USIM_OK;
@@ -357,6 +368,7 @@ int usim_random_actions(usim_handle* h, int64_t step, float* act_dev, void* stre
 
 int usim_rollout_random(usim_handle* h, int64_t first_step, int nsteps, const usim_step_io* s, int block_advance, void* stream) {
     if (!h || nsteps < 0) return USIM_ERR_INVALID;
+    DeviceGuard guard(h->device);
     DevIO io; int rc = fill_io(s, io, false);
     if (rc) return rc;
     io.act = nullptr;
@@ -378,6 +390,7 @@ int usim_rollout_random(usim_handle* h, int64_t first_step, int nsteps, const us
 
 int usim_time_steps(usim_handle* h, int64_t first_step, int nsteps, const usim_step_io* s, int block_advance, void* stream, float* elapsed_ms) {
     if (!h || !elapsed_ms) return USIM_ERR_INVALID;
+    DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(h, hipEventRecord(h->ev0, st));
     int rc = usim_rollout_random(h, first_step, nsteps, s, block_advance, stream);
@@ -390,7 +403,7 @@ int usim_time_steps(usim_handle* h, int64_t first_step, int nsteps, const usim_s
 
 int usim_get_state(usim_handle* h, float* scalars, float* lattice) {
     if (!h || !scalars) return USIM_ERR_INVALID;
-    HIPCHK(h, hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
     HIPCHK(h, hipDeviceSynchronize());
     std::vector<float> buf((size_t)h->nfields * h->npad);
     HIPCHK(h, hipMemcpy(buf.data(), h->state, buf.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -412,7 +425,7 @@ int usim_get_state(usim_handle* h, float* scalars, float* lattice) {
 
 int usim_set_state(usim_handle* h, const float* scalars, const float* lattice) {
     if (!h || !scalars) return USIM_ERR_INVALID;
-    HIPCHK(h, hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
     HIPCHK(h, hipDeviceSynchronize());
     std::vector<float> buf((size_t)h->nfields * h->npad);
     HIPCHK(h, hipMemcpy(buf.data(), h->state, buf.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -442,6 +455,7 @@ int usim_set_state(usim_handle* h, const float* scalars, const float* lattice) {
 
 int usim_profile_step(usim_handle* h, const usim_step_io* s, int64_t step, uint64_t* ticks, int max_ticks) {
     if (!h || !ticks || max_ticks < 17) return USIM_ERR_INVALID;
+    DeviceGuard guard(h->device);
     DevIO io; int rc = fill_io(s, io, false);
     if (rc) return rc;
     io.act = nullptr;
