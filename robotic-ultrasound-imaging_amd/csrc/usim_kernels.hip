@@ -774,18 +774,21 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
             TSTAMP(13);
             // ---------------- integrate the arm: mj_Euler with implicit joint damping ----------------
             if (pass == 0) {
-                // (M + h D) x = M qacc with D = 0.1 I and h D = 2e-4 I << M: two steps of the fixed point x <- qacc - h d M^-1 x on the
-                // existing Cholesky factor contract by (h d / lambda_min(M))^3 < 3e-8, i.e. to fp32 rounding of the exact solve
-                float rhs[NJ], yk[NJ];
-                const float hd = dt * JOINT_DAMP;
+                // (M + h D) x = M qacc: the factorisation of M + h D does not depend on the contact solve, so the scheduler can
+                // overlap it with the lattice/contact phases; only one triangular solve pair stays on the tail of the step
+                float rhs[NJ], Ld[28], idd[NJ];
 #pragma unroll
-                for (int i = 0; i < NJ; ++i) yk[i] = qacc[i];
-                chol_solve<NJ>(Lm, idm, yk);
+                for (int i = 0; i < NJ; ++i) {
+                    float sm = 0.f;
 #pragma unroll
-                for (int i = 0; i < NJ; ++i) { rhs[i] = fmaf(-hd, yk[i], qacc[i]); yk[i] = rhs[i]; }
-                chol_solve<NJ>(Lm, idm, yk);
+                    for (int j = 0; j < NJ; ++j) sm = fmaf((i >= j) ? D.M[PK(i, j)] : D.M[PK(j, i)], qacc[j], sm);
+                    rhs[i] = sm;
+                }
 #pragma unroll
-                for (int i = 0; i < NJ; ++i) rhs[i] = fmaf(-hd, yk[i], qacc[i]);
+                for (int k = 0; k < 28; ++k) Ld[k] = D.M[k];
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) Ld[PK(i, i)] += dt * JOINT_DAMP;
+                chol_packed<NJ>(Ld, idd); chol_solve<NJ>(Ld, idd, rhs);
 #pragma unroll
                 for (int i = 0; i < NJ; ++i) { qd[i] = fmaf(dt, rhs[i], qd[i]); q[i] = fmaf(dt, qd[i], q[i]); }
                 // hand velocity: Jacobian from before the integration, qvel from after (mj_step data semantics)
