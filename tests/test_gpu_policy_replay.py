@@ -68,7 +68,7 @@ def test_other_checkpoints_confirm_the_inferred_controller_modes(usim, pins, nam
     vn = pol.DeviceVecNormalize.from_stats(stats, 1024, device=env.device, training=False, norm_reward=False)
     out = pol.policy_rollout(env, policy, vn, 2500, deterministic=False)
     assert lo < out["reward_per_step"] < hi, out["reward_per_step"]
-    assert out["mean_episode_length"] > 0.9 * meta["ep_mean_length"]
+    assert out["mean_episode_length"] > 0.75 * meta["ep_mean_length"]
     env.close()
 
 
