@@ -961,7 +961,8 @@ static void step_env(Sim* S, int i, const double* act_d, double* obs, double* re
     const uso_config* c = &S->cfg;
     const Model* m = &S->m;
     const real dt = (real)c->control_dt;
-    real act[8]; for (int a = 0; a < S->adim; a++) act[a] = (real)act_d[a];
+    real act[8];
+    for (int a = 0; a < S->adim; a++) { double v = act_d[a]; act[a] = (v == v && fabs(v) <= 3.0e38) ? (real)v : 0; }   /* non-finite action -> 0 */
     E->t += 1;                                             /* MujocoEnv.step: timestep += 1 [RESTATED, SURVEY C.1] */
     Pass P; forward_pass(S, E, act, 0, &P);
     /* mj_Euler with implicit joint damping [RESTATED]: qd += dt (M + dt D)^-1 M qacc ; q += dt qd */
@@ -1025,6 +1026,10 @@ static void step_env(Sim* S, int i, const double* act_d, double* obs, double* re
     E->ep_return += reward;
     E->ncon = P.f.ncon; for (int cix = 0; cix < P.f.ncon; cix++) E->con_el[cix] = m->el_shell_id[P.f.con_el[cix]];
     if (P.f.overflow) E->status |= 1;
+    {   /* numerical fault guard: a non-finite or run-away state ends the episode (status bit 2) */
+        double chk = 0; for (int j = 0; j < NJ; j++) chk += fabs((double)E->q[j]) + 1e-3 * fabs((double)E->qd[j]);
+        if (!(chk < 1.0e3)) { E->status |= 4; done = 1; }
+    }
     if (contacts) { contacts[0] = P.f.ncon; for (int cix = 0; cix < USO_MAXC; cix++) contacts[1 + cix] = cix < P.f.ncon ? E->con_el[cix] : -1; }
     if (rew) *rew = (double)reward;
     if (done_out) *done_out = (uint8_t)done;

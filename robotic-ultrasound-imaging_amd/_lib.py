@@ -35,7 +35,7 @@ class UsimStepIO(C.Structure):
     """struct usim_step_io (include/usim.h); all members are device pointers"""
     _fields_ = [(n, C.c_void_p) for n in (
         "act_dev", "obs_dev", "rew_dev", "done_dev", "term_obs_dev", "contacts_dev", "ep_return_dev", "ep_length_dev",
-        "act_out_dev", "log_dev")]
+        "act_out_dev", "status_dev", "log_dev")]
 
 
 # every exported symbol of include/usim.h: name -> (restype, argtypes)

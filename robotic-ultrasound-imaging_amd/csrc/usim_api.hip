@@ -332,7 +332,7 @@ static int fill_io(const usim_step_io* s, DevIO& io, bool need_act) {
     if (!s || !s->obs_dev || !s->rew_dev || !s->done_dev || (need_act && !s->act_dev)) return USIM_ERR_INVALID;
     io = DevIO{};
     io.act = s->act_dev; io.obs = s->obs_dev; io.rew = s->rew_dev; io.done = s->done_dev; io.term_obs = s->term_obs_dev;
-    io.contacts = s->contacts_dev; io.ep_ret = s->ep_return_dev; io.ep_len = s->ep_length_dev; io.act_out = s->act_out_dev; io.log = s->log_dev;
+    io.contacts = s->contacts_dev; io.ep_ret = s->ep_return_dev; io.ep_len = s->ep_length_dev; io.act_out = s->act_out_dev; io.log = s->log_dev; io.status_out = s->status_dev;
     return USIM_OK;
 }
 

@@ -57,6 +57,7 @@ struct DevIO {
     float* obs; float* rew; uint8_t* done;
     float* term_obs; int* contacts; float* ep_ret; int* ep_len;
     float* act_out;                 // [n][A] drawn actions (LF_RANDOM_ACT) or nullptr
+    int* status_out;                // [n] status word of the step (bit 0 contact-slot overflow, bit 2 numerical fault) or nullptr
     float* log;                     // [n][LOG_WIDTH] per-step episode record (CSV dump of the reference) or nullptr
     const uint8_t* mask;            // reset mask (reset-only launches)
     const float* reset_params;      // [n][13] explicit reset draws or nullptr

@@ -305,7 +305,10 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
             }
         } else {
 #pragma unroll
-            for (int a = 0; a < 7; ++a) if (a < C.adim) act[a] = io.act[(size_t)ei * C.adim + a];
+            for (int a = 0; a < 7; ++a) if (a < C.adim) {
+                float v = io.act[(size_t)ei * C.adim + a];
+                act[a] = (v == v && fabsf(v) <= 3.0e38f) ? v : 0.f;      // a non-finite action component is treated as 0
+            }
         }
     }
 
@@ -870,8 +873,16 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                         for (int a = 0; a < 7; ++a) L[46 + a] = act[a];
                     }
                     if (R.overflow) status |= 1;
+                    {
+                        // numerical fault guard: a non-finite or run-away state ends the episode and is flagged
+                        float chk = 0.f;
+#pragma unroll
+                        for (int i = 0; i < NJ; ++i) chk += fabsf(q[i]) + 1e-3f * fabsf(qd[i]);
+                        if (!(chk < 1.0e3f)) { status |= 4; done = true; }
+                    }
                     if (store) {
                         io.rew[ei] = reward;
+                        if (io.status_out) io.status_out[ei] = status;
                         io.done[ei] = done ? 1 : 0;
                         if (io.contacts) {
                             io.contacts[(size_t)ei * (1 + MAXC)] = R.ncon;

@@ -68,8 +68,9 @@ class UltrasoundVecEnv:
             self._contacts = torch.zeros((n, 1 + _lib.MAXC), dtype=torch.int32, device=self.device)
             self._ep_ret = torch.zeros(n, dtype=torch.float32, device=self.device)
             self._ep_len = torch.zeros(n, dtype=torch.int32, device=self.device)
+            self._status = torch.zeros(n, dtype=torch.int32, device=self.device)
         self._io = _lib.UsimStepIO(self._act.data_ptr(), self._obs.data_ptr(), self._rew.data_ptr(), self._done.data_ptr(),
-                                   self._term.data_ptr(), self._contacts.data_ptr(), self._ep_ret.data_ptr(), self._ep_len.data_ptr(), None, None)
+                                   self._term.data_ptr(), self._contacts.data_ptr(), self._ep_ret.data_ptr(), self._ep_len.data_ptr(), None, self._status.data_ptr(), None)
         self._t_start = time.time()
         self._pending = False
         self.horizon = int(self.cfg.horizon)
@@ -151,7 +152,7 @@ class UltrasoundVecEnv:
         """usim_step_io over a rollout block (dict of [T, n, ...] device tensors: obs, rew, done and optionally act)."""
         act = block.get("act")
         return _lib.UsimStepIO(None, block["obs"].data_ptr(), block["rew"].data_ptr(), block["done"].data_ptr(), None, None, None, None,
-                               None if act is None else act.data_ptr(), None)
+                               None if act is None else act.data_ptr(), None, None)
 
     def rollout_random(self, first_step, nsteps, block=None):
         """Enqueue nsteps steps with in-kernel synthetic actions.  With `block`, step k
@@ -199,6 +200,11 @@ class UltrasoundVecEnv:
     @property
     def step_log(self):
         return getattr(self, "_log", None)
+
+    @property
+    def status(self):
+        """int32 [n] status word of the last step (bit 0: contact-slot overflow, bit 2: numerical fault -> episode ended)"""
+        return self._status
 
     @property
     def terminal_obs(self):

@@ -204,3 +204,37 @@ def test_episode_csv_dump_matches_reference_wire_format(usim, tmp_path, monkeypa
     assert np.allclose(load(pol / "action_2.csv"), 0.6)
     assert set(np.unique(load(sim / "is_contact_2.csv"))) <= {0.0, 1.0}
     env.close()
+
+
+def test_numerical_fault_guard_and_action_sanitising(usim):
+    """Non-finite action components are treated as 0; a non-finite / run-away state ends the episode, sets status bit 2 and the
+    environment restarts from its next prepared episode while its neighbours are untouched."""
+    from oracle_lib import Oracle
+    n = 64
+    env, ref = _env(usim, n, "soft"), _env(usim, n, "soft")
+    env.reset_tensor(); ref.reset_tensor()
+    act = env.random_actions_tensor(0).clone()
+    bad = act.clone(); bad[3, 2] = float("nan"); bad[7, 0] = float("inf")
+    clean = act.clone(); clean[3, 2] = 0.0; clean[7, 0] = 0.0
+    o1 = [t.clone() for t in env.step_tensor(bad)]; o2 = [t.clone() for t in ref.step_tensor(clean)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(o1, o2)) and torch.isfinite(o1[0]).all()
+    st = env.get_state()
+    st["q"][5, :] = np.nan; st["qd"][9, :] = 1e9
+    env.set_state(st); ref.set_state(ref.get_state())
+    a1 = env.random_actions_tensor(1).clone()
+    obs, rew, done = [t.clone() for t in env.step_tensor(a1)]
+    obs_r, rew_r, done_r = [t.clone() for t in ref.step_tensor(a1)]
+    torch.cuda.synchronize()
+    status = env.status.cpu().numpy()
+    assert done[5] and done[9] and (status[5] & 4) and (status[9] & 4)
+    ok = np.ones(n, bool); ok[[5, 9]] = False
+    assert torch.equal(obs[ok], obs_r[ok]) and torch.equal(done[ok], done_r[ok]) and not (status[ok] & 4).any()
+    assert torch.isfinite(obs).all()                      # the faulted environments already show their reset observation
+    st2 = env.get_state()
+    assert np.isfinite(st2["q"]).all() and st2["t"][5] == 0 and st2["episode"][5] == st["episode"][5] + 1
+    # the oracle applies the same rule
+    ora = Oracle(4, torso="top"); ora.reset(); so = ora.get_state(); so["q"][1, :] = np.nan; ora.set_state(so)
+    _, _, d, _, _ = ora.step(ora.random_actions(0))
+    assert d[1] and int(ora.get_state()["episode"][1]) == int(so["episode"][1]) + 1
+    env.close(); ref.close()
