@@ -1028,7 +1028,7 @@ static void step_env(Sim* S, int i, const double* act_d, double* obs, double* re
     if (P.f.overflow) E->status |= 1;
     {   /* numerical fault guard: a non-finite or run-away state ends the episode (status bit 2) */
         double chk = 0; for (int j = 0; j < NJ; j++) chk += fabs((double)E->q[j]) + 1e-3 * fabs((double)E->qd[j]);
-        if (!(chk < 1.0e3)) { E->status |= 4; done = 1; }
+        if (!(chk < 1.0e3)) { E->status |= 4; done = 1; E->ep_return -= reward; reward = 0; if (!(E->ep_return == E->ep_return)) E->ep_return = 0; }
     }
     if (contacts) { contacts[0] = P.f.ncon; for (int cix = 0; cix < USO_MAXC; cix++) contacts[1 + cix] = cix < P.f.ncon ? E->con_el[cix] : -1; }
     if (rew) *rew = (double)reward;

@@ -878,7 +878,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                         float chk = 0.f;
 #pragma unroll
                         for (int i = 0; i < NJ; ++i) chk += fabsf(q[i]) + 1e-3f * fabsf(qd[i]);
-                        if (!(chk < 1.0e3f)) { status |= 4; done = true; }
+                        if (!(chk < 1.0e3f)) { status |= 4; done = true; epret -= reward; reward = 0.f; if (!(epret == epret)) epret = 0.f; }
                     }
                     if (store) {
                         io.rew[ei] = reward;

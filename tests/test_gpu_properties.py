@@ -230,7 +230,7 @@ def test_numerical_fault_guard_and_action_sanitising(usim):
     assert done[5] and done[9] and (status[5] & 4) and (status[9] & 4)
     ok = np.ones(n, bool); ok[[5, 9]] = False
     assert torch.equal(obs[ok], obs_r[ok]) and torch.equal(done[ok], done_r[ok]) and not (status[ok] & 4).any()
-    assert torch.isfinite(obs).all()                      # the faulted environments already show their reset observation
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and rew[5] == 0     # faulted envs: reset observation, zero reward
     st2 = env.get_state()
     assert np.isfinite(st2["q"]).all() and st2["t"][5] == 0 and st2["episode"][5] == st["episode"][5] + 1
     # the oracle applies the same rule
