@@ -41,6 +41,10 @@ def test_reference_trained_policy_transfers(usim, pins):
     assert np.all(np.abs(m[6:9]) < 0.01) and np.all(s[6:9] < 3 * rs[6:9]) and np.all(s[6:9] > rs[6:9] / 3)   # eef velocity
     assert abs(m[14] - rm[14]) < 0.005                # probe sits ~1 cm above the trajectory depth (0.0102 on MuJoCo)
     assert m[15] < -0.8 and 0.2 < s[15] < 0.6         # quaternion channel: -1 with occasional sign flips (ref mean -0.95, std 0.30)
+    # the 64 raw in-episode observations stored with the checkpoint (VecNormalize.old_obs) bracket the same operating point
+    old = pins["tracking_old_obs"]
+    assert old[:, 2].min() >= 0 and np.median(old[:, 2]) < 20 and abs(np.median(old[:, 14]) - m[14]) < 0.005
+    assert np.abs(old[:, 6:9]).max() < 0.25 and np.percentile(np.abs(old[:, 10]), 90) < 6 * s[10]
     # the same environments under uniformly random gains earn far less
     env.reset_tensor()
     acc = 0.0
