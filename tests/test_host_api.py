@@ -12,52 +12,6 @@ import torch
 
 ROOT = Path(__file__).resolve().parent.parent
 
-# the `robosuite:` block of /root/reference/src/rl_config.yaml:18-57 (configuration data, verbatim values)
-RL_CONFIG_YAML = """
-seed: 3
-robosuite:
-  env_id: "Ultrasound"
-  robots: "Panda"
-  use_camera_obs: False
-  use_object_obs: False
-  has_renderer: False
-  has_offscreen_renderer: False
-  render_camera: null
-  control_freq: 500
-  horizon: 1000
-  camera_names: "agentview"
-  camera_heights: 48
-  camera_widths: 48
-  camera_depths: false
-  reward_shaping: true
-  controller_configs:
-    type: "OSC_POSE"
-    input_max: 1
-    input_min: -1
-    output_max: [0.05, 0.05, 0.05, 0.5, 0.5, 0.5]
-    output_min: [-0.05, -0.05, -0.05, -0.5, -0.5, -0.5]
-    kp: 300
-    damping_ratio: 1
-    impedance_mode: "tracking"
-    kp_limits: [0, 500]
-    kp_input_max: 1
-    kp_input_min: 0
-    damping_ratio_limits: [0, 2]
-    position_limits: null
-    orientation_limits: null
-    uncouple_pos_ori: True
-    control_delta: True
-    interpolation: null
-    ramp_ratio: 0.2
-  early_termination: True
-  save_data: False
-  deterministic_trajectory: False
-  torso_solref_randomization: True
-  initial_probe_pos_randomization: True
-  use_box_torso: True
-"""
-
-
 def _declared_functions():
     text = (ROOT / "include" / "usim.h").read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
@@ -91,10 +45,15 @@ def test_struct_layouts_match_header(usim):
 
 
 def test_default_config_is_the_shipped_rl_config(usim, tmp_path):
+    # a file with the schema of src/rl_config.yaml (top-level `seed`, `robosuite:` block forwarded verbatim, rl.py:87-92),
+    # including the rendering-only keys of the reference's block, which must be accepted and ignored
+    import yaml
+    block = dict(usim.default_robosuite_kwargs(), env_id="Ultrasound", use_camera_obs=False, has_renderer=False, has_offscreen_renderer=False,
+                 render_camera=None, camera_names="agentview", camera_heights=48, camera_widths=48, camera_depths=False, reward_shaping=True)
     p = tmp_path / "rl_config.yaml"
-    p.write_text(RL_CONFIG_YAML)
+    p.write_text(yaml.safe_dump({"seed": 3, "training": True, "robosuite": block}))
     seed, kwargs = usim.load_yaml(p)
-    assert seed == 3
+    assert seed == 3 and kwargs["controller_configs"]["impedance_mode"] == "tracking"
     c = usim.make_config(seed=seed, **kwargs)
     d = usim.make_config(seed=3, **usim.default_robosuite_kwargs())
     for name, _ in usim._lib.UsimConfig._fields_:
