@@ -20,11 +20,11 @@ MARGIN = {"contact": 5e-6,   # m     : |capsule distance| below which the contac
           "joint": 1e-4}     # rad
 
 
-def _mk(usim, n, torso, mode, seed=3, **extra):
+def _mk(usim, n, torso, mode, seed=3, omp=False, **extra):
     kw = usim.default_robosuite_kwargs()
     kw["controller_configs"] = dict(kw["controller_configs"], impedance_mode=mode)
     env = usim.UltrasoundVecEnv(n, device="cuda:0", seed=seed, torso=torso, **kw, **extra)
-    ora = Oracle(n, precision="f64", mode=mode, torso="top" if torso == "soft" else "none", seed=seed, **extra)
+    ora = Oracle(n, precision="f64", omp=omp, mode=mode, torso="top" if torso == "soft" else "none", seed=seed, **extra)
     return env, ora
 
 
@@ -108,6 +108,13 @@ def test_rigid_torso_parity_200_steps(usim, mode):
 def test_soft_torso_parity_200_steps(usim, mode):
     """BASELINE configs[2]: soft-torso contact + force/velocity-tracking reward"""
     _run_parity(usim, 256, 200, "soft", mode)
+
+
+def test_full_size_parity_4096_envs(usim):
+    """BASELINE configs[2] at its full size: 4096 environments x 200 steps against the oracle (OpenMP build, same source)"""
+    import os
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 64)))
+    _run_parity(usim, 4096, 200, "soft", "tracking", omp=True)
 
 
 def test_eight_lanes_per_env_mapping(usim):
