@@ -76,7 +76,12 @@ def make_config(seed=3, env_offset=0, **kw):
     omax = cc.get("output_max", [0.05] * 3 + [0.5] * 3)
     omax = [omax] * 6 if not isinstance(omax, (list, tuple)) else list(omax)
     c.out_max_pos, c.out_max_ori = float(omax[0]), float(omax[3])
-    c.control_dt = 1.0 / float(kw.pop("control_freq", 500))
+    control_freq = float(kw.pop("control_freq", 500))
+    if abs(control_freq - 500.0) > 1e-9:
+        # robosuite runs control_timestep / model_timestep (2 ms) physics substeps per env.step(); only the shipped setting
+        # (rl_config.yaml:26, main.py: control_freq 500 = one substep) is implemented
+        raise ValueError("only control_freq=500 (one 2 ms physics substep per control step) is implemented")
+    c.control_dt = 1.0 / control_freq
     c.horizon = int(kw.pop("horizon", 1000))
     c.early_termination = int(bool(kw.pop("early_termination", False)))
     c.deterministic_trajectory = int(bool(kw.pop("deterministic_trajectory", False)))
