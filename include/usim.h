@@ -65,6 +65,7 @@ typedef struct usim_config {
     int32_t ik_iters;                          /* reset inverse-kinematics iterations */
     int32_t env_offset;                        /* global index of env 0 of this handle (multi-GPU shard) */
     int32_t lanes_per_env;                     /* soft-torso kernel mapping: 0 auto, 8 or 16 lanes per environment */
+    int32_t torso_shape;                       /* use_box_torso (rl_config.yaml:57): 0 box (soft_box.xml), 1 cylinder (soft_human_torso.xml) */
     uint64_t seed;                             /* rl_config.yaml:1 */
     double control_dt;                         /* 1 / control_freq (rl_config.yaml:26) */
     double kp_fixed, damping_ratio;            /* rl_config.yaml:38-39 */

@@ -63,16 +63,21 @@ static const double GOAL_QUAT_XYZW[4] = {-0.69192486, 0.72186726, -0.00514253, -
 #define ORI_ERR_THRESH 0.10           /* ultrasound.py:181 */
 #define FORCE_EMA_ALPHA 0.1           /* ultrasound.py:153 */
 #define NOISE_SIGMA 0.010             /* ultrasound.py:150 */
-#define TOP_TORSO_OFFSET 0.039        /* ultrasound.py:184 (box torso) */
+#define TOP_TORSO_OFFSET_BOX 0.039    /* ultrasound.py:184 */
+#define TOP_TORSO_OFFSET_CYL 0.041
 #define X_RANGE 0.15                  /* ultrasound.py:185 */
-#define Y_RANGE 0.09                  /* ultrasound.py:186 (box torso) */
+#define Y_RANGE_BOX 0.09              /* ultrasound.py:186 */
+#define Y_RANGE_CYL 0.05
 #define GRID_PTS 50                   /* ultrasound.py:187 */
 #define QLIM_TOL 0.1                  /* robosuite check_q_limits tolerance [RESTATED], ultrasound.py:651 */
 
 /* world placement */
 static const double BASE_WORLD[3] = {-0.56, 0.0, 0.913};   /* ultrasound.py:279-280, Panda on RethinkMount [RESTATED] */
-static const double TORSO_WORLD[3] = {0.0, 0.0, 0.8572};   /* ultrasound.py:146,304-314, soft_box.xml:14 (0.8+0.005+0.0522) */
-#define TORSO_DROP 0.0047             /* spawn gap above the table: 0.8572-0.0525-0.8 */
+/* torso spawn height: table 0.8 + z_offset 0.005 - bottom_site (ultrasound.py:146,304-314): box -0.0522 (soft_box.xml:14),
+ * cylinder -0.05 (soft_human_torso.xml:14); the lowest elements are 0.0525 below the centre in both shapes */
+#define TORSO_Z_BOX 0.8572
+#define TORSO_Z_CYL 0.855
+#define TORSO_HALF_HEIGHT 0.0525
 #define GRAV 9.81
 
 /* Panda (robosuite asset, un-vendored) -- the build's own model definition */
@@ -213,6 +218,7 @@ typedef struct {
     real probe_com7[3], probe_inertia7[9];          /* probe body alone (torque sensor), link-7 frame */
     real cap_c_site[3], cap_axis_site[3];           /* probe capsule centre/axis in site frame */
     real torso_c[3];                                /* torso centre at spawn, base-centred */
+    double torso_w[3], top_offset, y_range, drop;   /* world placement, trajectory height/width, spawn gap above the table */
     real goal_rot[9];                               /* rotmat of goal_quat */
     /* lattice */
     int n_el;                                       /* dynamic elements */
@@ -320,7 +326,11 @@ static void build_model(Sim* S) {
     /* probe collision capsule in the site frame */
     v3set(m->cap_c_site, 0, 0, (real)(-S->cfg.probe_radius));
     v3set(m->cap_axis_site, 0, 1, 0);
-    for (int i = 0; i < 3; i++) m->torso_c[i] = (real)(TORSO_WORLD[i] - BASE_WORLD[i]);
+    const int cyl = S->cfg.torso_shape == 1;
+    m->torso_w[0] = 0; m->torso_w[1] = 0; m->torso_w[2] = cyl ? TORSO_Z_CYL : TORSO_Z_BOX;
+    m->top_offset = cyl ? TOP_TORSO_OFFSET_CYL : TOP_TORSO_OFFSET_BOX; m->y_range = cyl ? Y_RANGE_CYL : Y_RANGE_BOX;
+    m->drop = m->torso_w[2] - TORSO_HALF_HEIGHT - 0.8;
+    for (int i = 0; i < 3; i++) m->torso_c[i] = (real)(m->torso_w[i] - BASE_WORLD[i]);
     double gq[4] = {GOAL_QUAT_XYZW[3], GOAL_QUAT_XYZW[0], GOAL_QUAT_XYZW[1], GOAL_QUAT_XYZW[2]};
     quat_wxyz_to_mat(m->goal_rot, gq);
 
@@ -342,6 +352,14 @@ static void build_model(Sim* S) {
     for (int a = 0; a < LAT_NX; a++) for (int c = 0; c < LAT_NZ; c++) {
         int e = top_of[a][c], b = LAT_NY - 1;
         double loc[3] = {(a - 0.5 * (LAT_NX - 1)) * LAT_SPACING, (b - 0.5 * (LAT_NY - 1)) * LAT_SPACING, (c - 0.5 * (LAT_NZ - 1)) * LAT_SPACING};
+        if (cyl) {
+            /* MuJoCo composite type "cylinder" (soft_human_torso.xml:9) [RESTATED: BoxProject]: the normalised grid coordinate
+             * keeps its max-norm radius in the local x-y cross-section but its direction is projected on the unit circle,
+             * i.e. concentric squares become concentric ellipses with the box's half extents as semi-axes */
+            const double sx = 0.5 * (LAT_NX - 1) * LAT_SPACING, sy = 0.5 * (LAT_NY - 1) * LAT_SPACING;
+            double xn = loc[0] / sx, yn = loc[1] / sy, l0 = fmax(fabs(xn), fabs(yn)), nn = sqrt(xn * xn + yn * yn);
+            if (nn > 0) { loc[0] = sx * l0 * xn / nn; loc[1] = sy * l0 * yn / nn; }
+        }
         double nl = sqrt(loc[0] * loc[0] + loc[1] * loc[1] + loc[2] * loc[2]);
         for (int i = 0; i < 3; i++) {
             double p = Rt[3 * i] * loc[0] + Rt[3 * i + 1] * loc[1] + Rt[3 * i + 2] * loc[2];
@@ -571,6 +589,7 @@ typedef struct {
 static real torso_dz(const Sim* S, int t, real* vz, real* az) {
     /* prescribed base motion: free fall from the 4.7 mm spawn gap, then rest (ultrasound.py:313) */
     *vz = 0; *az = 0;
+    const double TORSO_DROP = S->m.drop;
     if (!S->cfg.torso_drop) return (real)(-TORSO_DROP);
     double tt = t * S->cfg.control_dt, z = -0.5 * GRAV * tt * tt;
     if (z <= -TORSO_DROP) return (real)(-TORSO_DROP);
@@ -889,7 +908,8 @@ static void reset_env(Sim* S, int i, const double* ex /* explicit draws or NULL 
     philox4x32(gid, (uint32_t)episode, 1, 0, k0, k1, B);
     philox4x32(gid, (uint32_t)episode, 2, 0, k0, k1, C);
     double start[3], end[3], u0, noise[3] = {0, 0, 0}, stiff = c->stiffness, damp = c->damping, mu;
-    double tz = TORSO_WORLD[2] + TOP_TORSO_OFFSET;
+    const double* TORSO_WORLD = m->torso_w; const double Y_RANGE = m->y_range;
+    double tz = TORSO_WORLD[2] + m->top_offset;
     if (ex) {
         for (int a = 0; a < 3; a++) { start[a] = ex[a]; end[a] = ex[3 + a]; noise[a] = ex[7 + a]; }
         u0 = ex[6]; stiff = ex[10]; damp = ex[11]; mu = ex[12];
@@ -1050,7 +1070,7 @@ void uso_default_config(uso_config* c) {
     c->seed = 3; c->control_dt = 0.002; c->kp_fixed = 300; c->damping_ratio = 1; c->kp_min = 0; c->kp_max = 500;
     c->out_max_pos = 0.05; c->out_max_ori = 0.5; c->stiffness = 1324.17; c->damping = 17.59;
     c->elem_friction = 0.01; c->probe_friction = 1e-4;
-    c->probe_radius = PROBE_RADIUS; c->probe_halflen = PROBE_HALFLEN;
+    c->probe_radius = PROBE_RADIUS; c->probe_halflen = PROBE_HALFLEN; c->torso_shape = 0;
 }
 void* uso_create(const uso_config* c, int n) {
     Sim* S = (Sim*)calloc(1, sizeof(Sim));

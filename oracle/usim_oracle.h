@@ -47,6 +47,7 @@ typedef struct uso_config {
     int32_t pgs_iters;            /* fixed contact-PGS sweep count */
     int32_t ik_iters;             /* fixed reset-IK iteration count */
     int32_t env_offset;           /* global index of env 0 (multi-GPU shards) */
+    int32_t torso_shape;          /* 0 box (soft_box.xml, use_box_torso True), 1 cylinder (soft_human_torso.xml) */
     uint64_t seed;                /* rl_config.yaml:1 */
     double control_dt;            /* 1/control_freq = 0.002 (rl_config.yaml:26) */
     double kp_fixed;              /* rl_config.yaml:38 / main.py:31 */

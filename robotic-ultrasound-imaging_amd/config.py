@@ -56,8 +56,7 @@ def make_config(seed=3, env_offset=0, **kw):
         raise ValueError("only the Panda robot of rl_config.yaml:20 is implemented (UR5e: SURVEY.md 8f)")
     if kw.pop("gripper_types", "UltrasoundProbeGripper") != "UltrasoundProbeGripper":
         raise ValueError("Tried to specify gripper other than UltrasoundProbeGripper in Ultrasound environment!")
-    if not kw.pop("use_box_torso", True):
-        raise ValueError("cylinder torso (soft_human_torso.xml) is not implemented (SURVEY.md 8f)")
+    use_box = bool(kw.pop("use_box_torso", True))
     kw.pop("save_data", False)          # handled by the host classes (episode_log.EpisodeLogger), not by the simulator config
     if kw.pop("use_object_obs", False):
         raise ValueError("use_object_obs=True is not implemented (rl_config.yaml:22 uses False)")
@@ -102,6 +101,7 @@ def make_config(seed=3, env_offset=0, **kw):
             kw.pop(k)
     if kw:
         raise TypeError(f"unexpected Ultrasound kwargs: {sorted(kw)}")
+    c.torso_shape = 0 if use_box else 1
     c.seed = int(seed)
     c.env_offset = int(env_offset)
     return c

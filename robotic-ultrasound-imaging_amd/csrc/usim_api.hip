@@ -58,7 +58,10 @@ namespace {
 const double kPi = 3.14159265358979323846;
 const double kGoalQuat[4] = {-0.69192486, 0.72186726, -0.00514253, -0.01100909};   // ultrasound.py:174 (x,y,z,w)
 const double kBase[3] = {-0.56, 0.0, 0.913};                                         // ultrasound.py:279-280 + mount height
-const double kTorso[3] = {0.0, 0.0, 0.8 + 0.005 + 0.0522};                           // ultrasound.py:146,313; soft_box.xml:14
+// torso spawn height = table 0.8 + z_offset 0.005 - bottom_site z (ultrasound.py:146,313): box -0.0522 (soft_box.xml:14), cylinder
+// -0.05 (soft_human_torso.xml:14); trajectory height / waypoint grid width per shape (ultrasound.py:184,186)
+const double kTorsoZ[2] = {0.8 + 0.005 + 0.0522, 0.8 + 0.005 + 0.05};
+const double kTopOff[2] = {0.039, 0.041}, kYRange[2] = {0.09, 0.05};
 const double kHandPos[3] = {0, 0, 0.107};
 const double kProbePos[3] = {-0.004, -0.063, 0.128};                                 // ultrasound_probe_gripper.xml:6
 const double kProbeCom[3] = {0.0013, 0.021, -0.043};                                 // stand-in (mesh missing from the snapshot)
@@ -129,6 +132,8 @@ static int build_model(usim_handle* h) {
     M.m7 = (float)c7.m;
     for (int i = 0; i < 3; ++i) { M.c7[i] = (float)c7.c[i]; M.site7[i] = (float)site7[i]; M.hand7[i] = (float)kHandPos[i]; M.pcom7[i] = (float)pcom7[i]; }
     pack_sym(c7.I, M.I7); pack_sym(Ip7, M.pI7);
+    const int shape = h->cfg.torso_shape ? 1 : 0;
+    const double kTorso[3] = {0.0, 0.0, kTorsoZ[shape]};
     for (int i = 0; i < 3; ++i) { M.torso[i] = (float)(kTorso[i] - kBase[i]); M.base[i] = (float)kBase[i]; }
     {
         double x = kGoalQuat[0], y = kGoalQuat[1], z = kGoalQuat[2], w = kGoalQuat[3];
@@ -158,7 +163,13 @@ static int build_model(usim_handle* h) {
     std::vector<double> L((size_t)N_TOP * N_TOP, 0.0);
     for (int a = 0; a < 9; ++a) for (int c = 0; c < 11; ++c) {
         const int e = top_index[a][c];
-        const double loc[3] = {(a - 4) * 0.035, 1.5 * 0.035, (c - 5) * 0.035};
+        double loc[3] = {(a - 4) * 0.035, 1.5 * 0.035, (c - 5) * 0.035};
+        if (shape == 1) {
+            // composite type "cylinder" (soft_human_torso.xml:9): direction in the local x-y cross-section projected on the unit
+            // circle, max-norm radius kept -> the top row of the box becomes the upper arc of an ellipse 0.14 x 0.0525
+            const double xn = loc[0] / 0.14, yn = loc[1] / 0.0525, l0 = std::fmax(std::fabs(xn), std::fabs(yn)), nn = std::sqrt(xn * xn + yn * yn);
+            loc[0] = 0.14 * l0 * xn / nn; loc[1] = 0.0525 * l0 * yn / nn;
+        }
         const double len = std::sqrt(loc[0] * loc[0] + loc[1] * loc[1] + loc[2] * loc[2]);
         // parent quat (0.5, 0.5, -0.5, -0.5): world x = -local z, world y = -local x, world z = local y
         const double w[3] = {-loc[2], -loc[0], loc[1]};
@@ -209,7 +220,7 @@ int usim_default_config(usim_config* c) {
     std::memset(c, 0, sizeof *c);
     c->mode = USIM_MODE_TRACKING; c->torso = USIM_TORSO_TOP; c->horizon = 1000; c->early_termination = 1;
     c->deterministic_trajectory = 0; c->torso_solref_randomization = 1; c->initial_probe_pos_randomization = 1;
-    c->friction_randomization = 0; c->torso_drop = 1; c->pgs_iters = 8; c->ik_iters = 5; c->env_offset = 0; c->lanes_per_env = 0; c->seed = 3;
+    c->friction_randomization = 0; c->torso_drop = 1; c->pgs_iters = 8; c->ik_iters = 5; c->env_offset = 0; c->lanes_per_env = 0; c->torso_shape = 0; c->seed = 3;
     c->control_dt = 0.002; c->kp_fixed = 300; c->damping_ratio = 1; c->kp_min = 0; c->kp_max = 500; c->out_max_pos = 0.05; c->out_max_ori = 0.5;
     c->stiffness = 1324.17; c->damping = 17.59; c->elem_friction = 0.01; c->probe_friction = 1e-4; c->probe_radius = 0.04; c->probe_halflen = 0.02;
     return USIM_OK;
@@ -218,7 +229,8 @@ int usim_default_config(usim_config* c) {
 int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** out) {
     if (!cfg || !out || n_envs <= 0) return USIM_ERR_INVALID;
     if (cfg->mode < 0 || cfg->mode > 3 || cfg->torso < 0 || cfg->torso > 1 || cfg->horizon <= 0 || cfg->control_dt <= 0 ||
-        cfg->probe_halflen < 1e-4 || cfg->probe_radius <= 0 || cfg->pgs_iters < 0 || cfg->ik_iters < 0) return USIM_ERR_INVALID;
+        cfg->probe_halflen < 1e-4 || cfg->probe_radius <= 0 || cfg->pgs_iters < 0 || cfg->ik_iters < 0 || cfg->torso_shape < 0 ||
+        cfg->torso_shape > 1) return USIM_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return USIM_ERR_NO_DEVICE;
     usim_handle* h = new (std::nothrow) usim_handle();
@@ -238,6 +250,10 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
     C.kp_max = (float)cfg->kp_max; C.out_pos = (float)cfg->out_max_pos; C.out_ori = (float)cfg->out_max_ori; C.stiffness = (float)cfg->stiffness;
     C.damping = (float)cfg->damping; C.elem_fric = (float)cfg->elem_friction; C.probe_fric = (float)cfg->probe_friction;
     C.probe_r = (float)cfg->probe_radius; C.probe_hl = (float)cfg->probe_halflen;
+    {
+        const int shape = cfg->torso_shape ? 1 : 0;
+        C.top_off = (float)kTopOff[shape]; C.y_range = (float)kYRange[shape]; C.drop = (float)(kTorsoZ[shape] - 0.0525 - 0.8);
+    }
     h->nfields = h->n_el ? F_TOTAL_TOP : F_NSCALAR;
     h->bank_row0 = h->nfields;                                  // two reset-bank slots follow the live state rows
     size_t bytes = (size_t)(h->nfields + BANK_ROWS) * h->npad * sizeof(float);

@@ -50,6 +50,7 @@ struct DevCfg {
     uint32_t key0, key1;
     float dt, kp_fixed, damping_ratio, kp_min, kp_max, out_pos, out_ori;
     float stiffness, damping, elem_fric, probe_fric, probe_r, probe_hl;
+    float top_off, y_range, drop;       // trajectory height above the torso centre, half width of the waypoint grid, spawn gap
 };
 
 struct DevIO {

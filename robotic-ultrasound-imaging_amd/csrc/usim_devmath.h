@@ -46,7 +46,6 @@ constexpr float JOINT_DAMP = 0.1f;
 constexpr float GRAV = 9.81f;
 constexpr float PROBE_MASS = 1.0f;
 constexpr float ELEM_R = 0.0075f, ELEM_MASS = 0.01f;
-constexpr float TORSO_DROP = 0.0047f;
 // MuJoCo default soft-constraint parameters (solref 0.02 1, solimp 0.9 0.95 0.001 0.5 2) and robosuite's impratio
 constexpr float SR_TC = 0.02f, SI_D0 = 0.9f, SI_DMAX = 0.95f, SI_WIDTH = 0.001f, IMPRATIO = 20.f;
 constexpr float PI_F = 3.14159265358979323846f;

@@ -87,10 +87,10 @@ DI float group_bcast(float v, int k) {
 
 // prescribed torso base motion: free fall over the 4.7 mm spawn gap, then rest (ultrasound.py:313)
 DI void torso_motion(const DevCfg& C, int tsim, float& dz, float& vz, float& az) {
-    dz = -TORSO_DROP; vz = 0.f; az = 0.f;
+    dz = -C.drop; vz = 0.f; az = 0.f;
     if (C.torso_drop) {
         float tt = (float)tsim * C.dt, zf = -0.5f * GRAV * tt * tt;
-        if (zf > -TORSO_DROP) { dz = zf; vz = -GRAV * tt; az = -GRAV; }
+        if (zf > -C.drop) { dz = zf; vz = -GRAV * tt; az = -GRAV; }
     }
 }
 
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                 u4 A = philox(gid, (uint32_t)ep_t, 0u, 0u, C.key0, C.key1);
                 u4 B = philox(gid, (uint32_t)ep_t, 1u, 0u, C.key0, C.key1);
                 u4 Cc = philox(gid, (uint32_t)ep_t, 2u, 0u, C.key0, C.key1);
-                const float tz = M.torso[2] + M.base[2] + 0.039f;          // ultrasound.py:184,807
+                const float tz = M.torso[2] + M.base[2] + C.top_off;      // ultrasound.py:184,807
                 f3 noise = mk(0, 0, 0);
                 kst = C.stiffness; kdmp = C.damping;
                 if (io.reset_params) {
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                         // ultrasound.py:787-788: np.linspace grids over the torso top, 50 points each
                         const float tx = M.torso[0] + M.base[0], ty = M.torso[1] + M.base[1];
                         const float xs = -0.15f + tx + 0.03f, xstep = (0.15f + tx - xs) / 49.f;
-                        const float ys = -0.09f + ty, ystep = 0.18f / 49.f;
+                        const float ys = -C.y_range + ty, ystep = 2.f * C.y_range / 49.f;
                         ts = mk(xs + (float)urange(A.a, 50u) * xstep, ys + (float)urange(A.b, 50u) * ystep, tz);
                         te = mk(xs + (float)urange(A.c, 50u) * xstep, ys + (float)urange(A.d, 50u) * ystep, tz);
                     }

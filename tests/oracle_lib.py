@@ -23,7 +23,7 @@ SCALAR_FIELDS = {  # name -> slice in the uso_get_state scalar block
 class OracleConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "mode", "torso", "horizon", "early_termination", "deterministic_trajectory", "torso_solref_randomization",
-        "initial_probe_pos_randomization", "friction_randomization", "torso_drop", "pgs_iters", "ik_iters", "env_offset")] + \
+        "initial_probe_pos_randomization", "friction_randomization", "torso_drop", "pgs_iters", "ik_iters", "env_offset", "torso_shape")] + \
         [("seed", C.c_uint64)] + [(n, C.c_double) for n in (
             "control_dt", "kp_fixed", "damping_ratio", "kp_min", "kp_max", "out_max_pos", "out_max_ori", "stiffness",
             "damping", "elem_friction", "probe_friction", "probe_radius", "probe_halflen")]

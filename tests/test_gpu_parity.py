@@ -117,6 +117,29 @@ def test_full_size_parity_4096_envs(usim):
     _run_parity(usim, 4096, 200, "soft", "tracking", omp=True)
 
 
+def test_cylinder_torso_parity(usim):
+    """use_box_torso=False (soft_human_torso.xml): elliptic cross-section, y_range 0.05, trajectory 0.041 above the centre"""
+    n = 128
+    kw = usim.default_robosuite_kwargs(); kw["use_box_torso"] = False
+    env = usim.UltrasoundVecEnv(n, device="cuda:0", seed=3, **kw)
+    ora = Oracle(n, precision="f64", seed=3, torso_shape=1)
+    og, oo = env.reset(), ora.reset()
+    st = env.get_state()
+    assert np.allclose(st["traj_start"][:, 2], 0.855 + 0.041, atol=1e-6) and np.abs(st["traj_start"][:, 1]).max() <= 0.05 + 1e-6   # ultrasound.py:184,186
+    assert np.allclose(og[:, 12:19], oo[:, 12:19], atol=2e-6) and np.allclose(og[:, :3], oo[:, :3], atol=2e-2, rtol=1e-3)
+    alive = np.ones(n, bool)
+    for k in range(120):
+        a = ora.random_actions(k)
+        obs_o, rew_o, done_o, _, con_o = ora.step(a)
+        obs_g, rew_g, done_g, _ = env.step(a.astype(np.float32))
+        alive &= (done_g == done_o) & (env.contacts.cpu().numpy() == con_o).all(1)
+    assert alive.mean() > 0.95
+    sg, so = env.get_state(), ora.get_state()
+    for key in ("q", "qd", "s"):
+        assert _relerr(np.asarray(sg[key])[alive], so[key][alive]) < STATE_RTOL, key
+    env.close()
+
+
 def test_eight_lanes_per_env_mapping(usim):
     """the G = 8 instantiation of the grouped kernel (two-instruction DPP broadcast) gives the same results"""
     env, ora = _mk(usim, 96, "soft", "tracking")

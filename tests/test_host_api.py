@@ -78,6 +78,7 @@ def test_config_rejects_what_the_reference_rejects(usim):
         usim.make_config(**{**kw, "no_such_option": 1})
     with pytest.raises(ValueError):
         usim.make_config(**{**kw, "control_freq": 20})             # would need 25 physics substeps per step (ultrasound.py:119 default)
+    assert usim.make_config(**{**kw, "use_box_torso": False}).torso_shape == 1 and usim.make_config(**kw).torso_shape == 0
     fixed = usim.make_config(**{**kw, "controller_configs": {**kw["controller_configs"], "impedance_mode": "fixed"}})
     assert fixed.mode == 1 and fixed.kp_fixed == 300.0
 

@@ -279,3 +279,19 @@ def test_oracle_is_clean_under_asan_and_ubsan():
     r = subprocess.run(["make", "-s", "-C", str(ORACLE_DIR), "sanitize"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "selftest ok" in r.stdout and "ERROR" not in (r.stdout + r.stderr)
+
+
+def test_cylinder_torso_geometry():
+    """soft_human_torso.xml (use_box_torso=False): the top row of elements lies on the upper arc of the 0.14 x 0.0525 ellipse, so
+    contact at reset starts lower away from the crest; trajectory constants of ultrasound.py:184,186."""
+    box, cyl = Oracle(2048, torso_shape=0), Oracle(2048, torso_shape=1)
+    ob, oc = box.reset(), cyl.reset()
+    sb, sc = box.get_state(), cyl.get_state()
+    assert np.allclose(sb["traj_start"][:, 2], 0.8572 + 0.039) and np.allclose(sc["traj_start"][:, 2], 0.855 + 0.041)
+    assert np.abs(sb["traj_start"][:, 1]).max() > 0.08 and np.abs(sc["traj_start"][:, 1]).max() <= 0.05 + 1e-12
+    assert np.all(oc[:, 2] >= 0) and (oc[:, 2] > 0).mean() > 0.5
+    # on the crest (|y| small) the cylinder is as high as the box; towards |y| = 0.05 it has dropped by ~3.5 mm
+    yc = sc["traj_start"][:, 1] * (1 - sc["u0"]) + sc["traj_end"][:, 1] * sc["u0"]
+    edge, crest = np.abs(yc) > 0.04, np.abs(yc) < 0.01
+    on = lambda o, m: o[m & (o[:, 2] > 0), 14].max()
+    assert on(oc, crest) > on(oc, edge) - 1e-3
