@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--workload", choices=["soft", "rigid"], default="soft")
     ap.add_argument("--block", type=int, default=128, help="rollout block length T (steps per all-gather)")
+    ap.add_argument("--randomize", action="store_true", help="BASELINE configs[4]: per-env randomised stiffness/damping + probe friction")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     args = ap.parse_args()
@@ -91,7 +92,8 @@ def main():
     from importlib import import_module
     dmod = import_module("robotic-ultrasound-imaging_amd.distributed")
     n = args.envs_per_gpu
-    env = usim.UltrasoundVecEnv(n, device=device, seed=3, env_offset=rank * n, torso=args.workload, **usim.default_robosuite_kwargs())
+    extra = {"friction_randomization": 1} if args.randomize else {}
+    env = usim.UltrasoundVecEnv(n, device=device, seed=3, env_offset=rank * n, torso=args.workload, **extra, **usim.default_robosuite_kwargs())
     T = max(1, min(args.block, args.steps))
     blocks = [env.alloc_block(T), env.alloc_block(T)]      # double-buffered: gather block b while simulating b^1
     gather = dmod.RolloutGather(device=device) if (use_dist and not args.no_gather) else None
@@ -162,7 +164,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD_NAME[args.workload], "envs_per_gpu": n, "global_envs": n * world,
-                       "controller": "OSC_POSE impedance_mode=tracking", "rollout_block": T,
+                       "controller": "OSC_POSE impedance_mode=tracking", "rollout_block": T, "domain_randomisation": "stiffness+damping" + ("+friction" if args.randomize else ""),
                        "parallelism": f"env-shard x{world}" + (" + RCCL all-gather of transition blocks" if gather is not None else "")},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": "profiles/r01/traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch)" if traffic else None,
