@@ -29,7 +29,7 @@ WORKLOAD_NAME = {"rigid": "configs[1]: 4096 envs/GPU, rigid torso (contact solve
                  "soft": "configs[2]: 4096 envs/GPU, soft-torso contact + force/velocity-tracking reward"}
 
 
-def cpu_baseline(workload, n_envs, budget_s=15.0):
+def cpu_baseline(workload, n_envs, budget_s=float(os.environ.get("USIM_CPU_BUDGET_S", "15"))):
     """The oracle (kind "port": the reference's own mujoco-py path cannot run) timed on this box's host
     cores with OpenMP over environments, on a bounded sample of the same workload."""
     import numpy as np

@@ -1,0 +1,47 @@
+"""bench.py and __graft_entry__.smoke() are the driver's entry points: run them as the driver does and check the JSON contract."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "roofline", "cpu_baseline"}
+
+
+def _run(args, env=None):
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py")] + args, capture_output=True, text=True, timeout=600, cwd=str(ROOT),
+                       env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.strip()]
+    return json.loads(lines[-1])            # the record is the LAST stdout line
+
+
+def test_bench_json_contract_default_workload():
+    out = _run(["--gpus", "1", "--steps", "256", "--warmup", "32"], env={"USIM_CPU_BUDGET_S": "2"})
+    assert REQUIRED <= set(out)
+    assert out["metric"].startswith("env-steps/sec") and out["unit"] == "env-steps/s" and out["higher_is_better"] is True
+    assert out["n_gpus"] == 1 and out["steps"] == 256 and out["warmup"] == 32 and out["scaling"] == "weak" and out["vs_baseline"] is None
+    assert out["dtype"] == "f32" and out["data"] == "synthetic" and "workload" in out["config"] and "model" not in out["config"]
+    assert out["value"] > 1e6 and abs(out["value"] - 4096 * 256 / (out["ms_per_step"] * 256e-3)) / out["value"] < 1e-6
+    rf = out["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
+    assert rf["algorithmic_bytes_per_env_step"] == 1912 and (rf["traffic"] is None or rf["traffic"] > 1e6)
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "env-steps/s" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
+
+
+def test_bench_rigid_workload_and_block_tail():
+    out = _run(["--steps", "200", "--warmup", "10", "--workload", "rigid", "--no-cpu-baseline", "--block", "64"])
+    assert out["roofline"]["algorithmic_bytes_per_env_step"] == 316 and "cpu_baseline" not in out and out["value"] > 1e7
+
+
+def test_graft_entry_smoke():
+    r = subprocess.run([sys.executable, str(ROOT / "__graft_entry__.py"), "smoke"], capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout + r.stderr
