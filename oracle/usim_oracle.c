@@ -656,8 +656,11 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
         m3mulv(t3, k->Rs, m->cap_c_site); v3add(cc, k->x, t3);
         m3mulv(ax, k->Rs, m->cap_axis_site);
         v3addscl(p1, cc, ax, (real)(-S->cfg.probe_halflen)); v3set(d1, ax[0] * (real)(2 * S->cfg.probe_halflen), ax[1] * (real)(2 * S->cfg.probe_halflen), ax[2] * (real)(2 * S->cfg.probe_halflen));
-        int nc = 0;
-        real cn[USO_MAXC][3], cp[USO_MAXC][3], cdist[USO_MAXC];
+        /* candidates: the first USO_MAXCAND penetrating elements in ascending shell id; when more than USO_MAXC are found the
+         * USO_MAXC deepest are kept (ties keep the lower id) and the list stays in ascending shell id.  MuJoCo keeps every contact;
+         * the slot limit is a design choice of this simulator, reported in status bit 0. */
+        int nc = 0, ncand = 0, cand_el[USO_MAXCAND];
+        real cn[USO_MAXCAND][3], cp[USO_MAXCAND][3], cdist[USO_MAXCAND];
         for (int e = 0; e < n; e++) {
             real tip[3], p2[3], d2[3], c1[3], c2[3], d[3];
             for (int a = 0; a < 3; a++) tip[a] = m->torso_c[a] + m->el_pos[e][a] + (E->s[e] - (real)ELEM_RADIUS) * m->el_axis[e][a];
@@ -670,10 +673,27 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
             real am = (real)fabs((double)dist);
             if (am < out->min_margin) out->min_margin = am;
             if (dist < 0) {
-                if (nc >= USO_MAXC) { out->overflow = 1; continue; }
-                if (len > (real)1e-9) { for (int a = 0; a < 3; a++) cn[nc][a] = d[a] / len; } else v3set(cn[nc], 0, 0, 1);
-                for (int a = 0; a < 3; a++) cp[nc][a] = c2[a] + cn[nc][a] * ((real)ELEM_RADIUS + (real)0.5 * dist);
-                cdist[nc] = dist; out->con_el[nc] = e; out->con_dist[nc] = dist; nc++;
+                if (ncand >= USO_MAXC) out->overflow = 1;
+                if (ncand >= USO_MAXCAND) continue;
+                if (len > (real)1e-9) { for (int a = 0; a < 3; a++) cn[ncand][a] = d[a] / len; } else v3set(cn[ncand], 0, 0, 1);
+                for (int a = 0; a < 3; a++) cp[ncand][a] = c2[a] + cn[ncand][a] * ((real)ELEM_RADIUS + (real)0.5 * dist);
+                cdist[ncand] = dist; cand_el[ncand] = e; ncand++;
+            }
+        }
+        {
+            int alive[USO_MAXCAND];
+            for (int c = 0; c < ncand; c++) alive[c] = 1;
+            real last_dropped = 0;
+            for (int drop = ncand - USO_MAXC; drop > 0; drop--) {
+                int worst = -1;
+                for (int c = 0; c < ncand; c++) if (alive[c] && (worst < 0 || cdist[c] >= cdist[worst])) worst = c;
+                alive[worst] = 0; last_dropped = cdist[worst];
+            }
+            for (int c = 0; c < ncand; c++) {
+                if (!alive[c]) continue;
+                if (ncand > USO_MAXC) { real gap = (real)fabs((double)(last_dropped - cdist[c])); if (gap < out->min_margin) out->min_margin = gap; }
+                if (nc != c) { v3cpy(cn[nc], cn[c]); v3cpy(cp[nc], cp[c]); cdist[nc] = cdist[c]; }
+                out->con_el[nc] = cand_el[c]; out->con_dist[nc] = cdist[nc]; nc++;
             }
         }
         out->ncon = nc;

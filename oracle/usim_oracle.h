@@ -27,6 +27,7 @@ extern "C" {
 
 #define USO_OBS_DIM 19
 #define USO_MAXC 8          /* contact slots per env */
+#define USO_MAXCAND 16      /* penetrating elements considered before the USO_MAXC deepest are kept */
 #define USO_NSCALAR 40      /* scalar state words per env exported by uso_get_state */
 
 /* impedance_mode of the OSC controller (rl_config.yaml:41, main.py:33, utils/plot.py:203-211,303-313) */

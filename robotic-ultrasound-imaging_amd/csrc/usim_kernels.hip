@@ -45,9 +45,10 @@ constexpr int GE_SD = 200;                            // sdot[99]
 constexpr int GE_A = 300;                             // lattice acceleration a~[99]
 constexpr int CG_WORDS = 8;                           // contact record: n3, r3, element, distance
 constexpr int GE_CG = 400;                            // contact records 8 x 8
-constexpr int GE_WS = 464;                            // per-contact wrench + element impulse 8 x 8
+constexpr int GE_WS = 464;                            // per-contact wrench + element impulse 8 x 8 (before that: candidate records 8..15)
+constexpr int MAXCAND = 16;                           // penetrating elements recorded before the MAXC deepest are kept
 constexpr int GE_STRIDE = 548;                        // 548 mod 64 = 36: disjoint 16-byte bank windows for 16 environments
-static_assert(GE_WS + MAXC * 8 <= GE_STRIDE, "per-environment LDS block overflow");
+static_assert(GE_WS + MAXC * 8 <= GE_STRIDE && GE_CG + MAXCAND * CG_WORDS <= GE_STRIDE, "per-environment LDS block overflow");
 
 template <int G> struct GroupGeom {
     static constexpr int EPW = 64 / G;                // environments per wave
@@ -96,7 +97,7 @@ DI void torso_motion(const DevCfg& C, int tsim, float& dz, float& vz, float& az)
 
 // Lattice front end of one forward pass, executed by the G lanes of a group on the group's LDS block: stage (s, sdot), build
 // the right-hand side of the soft-equality system, a~ = Linv rhs, collide the probe capsule with the 99 cap spheres and
-// leave the contact records (ascending shell id) in LDS.  Returns the number of contacts found (may exceed MAXC).
+// leave the contact records (ascending shell id; the MAXC deepest when more were found) in LDS.  Returns the number found (may exceed MAXC).
 template <int G, int NE>
 DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, const DevModel& M, const DevCfg& C, const int tsim,
                      const float kst, const float kdmp, const bool live, const float* s_pre, const float* sd_pre,
@@ -194,13 +195,37 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                         const unsigned long long bal = __ballot(hit);
                         const unsigned gm = (unsigned)(bal >> gbase) & ((1u << G) - 1u);
                         const int slot = nc + __popc(gm & ((1u << gl) - 1u));
-                        if (hit && slot < MAXC) {
+                        if (hit && slot < MAXCAND) {
                             const int b = GE_CG + slot * CG_WORDS;
                             EBF(b + 0) = nn.x; EBF(b + 1) = nn.y; EBF(b + 2) = nn.z;
                             EBF(b + 3) = rr.x; EBF(b + 4) = rr.y; EBF(b + 5) = rr.z;
                             EBF(b + 6) = __int_as_float(e); EBF(b + 7) = dist;
                         }
                         nc += __popc(gm);
+                    }
+                    if (nc > MAXC) {
+                        // rare: more penetrating elements than contact slots.  Keep the MAXC deepest of the first MAXCAND candidates
+                        // (ties keep the lower id), list still in ascending shell id; one lane of the group edits the records in place.
+                        group_sync();
+                        if (gl == 0) {
+                            const int m = nc < MAXCAND ? nc : MAXCAND;
+                            for (int drop = m - MAXC; drop > 0; --drop) {
+                                int worst = 0; float wd = -1.0e30f;
+                                for (int j = 0; j < m; ++j) {
+                                    const float dj = EBF(GE_CG + j * CG_WORDS + 7);
+                                    if (dj < 0.f && dj >= wd) { wd = dj; worst = j; }
+                                }
+                                EBF(GE_CG + worst * CG_WORDS + 7) = 1.0f;                       // dropped
+                            }
+                            int wpos = 0;
+                            for (int j = 0; j < m; ++j) {
+                                if (EBF(GE_CG + j * CG_WORDS + 7) < 0.f) {
+                                    if (wpos != j)
+                                        for (int a = 0; a < CG_WORDS; ++a) EBF(GE_CG + wpos * CG_WORDS + a) = EBF(GE_CG + j * CG_WORDS + a);
+                                    ++wpos;
+                                }
+                            }
+                        }
                     }
     return nc;
 #undef EBF
