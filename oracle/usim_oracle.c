@@ -580,6 +580,7 @@ typedef struct {
     real ael[N_TOP];
     int ncon, con_el[USO_MAXC];
     real con_dist[USO_MAXC];
+    real el_dist[N_TOP];        /* signed probe distance of every element (diagnostics) */
     real fc[3];                 /* cfrc_ext[probe][3:6]: net contact force on the probe, world axes */
     real tq_sensor[3];          /* torque sensor at ft_frame, site frame */
     real min_margin;            /* smallest |dist| among near-contact candidate pairs (threshold diagnostics) */
@@ -672,6 +673,7 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
             real len = v3norm(d), dist = len - (real)(S->cfg.probe_radius + ELEM_RADIUS);
             real am = (real)fabs((double)dist);
             if (am < out->min_margin) out->min_margin = am;
+            out->el_dist[e] = dist;
             if (dist < 0) {
                 if (ncand >= USO_MAXC) out->overflow = 1;
                 if (ncand >= USO_MAXCAND) continue;
@@ -988,6 +990,7 @@ static void reset_env(Sim* S, int i, const double* ex /* explicit draws or NULL 
     E->vbar = 0;                              /* |hand_vel| with qvel = 0 */
     E->fzbar = P.f.fc[2];
     E->ncon = P.f.ncon; for (int cix = 0; cix < P.f.ncon; cix++) E->con_el[cix] = m->el_shell_id[P.f.con_el[cix]];
+    if (P.f.overflow) E->status |= 1;         /* the status word covers the reset forward pass too */
     if (obs_out) {
         real ob[USO_OBS_DIM], tpw[3]; traj_eval(S, E, 0, tpw);
         make_obs(S, E, &P.k, &P.f, P.tq, hv, tpw, ob);
@@ -1185,6 +1188,14 @@ int uso_debug_forward(void* h, int env, double* out) {
     out[116] = (double)P.f.ncon; out[117] = (double)P.f.min_margin;
     for (int j = 0; j < NJ; j++) out[118 + j] = (double)P.f.qacc[j];
     return 0;
+}
+int uso_element_distances(void* h, int env, double* dist_out, int32_t* contacts_out) {
+    Sim* S = (Sim*)h; Env* E = &S->env[env];
+    if (S->cfg.torso == USO_TORSO_NONE) return -1;
+    Pass P; forward_pass(S, E, 0, 1, &P);
+    for (int e = 0; e < N_TOP; e++) dist_out[e] = (double)P.f.el_dist[e];
+    contacts_out[0] = P.f.ncon; for (int c = 0; c < USO_MAXC; c++) contacts_out[1 + c] = c < P.f.ncon ? P.f.con_el[c] : -1;
+    return P.f.overflow;
 }
 /* standalone helpers exported for known-answer tests of the env-level formulas */
 double uso_distance_quat(const double* q1_wxyz, const double* q2_wxyz) {

@@ -97,6 +97,9 @@ int uso_random_actions(void* h, int64_t step, double* act);
  * out[0..2] eef pos (world), [3..11] eef rotmat row-major, [12..60] M 7x7, [61..67] bias,
  * [68..109] J 6x7 (site, world axes), [110..112] contact force on probe, [113..115] ee torque sensor */
 int uso_debug_forward(void* h, int env, double* out);
+/* diagnostics: signed probe distance of the 99 elements (element order) at the current state, the contact list the forward
+ * pass keeps (count + element indices, not shell ids); returns the overflow flag */
+int uso_element_distances(void* h, int env, double* dist_out, int32_t* contacts_out);
 
 #ifdef __cplusplus
 }

@@ -191,3 +191,40 @@ def test_domain_randomisation_config5_parity(usim):
     # friction now matters: tangential contact force is visible and matches
     assert _relerr(obs_g[:, :3], obs_o[:, :3]) < 5e-3
     env.close()
+
+
+@pytest.mark.parametrize("lanes", [16, 8])
+def test_contact_slot_overflow_parity(usim, lanes):
+    """probes spawned 1.2-3 cm deep touch up to 11 elements: both implementations keep the 8 deepest, in ascending shell id,
+    flag the overflow, and stay in step afterwards"""
+    n = 256
+    env, ora = _mk(usim, n, "soft", "tracking")
+    if lanes == 8:
+        env.close()
+        env = usim.UltrasoundVecEnv(n, device="cuda:0", seed=3, torso="soft", lanes_per_env=8, **usim.default_robosuite_kwargs())
+    env.reset(); ora.reset()
+    st = ora.get_state()
+    rng = np.random.default_rng(5)
+    noise = np.stack([rng.normal(scale=5e-3, size=n), rng.normal(scale=5e-3, size=n), -rng.uniform(0.012, 0.03, size=n)], axis=1)
+    p = np.concatenate([st["traj_start"], st["traj_end"], st["u0"][:, None], noise, st["stiffness"][:, None], st["damping"][:, None],
+                        st["mu"][:, None]], axis=1)
+    og, oo = env.reset_explicit_tensor(p).cpu().numpy(), ora.reset_explicit(p)
+    assert np.allclose(og[:, 12:19], oo[:, 12:19], atol=2e-6) and np.allclose(og[:, :3], oo[:, :3], atol=5e-2, rtol=2e-3)
+    sg, so = env.get_state(), ora.get_state()
+    assert np.array_equal(sg["status"].astype(int) & 1, so["status"].astype(int) & 1) and (so["status"].astype(int) & 1).sum() > 20
+    alive = np.ones(n, bool)
+    for k in range(25):
+        a = np.full((n, 6), 0.5)
+        obs_o, rew_o, done_o, _, con_o = ora.step(a, auto_reset=False)
+        obs_g, rew_g, done_g = env.step_tensor(torch.as_tensor(a, dtype=torch.float32, device=env.device), auto_reset=False)
+        con_g = env.contacts.cpu().numpy()
+        mism = (con_g != con_o).any(1) & alive
+        if mism.any():
+            inf = ora.last_info()
+            assert all(inf["contact_margin"][i] < MARGIN["contact"] for i in np.nonzero(mism)[0]) and mism.sum() <= 2
+            alive &= ~mism
+        alive &= ~done_o                      # finished episodes are not stepped further in this test
+        assert np.array_equal(con_g[alive], con_o[alive]) and np.array_equal(done_g.cpu().numpy().astype(bool)[alive], done_o[alive])
+        assert np.abs(obs_g.cpu().numpy()[alive, 12:19] - obs_o[alive, 12:19]).max() < 5e-5
+    assert (con_o[:, 0] == 8).sum() > 10 and alive.sum() > n // 2
+    env.close()

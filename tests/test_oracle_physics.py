@@ -295,3 +295,37 @@ def test_cylinder_torso_geometry():
     edge, crest = np.abs(yc) > 0.04, np.abs(yc) < 0.01
     on = lambda o, m: o[m & (o[:, 2] > 0), 14].max()
     assert on(oc, crest) > on(oc, edge) - 1e-3
+
+
+def test_contact_slot_overflow_keeps_the_deepest_elements():
+    """More penetrating elements than contact slots (a probe spawned 2 cm deep): the forward pass keeps the 8 deepest of the first
+    16 by element order, in ascending order, and raises the overflow flag; numpy redoes the selection from the element distances."""
+    import ctypes as C
+    n = 256
+    o = Oracle(n, torso="top", deterministic_trajectory=0)
+    o.reset()
+    st = o.get_state()
+    rng = np.random.default_rng(5)
+    noise = np.stack([rng.normal(scale=5e-3, size=n), rng.normal(scale=5e-3, size=n), -rng.uniform(0.012, 0.03, size=n)], axis=1)
+    params = np.concatenate([st["traj_start"], st["traj_end"], st["u0"][:, None], noise, st["stiffness"][:, None], st["damping"][:, None],
+                             st["mu"][:, None]], axis=1)
+    o.reset_explicit(params)
+    o.lib.uso_element_distances.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    seen_overflow = 0
+    for i in range(n):
+        dist = np.zeros(99); con = np.zeros(9, dtype=np.int32)
+        ovf = o.lib.uso_element_distances(o.h, i, dist.ctypes.data_as(C.POINTER(C.c_double)), con.ctypes.data_as(C.POINTER(C.c_int32)))
+        hits = np.flatnonzero(dist < 0)
+        assert ovf == int(len(hits) > 8)
+        cand = hits[:16]
+        if len(cand) > 8:
+            order = np.lexsort((cand, dist[cand]))            # deepest first, ties to the lower index
+            keep = np.sort(cand[order[:8]])
+            seen_overflow += 1
+        else:
+            keep = cand
+        assert con[0] == len(keep) and list(con[1:1 + len(keep)]) == list(keep) and np.all(con[1 + len(keep):] == -1)
+    assert seen_overflow > 20
+    # the status word reports it for the rest of the episode
+    o.step(np.full((n, 6), 0.5), auto_reset=False)
+    assert (o.get_state()["status"].astype(int) & 1).sum() >= seen_overflow
