@@ -98,7 +98,7 @@ DI void torso_motion(const DevCfg& C, int tsim, float& dz, float& vz, float& az)
 // Lattice front end of one forward pass, executed by the G lanes of a group on the group's LDS block: stage (s, sdot), build
 // the right-hand side of the soft-equality system, a~ = Linv rhs, collide the probe capsule with the 99 cap spheres and
 // leave the contact records (ascending shell id; the MAXC deepest when more were found) in LDS.  Returns the number found (may exceed MAXC).
-template <int G, int NE>
+template <int G, int NE, bool MM>
 DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, const DevModel& M, const DevCfg& C, const int tsim,
                      const float kst, const float kdmp, const bool live, const float* s_pre, const float* sd_pre,
                      const f3 Kx, const f3 Ksy, const f3 Ksz) {
@@ -135,8 +135,52 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                     }
                     if (gl == 0) EBF(GE_X + N_TOP) = 0.f;          // pad word read by the 16-byte row chunks
                     group_sync();
-                                    // ---- a~ = Linv * rhs: lane gl computes rows gl, gl+G, ...; Linv rows and rhs are read as 16-byte chunks ----
-                    {
+                                    // ---- a~ = Linv * rhs ----
+                    if constexpr (MM) {
+                        // Matrix-core form (every lane of the wave is active here): the wave's environments are the columns of one dense
+                        // product A~[99 x EPW] = Linv[99 x 100] X[100 x EPW], issued as v_mfma_f32_4x4x1 (16 blocks of 4 rows x 4 columns
+                        // per instruction).  Lane l feeds Linv row l (and row 64 + l) as the A operand and the rhs of environment l % 4 as
+                        // the B operand; it receives rows 4 (l / 4) .. + 3 of that environment (layout: tools/probe/mfma_4x4x1_layout.hip).
+                        typedef float v4f __attribute__((ext_vector_type(4)));
+                        constexpr int EPW = 64 / G, NSET = (EPW >= 4 && EPW <= 8) ? EPW / 4 : 1;
+                        const int lane = gbase + gl, ebw = eb - gbase / G, blk = lane >> 2;
+                        const int r1 = (64 + lane < N_TOP) ? 64 + lane : N_TOP - 1;
+                        const float4* la0 = reinterpret_cast<const float4*>(&lds[TB_LINV + lane * LROW]);
+                        const float4* la1 = reinterpret_cast<const float4*>(&lds[TB_LINV + r1 * LROW]);
+                        const float4* xb[NSET];
+                        v4f acc0[NSET], acc1[NSET];
+    #pragma unroll
+                        for (int u = 0; u < NSET; ++u) {
+                            xb[u] = reinterpret_cast<const float4*>(&lds[TB_WORDS + (ebw + 4 * u + (lane & 3)) * GE_STRIDE + GE_X]);
+                            acc0[u] = (v4f){0.f, 0.f, 0.f, 0.f}; acc1[u] = (v4f){0.f, 0.f, 0.f, 0.f};
+                        }
+    #pragma unroll 5
+                        for (int c = 0; c < LROW / 4; ++c) {
+                            const float4 a0 = la0[c], a1 = la1[c];
+    #pragma unroll
+                            for (int u = 0; u < NSET; ++u) {
+                                const float4 b = xb[u][c];
+                                acc0[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.x, b.x, acc0[u], 0, 0, 0);
+                                acc1[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.x, b.x, acc1[u], 0, 0, 0);
+                                acc0[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.y, b.y, acc0[u], 0, 0, 0);
+                                acc1[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.y, b.y, acc1[u], 0, 0, 0);
+                                acc0[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.z, b.z, acc0[u], 0, 0, 0);
+                                acc1[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.z, b.z, acc1[u], 0, 0, 0);
+                                acc0[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.w, b.w, acc0[u], 0, 0, 0);
+                                acc1[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.w, b.w, acc1[u], 0, 0, 0);
+                            }
+                        }
+    #pragma unroll
+                        for (int u = 0; u < NSET; ++u) {
+                            float* dst = &lds[TB_WORDS + (ebw + 4 * u + (lane & 3)) * GE_STRIDE + GE_A];
+                            *reinterpret_cast<float4*>(&dst[4 * blk]) = make_float4(acc0[u][0], acc0[u][1], acc0[u][2], acc0[u][3]);
+                            if (64 + 4 * blk < LROW)                       // rows 64..99 (word 99 is padding)
+                                *reinterpret_cast<float4*>(&dst[64 + 4 * blk]) = make_float4(acc1[u][0], acc1[u][1], acc1[u][2], acc1[u][3]);
+                        }
+                        group_sync();
+                    } else {
+                        // VALU form for launches whose environments may be masked: lane gl computes rows gl, gl+G, ...; Linv rows and rhs
+                        // are read as 16-byte chunks
                         const float4* xv = reinterpret_cast<const float4*>(&EBF(GE_X));
                         constexpr int RB = 4;                              // rows per pass share one read of the rhs chunk
     #pragma unroll
@@ -589,7 +633,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                 float dz, vz, az;
                 torso_motion(C, tsim, dz, vz, az);
                 TSTAMP(4);
-                int nc = lattice_front<G, NE>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, pass == 0, s_pre, sd_pre, K.x, K.sy, K.sz);
+                int nc = lattice_front<G, NE, MODE == 0>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, pass == 0, s_pre, sd_pre, K.x, K.sy, K.sz);
                 TSTAMP(7);
                 if (nc > MAXC) { R.overflow = 1; nc = MAXC; }
                 R.ncon = nc;
