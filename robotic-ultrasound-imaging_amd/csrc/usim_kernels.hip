@@ -723,8 +723,9 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                                     for (int d = 0; d < 3; ++d) {
                                         // three independent partial sums keep the dependent chain short (one wave per SIMD)
                                         float r0 = fmaf(Rd[d], f[d], fmaf(g[d], ae, -aref[d]));
-                                        float r1 = fmaf(w[d][2], alpha[2], fmaf(w[d][1], alpha[1], w[d][0] * alpha[0]));
-                                        float r2 = fmaf(w[d][5], alpha[5], fmaf(w[d][4], alpha[4], w[d][3] * alpha[3]));
+                                        // even / odd split: the packed-fp32 pairs (alpha[0],alpha[1]) ... match the pairs of the update below
+                                        float r1 = fmaf(w[d][4], alpha[4], fmaf(w[d][2], alpha[2], w[d][0] * alpha[0]));
+                                        float r2 = fmaf(w[d][5], alpha[5], fmaf(w[d][3], alpha[3], w[d][1] * alpha[1]));
                                         float res = r0 + (r1 + r2);
                                         float fn = f[d] - res * invD[d];
                                         if (d == 0) fn = fmaxf(fn, 0.f);
