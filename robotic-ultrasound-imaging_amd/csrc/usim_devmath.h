@@ -22,6 +22,11 @@ DI float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 DI f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 DI f3 madd(f3 a, f3 b, float s) { return mk(fmaf(b.x, s, a.x), fmaf(b.y, s, a.y), fmaf(b.z, s, a.z)); }
 DI float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+// single-instruction v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 (1 ulp) for well-scaled operands: the library forms wrap each of these in a
+// denormal-range rescue of five more instructions, and the step kernel is bound by VALU issue slots
+DI float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+DI float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+DI float rsq_(float x) { return __builtin_amdgcn_rsqf(x); }
 // symmetric 3x3 (xx,xy,xz,yy,yz,zz) times vector
 DI f3 symmul(const float* I, f3 v) {
     return mk(I[0] * v.x + I[1] * v.y + I[2] * v.z, I[1] * v.x + I[3] * v.y + I[4] * v.z, I[2] * v.x + I[4] * v.y + I[5] * v.z);
@@ -81,9 +86,9 @@ DI void chol_packed(float* L, float* invd) {
         float d = L[PK(j, j)];
 #pragma unroll
         for (int k = 0; k < j; ++k) d = fmaf(-L[PK(j, k)], L[PK(j, k)], d);
-        d = sqrtf(fmaxf(d, 1e-30f));
-        float inv = 1.0f / d;
-        L[PK(j, j)] = d; invd[j] = inv;
+        d = fmaxf(d, 1e-30f);
+        float inv = rsq_(d);
+        L[PK(j, j)] = d * inv; invd[j] = inv;
 #pragma unroll
         for (int i = j + 1; i < N; ++i) {
             float s = L[PK(i, j)];
@@ -228,10 +233,10 @@ DI void mat2quat_xyzw(f3 cx, f3 cy, f3 cz, float* q) {
     // rotation matrix columns cx, cy, cz: m_rc = (column c).component r
     float m00 = cx.x, m10 = cx.y, m20 = cx.z, m01 = cy.x, m11 = cy.y, m21 = cy.z, m02 = cz.x, m12 = cz.y, m22 = cz.z;
     float tr = m00 + m11 + m22, w, x, y, z;
-    if (tr > 0.f) { float s = sqrtf(tr + 1.f) * 2.f; w = 0.25f * s; x = (m21 - m12) / s; y = (m02 - m20) / s; z = (m10 - m01) / s; }
-    else if (m00 > m11 && m00 > m22) { float s = sqrtf(1.f + m00 - m11 - m22) * 2.f; w = (m21 - m12) / s; x = 0.25f * s; y = (m01 + m10) / s; z = (m02 + m20) / s; }
-    else if (m11 > m22) { float s = sqrtf(1.f + m11 - m00 - m22) * 2.f; w = (m02 - m20) / s; x = (m01 + m10) / s; y = 0.25f * s; z = (m12 + m21) / s; }
-    else { float s = sqrtf(1.f + m22 - m00 - m11) * 2.f; w = (m10 - m01) / s; x = (m02 + m20) / s; y = (m12 + m21) / s; z = 0.25f * s; }
+    if (tr > 0.f) { float s = sqrt_(tr + 1.f) * 2.f, r = rcp_(s); w = 0.25f * s; x = (m21 - m12) * r; y = (m02 - m20) * r; z = (m10 - m01) * r; }
+    else if (m00 > m11 && m00 > m22) { float s = sqrt_(1.f + m00 - m11 - m22) * 2.f, r = rcp_(s); w = (m21 - m12) * r; x = 0.25f * s; y = (m01 + m10) * r; z = (m02 + m20) * r; }
+    else if (m11 > m22) { float s = sqrt_(1.f + m11 - m00 - m22) * 2.f, r = rcp_(s); w = (m02 - m20) * r; x = (m01 + m10) * r; y = 0.25f * s; z = (m12 + m21) * r; }
+    else { float s = sqrt_(1.f + m22 - m00 - m11) * 2.f, r = rcp_(s); w = (m10 - m01) * r; x = (m02 + m20) * r; y = (m12 + m21) * r; z = 0.25f * s; }
     if (w < 0.f) { w = -w; x = -x; y = -y; z = -z; }
     q[0] = x; q[1] = y; q[2] = z; q[3] = w;
 }
@@ -256,12 +261,12 @@ DI float distance_quat_goal(const float* q, const float* ghat, float eps_g) {
     float m = fminf(dm, dp);
     if (m == 0.f) return 0.f;                           // q_log: zero vector part (quaternion.py:17-18)
     float h = eps_g + 0.5f * m * (1.f - eps_g);
-    return 4.f * asinf(sqrtf(fminf(0.5f * h, 1.f)));
+    return 4.f * asinf(sqrt_(fminf(0.5f * h, 1.f)));
 }
 
 // closest point of the segment p1 + s d1 (s in [0,1]) to the point c
 DI f3 seg_point(f3 p1, f3 d1, f3 c) {
-    float s = clampf(dot(d1, c - p1) / dot(d1, d1), 0.f, 1.f);
+    float s = clampf(dot(d1, c - p1) * rcp_(dot(d1, d1)), 0.f, 1.f);
     return madd(p1, d1, s);
 }
 

@@ -116,7 +116,7 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                     group_sync();
                                     // ---- lattice right-hand side: a_s + w_fix aref_fix + w_ten sum_j aref_ij ----
                     const float kfix = 1.0f / (SI_DMAX * SR_TC * SR_TC), bfix = 2.0f / (SI_DMAX * SR_TC);
-                    const float kten = kst / SI_DMAX, bten = kdmp / SI_DMAX;
+                    const float kten = kst * (1.0f / SI_DMAX), bten = kdmp * (1.0f / SI_DMAX);
     #pragma unroll
                     for (int i = 0; i < NE; ++i) {
                         const int e = gl + i * G;
@@ -214,7 +214,7 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                     //      wave ballot gives every hit its slot so that the contact list stays sorted by ascending shell id ----
                     f3 cc = Kx - Ksz * C.probe_r;                       // capsule centre one radius behind the tip
                     f3 p1 = cc - Ksy * C.probe_hl, d1 = Ksy * (2.f * C.probe_hl);
-                    const float inv_dd = 1.0f / dot(d1, d1);
+                    const float inv_dd = rcp_(dot(d1, d1));
                     int nc = 0;
     #pragma unroll
                     for (int i = 0; i < NE; ++i) {
@@ -228,11 +228,11 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                             f3 tip = mk(M.torso[0] + lds[TB_POS + 3 * e], M.torso[1] + lds[TB_POS + 3 * e + 1], M.torso[2] + lds[TB_POS + 3 * e + 2] + dz) + ax * (se - ELEM_R);
                             f3 c1 = madd(p1, d1, clampf(dot(d1, tip - p1) * inv_dd, 0.f, 1.f));      // closest point of the probe segment
                             f3 dd = c1 - tip;
-                            float len = sqrtf(dot(dd, dd));
+                            float len = sqrt_(dot(dd, dd));
                             dist = len - (C.probe_r + ELEM_R);
                             hit = dist < 0.f;
                             if (hit) {
-                                nn = (len > 1e-9f) ? dd * (1.f / len) : mk(0, 0, 1);
+                                nn = (len > 1e-9f) ? dd * rcp_(len) : mk(0, 0, 1);
                                 rr = tip + nn * (ELEM_R + 0.5f * dist) - Kx;
                             }
                         }
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
     bool need = reset_only ? (io.mask ? io.mask[ei] != 0 : true) : false;   // lanes that (re)initialise in pass 1
     if (refill) need = valid;
     bool done = false;
-    const float dt = C.dt;
+    const float dt = C.dt, inv_h = rcp_((float)C.horizon);
 
     constexpr int pass = MODE;                        // 0: step from the live state, 1: reset computation
     int ep_t = episode;                               // episode index the reset draws are keyed on
@@ -523,17 +523,17 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
             if (pass == 0) {
                 float kp[6], kd[6];
                 f3 gpos, gx, gy, gz;
-                float up = clampf((float)(t - 1) / (float)C.horizon + u0, 0.f, 1.f);   // controller.traj_pos from the previous _post_action
+                float up = clampf((float)(t - 1) * inv_h + u0, 0.f, 1.f);   // controller.traj_pos from the previous _post_action
                 f3 tpw = ts + (te - ts) * up;
                 if (C.mode == 1) {
                     float d[6];
 #pragma unroll
                     for (int a = 0; a < 6; ++a) d[a] = clampf(act[a], -1.f, 1.f) * (a < 3 ? C.out_pos : C.out_ori);
                     gpos = K.x + mk(d[0], d[1], d[2]);
-                    float ang = sqrtf(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+                    float ang = sqrt_(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
                     if (ang < 1e-12f) { gx = K.sx; gy = K.sy; gz = K.sz; }
                     else {
-                        float hh = 0.5f * ang, sh = sinf(hh) / ang, qw = cosf(hh), qx = d[3] * sh, qy = d[4] * sh, qz = d[5] * sh;
+                        float hh = 0.5f * ang, sh = sinf(hh) * rcp_(ang), qw = cosf(hh), qx = d[3] * sh, qy = d[4] * sh, qz = d[5] * sh;
                         // rotation matrix of the delta quaternion, applied on the left of the current orientation
                         f3 e0 = mk(1.f - 2.f * (qy * qy + qz * qz), 2.f * (qx * qy + qw * qz), 2.f * (qx * qz - qw * qy));
                         f3 e1 = mk(2.f * (qx * qy - qw * qz), 1.f - 2.f * (qx * qx + qz * qz), 2.f * (qy * qz + qw * qx));
@@ -543,13 +543,13 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                         gz = e0 * K.sz.x + e1 * K.sz.y + e2 * K.sz.z;
                     }
 #pragma unroll
-                    for (int a = 0; a < 6; ++a) { kp[a] = C.kp_fixed; kd[a] = 2.f * sqrtf(C.kp_fixed) * C.damping_ratio; }
+                    for (int a = 0; a < 6; ++a) { kp[a] = C.kp_fixed; kd[a] = 2.f * sqrt_(C.kp_fixed) * C.damping_ratio; }
                 } else {
 #pragma unroll
                     for (int a = 0; a < 6; ++a) {
                         float v = (C.mode == 3) ? 0.f : clampf(act[a], 0.f, 1.f);     // wrench mode: no impedance term
                         kp[a] = C.kp_min + v * (C.kp_max - C.kp_min);
-                        kd[a] = 2.f * sqrtf(kp[a]) * C.damping_ratio;
+                        kd[a] = 2.f * sqrt_(kp[a]) * C.damping_ratio;
                     }
                     gpos = mk(tpw.x - M.base[0], tpw.y - M.base[1], tpw.z - M.base[2]);
                     if (C.mode == 2) gpos.z += clampf(act[6], -1.f, 1.f) * C.out_pos;
@@ -673,16 +673,16 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                         const int e = __float_as_int(EB(b + 6));
                         const float dist = EB(b + 7);
                         f3 ref = (fabsf(nn.x) > 0.9f) ? mk(0, 1, 0) : mk(1, 0, 0);
-                        f3 t1 = cross(nn, ref); t1 = t1 * (1.f / sqrtf(dot(t1, t1)));
+                        f3 t1 = cross(nn, ref); t1 = t1 * rsq_(dot(t1, t1));
                         f3 t2 = cross(nn, t1);
                         f3 ax = mk(lds[TB_AXIS + 3 * e], lds[TB_AXIS + 3 * e + 1], lds[TB_AXIS + 3 * e + 2]);
                         const float sde = EB(GE_SD + e);
                         const float bcon = 2.0f / (SI_DMAX * SR_TC);
-                        float xx = fminf(-dist / SI_WIDTH, 1.f);
+                        float xx = fminf(-dist * (1.0f / SI_WIDTH), 1.f);
                         float yy = (xx < 0.5f) ? 2.f * xx * xx : 1.f - 2.f * (1.f - xx) * (1.f - xx);
                         float dimp = SI_D0 + yy * (SI_DMAX - SI_D0);
-                        float kk = dimp / (SI_DMAX * SI_DMAX * SR_TC * SR_TC);
-                        float Rn = (1.f - dimp) / dimp * M.invw;
+                        float kk = dimp * (1.0f / (SI_DMAX * SI_DMAX * SR_TC * SR_TC));
+                        float Rn = (1.f - dimp) * rcp_(dimp) * M.invw;
 #pragma unroll
                         for (int c = 0; c < MAXC; ++c) if (c < nc) Km[c] = lds[TB_LINV + e * LROW + cel[c]] * (1.0f / ELEM_MASS);
                         float linv_ee = lds[TB_LINV + e * LROW + e] * (1.0f / ELEM_MASS);
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                             }
                             aref[d] = -bcon * vrel - (d == 0 ? kk * dist : 0.f);
                             Rd[d] = (d == 0) ? Rn : Rn * (1.0f / IMPRATIO);
-                            invD[d] = 1.0f / (Aii + Rd[d]);
+                            invD[d] = rcp_(Aii + Rd[d]);
                         }
                     }
                     TSTAMP(9);
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                                     // elliptic cone: |f_t| <= mu f_n
                                     float ft2 = f[1] * f[1] + f[2] * f[2], lim = mu * f[0];
                                     if (ft2 > lim * lim) {
-                                        float sc = lim * rsqrtf(ft2);
+                                        float sc = lim * rsq_(ft2);
 #pragma unroll
                                         for (int d = 1; d < 3; ++d) {
                                             float df = f[d] * sc - f[d];
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
             // ---------------- observation (ultrasound.py:363-401) ----------------
             {
                 const int tprev = (pass == 0) ? t - 1 : 0;
-                float up = clampf((float)tprev / (float)C.horizon + u0, 0.f, 1.f);
+                float up = clampf((float)tprev * inv_h + u0, 0.f, 1.f);
                 f3 tpw = ts + (te - ts) * up;
                 if (pass == 1) fzbar = R.fc[2];                          // ultrasound.py:477
                 obs[0] = R.fc[0]; obs[1] = R.fc[1]; obs[2] = R.fc[2];
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                     if (contact) touched = 1;
                     float pe0 = 90.f * (xw.x - tpw.x), pe1 = 90.f * (xw.y - tpw.y);
                     pe0 *= pe0; pe1 *= pe1;
-                    pos_err_norm = sqrtf(pe0 * pe0 + pe1 * pe1);
+                    pos_err_norm = sqrt_(pe0 * pe0 + pe1 * pe1);
                     float pos_rew = 5.f * expf(-pos_err_norm);
                     float qc[4] = {qe[3], qe[0], qe[1], qe[2]};
                     ori_err = 0.2f * distance_quat_goal(qc, M.ghat, M.geps);
@@ -910,10 +910,10 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                     float reward = pos_rew + ori_rew + vel_rew + force_rew + dforce_rew;
                     done = t >= C.horizon;
                     // ---------------- bookkeeping (ultrasound.py:528-546) ----------------
-                    float hvn = sqrtf(dot(hv, hv));
-                    vbar += (hvn - vbar) / (float)t;
+                    float hvn = sqrt_(dot(hv, hv));
+                    vbar += (hvn - vbar) * rcp_((float)t);
                     float fz = R.fc[2];
-                    dfz = (fz - fzprev) / dt;
+                    dfz = (fz - fzprev) * rcp_(dt);
                     fzprev = fz;
                     fzbar = 0.1f * fz + 0.9f * fzbar;
                     if (C.early_term) {                                // ultrasound.py:635-670
@@ -927,7 +927,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                     if (store && io.log) {
                         // per-step episode record in the order of the reference's CSV dump (ultrasound.py:552-614)
                         float* L = io.log + (size_t)ei * LOG_WIDTH;
-                        const float upn = clampf((float)t / (float)C.horizon + u0, 0.f, 1.f);
+                        const float upn = clampf((float)t * inv_h + u0, 0.f, 1.f);
                         const f3 tpn = ts + (te - ts) * upn;                                    // trajectory point after this step's update (:532)
                         L[0] = xw.x; L[1] = xw.y; L[2] = xw.z; L[3] = tpn.x; L[4] = tpn.y; L[5] = tpn.z;
                         L[6] = hv.x; L[7] = hv.y; L[8] = hv.z; L[9] = 0.04f; L[10] = vbar;
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                         L[20] = fz; L[21] = 5.0f; L[22] = fzbar; L[23] = dfz; L[24] = 0.f; L[25] = contact ? 1.f : 0.f;
 #pragma unroll
                         for (int i = 0; i < NJ; ++i) { L[26 + i] = q[i]; L[33 + i] = tau[i]; }
-                        L[40] = (float)(t - 1) / (float)C.horizon * 100.f;
+                        L[40] = (float)(t - 1) * inv_h * 100.f;
                         L[41] = pos_rew; L[42] = ori_rew; L[43] = vel_rew; L[44] = force_rew; L[45] = dforce_rew;
 #pragma unroll
                         for (int a = 0; a < 7; ++a) L[46 + a] = act[a];
