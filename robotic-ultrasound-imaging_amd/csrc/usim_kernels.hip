@@ -43,12 +43,15 @@ constexpr int GE_X = 0;                               // rhs[100] of the lattice
 constexpr int GE_S = 100;                             // s[99]
 constexpr int GE_SD = 200;                            // sdot[99]
 constexpr int GE_A = 300;                             // lattice acceleration a~[99]
+constexpr int GE_U = 300;                             // zero-bordered 11 x 13 grid of u = k_t s + b_t sdot; dead before a~ and the contact records land
+constexpr int GE_U_WORDS = 144;                       // (LAT_NA + 2) * (LAT_NC + 2) = 143, rounded to 16 bytes
 constexpr int CG_WORDS = 8;                           // contact record: n3, r3, element, distance
 constexpr int GE_CG = 400;                            // contact records 8 x 8
 constexpr int GE_WS = 464;                            // per-contact wrench + element impulse 8 x 8 (before that: candidate records 8..15)
 constexpr int MAXCAND = 16;                           // penetrating elements recorded before the MAXC deepest are kept
 constexpr int GE_STRIDE = 548;                        // 548 mod 64 = 36: disjoint 16-byte bank windows for 16 environments
-static_assert(GE_WS + MAXC * 8 <= GE_STRIDE && GE_CG + MAXCAND * CG_WORDS <= GE_STRIDE, "per-environment LDS block overflow");
+static_assert(GE_WS + MAXC * 8 <= GE_STRIDE && GE_CG + MAXCAND * CG_WORDS <= GE_STRIDE && GE_U + GE_U_WORDS <= GE_STRIDE, "per-environment LDS block overflow");
+static_assert((LAT_NA + 2) * (LAT_NC + 2) <= GE_U_WORDS && LAT_NA * LAT_NC == N_TOP, "padded lattice grid");
 
 template <int G> struct GroupGeom {
     static constexpr int EPW = 64 / G;                // environments per wave
@@ -101,40 +104,52 @@ DI void torso_motion(const DevCfg& C, int tsim, float& dz, float& vz, float& az)
 template <int G, int NE, bool MM>
 DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, const DevModel& M, const DevCfg& C, const int tsim,
                      const float kst, const float kdmp, const bool live, const float* s_pre, const float* sd_pre,
-                     const f3 Kx, const f3 Ksy, const f3 Ksz) {
+                     const f3 Kx, const f3 Ksy, const f3 Ksz, unsigned long long* dbg) {
+#define LSTAMP(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = __builtin_readcyclecounter(); } while (0)
 #define EBF(off) lds[TB_WORDS + eb * GE_STRIDE + (off)]
     const int* tb_nbr = reinterpret_cast<const int*>(lds + TB_NBR);
     float dz, vz, az;
     torso_motion(C, tsim, dz, vz, az);
-                                    // ---- stage s, sdot: lane gl of the group owns elements gl, gl+G, ... ----
-                    // (the loads were issued together with the scalar state at the top of the kernel)
+                                    // ---- stage s, sdot and the spring-damper potential u = k_t s + b_t sdot: lane gl of the group owns elements
+                    //      gl, gl+G, ...  u goes into a zero-bordered 11 x 13 copy of the 9 x 11 grid, so that the four neighbours of an
+                    //      element are four unconditional reads; a pinned rim neighbour (s = 0) is a border cell.
+                    // (the loads of s, sdot were issued together with the scalar state at the top of the kernel)
+                    const float kfix = 1.0f / (SI_DMAX * SR_TC * SR_TC), bfix = 2.0f / (SI_DMAX * SR_TC);
+                    const float kten = kst * (1.0f / SI_DMAX), bten = kdmp * (1.0f / SI_DMAX);
+                    {
+                        float4* uz = reinterpret_cast<float4*>(&EBF(GE_U));
+    #pragma unroll
+                        for (int v = gl; v < GE_U_WORDS / 4; v += G) uz[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    int up[NE];
+                    float u_own[NE];
     #pragma unroll
                     for (int i = 0; i < NE; ++i) {
                         const int e = gl + i * G;
-                        if (e < N_TOP) { EBF(GE_S + e) = live ? s_pre[i] : 0.f; EBF(GE_SD + e) = live ? sd_pre[i] : 0.f; }
+                        const int ix = (e * 373) >> 12, iz = e - LAT_NC * ix;            // e / 11 for e < 682
+                        up[i] = (ix + 1) * (LAT_NC + 2) + iz + 1;
+                        const float se = live ? s_pre[i] : 0.f, sde = live ? sd_pre[i] : 0.f;
+                        u_own[i] = fmaf(kten, se, bten * sde);
+                        if (e < N_TOP) { EBF(GE_S + e) = se; EBF(GE_SD + e) = sde; EBF(GE_U + up[i]) = u_own[i]; }
                     }
                     group_sync();
-                                    // ---- lattice right-hand side: a_s + w_fix aref_fix + w_ten sum_j aref_ij ----
-                    const float kfix = 1.0f / (SI_DMAX * SR_TC * SR_TC), bfix = 2.0f / (SI_DMAX * SR_TC);
-                    const float kten = kst * (1.0f / SI_DMAX), bten = kdmp * (1.0f / SI_DMAX);
+                                    // ---- lattice right-hand side: a_s + w_fix aref_fix + w_ten sum_j aref_ij
+                    //      = a_s - w_fix (k_fix s + b_fix sdot) - w_ten (deg u - sum of the four neighbour cells), deg = 4 (3 at the corners) ----
     #pragma unroll
                     for (int i = 0; i < NE; ++i) {
                         const int e = gl + i * G;
                         if (e >= N_TOP) continue;
-                        float se = EBF(GE_S + e), sde = EBF(GE_SD + e);
-                        float r = -(GRAV + az) * lds[TB_AXIS + 3 * e + 2] + M.wfix * (-bfix * sde - kfix * se);
-    #pragma unroll
-                        for (int d = 0; d < 4; ++d) {
-                            int j = tb_nbr[4 * e + d];
-                            if (j >= -1) {
-                                float sj = (j >= 0) ? EBF(GE_S + j) : 0.f, sdj = (j >= 0) ? EBF(GE_SD + j) : 0.f;
-                                r += M.wten * (-bten * (sde - sdj) - kten * (se - sj));
-                            }
-                        }
+                        const float se = live ? s_pre[i] : 0.f, sde = live ? sd_pre[i] : 0.f;
+                        const float* uc = &EBF(GE_U + up[i]);
+                        const float nb = (uc[-1] + uc[1]) + (uc[-(LAT_NC + 2)] + uc[LAT_NC + 2]);
+                        const bool corner = (e == 0) | (e == LAT_NC - 1) | (e == N_TOP - LAT_NC) | (e == N_TOP - 1);
+                        float r = -(GRAV + az) * lds[TB_AXIS + 3 * e + 2] - M.wfix * fmaf(bfix, sde, kfix * se);
+                        r = fmaf(-M.wten, fmaf(corner ? 3.f : 4.f, u_own[i], -nb), r);
                         EBF(GE_X + e) = r;
                     }
                     if (gl == 0) EBF(GE_X + N_TOP) = 0.f;          // pad word read by the 16-byte row chunks
                     group_sync();
+                    LSTAMP(5);
                                     // ---- a~ = Linv * rhs ----
                     if constexpr (MM) {
                         // Matrix-core form (every lane of the wave is active here): the wave's environments are the columns of one dense
@@ -210,6 +225,7 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                             }
                         }
                     }
+                    LSTAMP(6);
                                     // ---- collision: probe capsule vs the 99 cap spheres; the G lanes test G consecutive elements at a time, the
                     //      wave ballot gives every hit its slot so that the contact list stays sorted by ascending shell id ----
                     f3 cc = Kx - Ksz * C.probe_r;                       // capsule centre one radius behind the tip
@@ -273,6 +289,7 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                     }
     return nc;
 #undef EBF
+#undef LSTAMP
 }
 
 struct StepOut {               // results of one forward pass that the env logic needs
@@ -319,7 +336,11 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
 #define STI(f) (reinterpret_cast<int*>(st))[(size_t)(f) * npad + ei]
 #define EB(off) lds[TB_WORDS + eb * GE_STRIDE + (off)]
 // phase timeline probe (diagnostics only): wave 0 of workgroup 0 stamps the shader clock when io.dbg is set
+#ifdef USIM_TSTAMP_NOWAIT   // experiment builds: do not drain outstanding memory operations at the stamps
+#define TSTAMP(k) do { if (io.dbg && blockIdx.x == 0 && threadIdx.x == 0) { io.dbg[k] = __builtin_readcyclecounter(); } } while (0)
+#else
 #define TSTAMP(k) do { if (io.dbg && blockIdx.x == 0 && threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); io.dbg[k] = __builtin_readcyclecounter(); } } while (0)
+#endif
 #define BK(slot, f) st[(size_t)(io.bank_row0 + (slot) * BANK_WORDS + (f)) * npad + ei]
 #define BKI(slot, f) (reinterpret_cast<int*>(st))[(size_t)(io.bank_row0 + (slot) * BANK_WORDS + (f)) * npad + ei]
     if (TORSO && item0 == (refill ? (int)blockIdx.x * EPB : 0)) {
@@ -633,7 +654,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                 float dz, vz, az;
                 torso_motion(C, tsim, dz, vz, az);
                 TSTAMP(4);
-                int nc = lattice_front<G, NE, MODE == 0>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, pass == 0, s_pre, sd_pre, K.x, K.sy, K.sz);
+                int nc = lattice_front<G, NE, MODE == 0>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, pass == 0, s_pre, sd_pre, K.x, K.sy, K.sz, io.dbg);
                 TSTAMP(7);
                 if (nc > MAXC) { R.overflow = 1; nc = MAXC; }
                 R.ncon = nc;
@@ -792,8 +813,8 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                     if (pass == 0) {
                         float a = EB(GE_A + e);
 #pragma unroll
-                        for (int k = 0; k < MAXC; ++k)
-                            if (k < ncmax && k < nc) a = fmaf(lds[TB_LINV + e * LROW + cel[k]], gf[k], a);
+                        for (int k = 0; k < MAXC; ++k)          // slots beyond this environment's count carry gf = 0 and element 0
+                            if (k < ncmax) a = fmaf(lds[TB_LINV + e * LROW + cel[k]], gf[k], a);
                         sdn = EB(GE_SD + e) + dt * a;
                         sn = EB(GE_S + e) + dt * sdn;
                     }

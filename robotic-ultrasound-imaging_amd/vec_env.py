@@ -167,15 +167,23 @@ class UltrasoundVecEnv:
         self._check(self.lib.usim_time_steps(self._handle, int(first_step), int(nsteps), C.byref(io), int(block is not None), self._stream(), C.byref(ms)))
         return float(ms.value)
 
-    PHASES = ["_", "load state", "action+fk+dynamics+chol", "osc", "smooth acc", "stage lattice", "lattice rhs", "lattice solve",
-              "collision", "contact rows", "pgs", "wrench", "lattice integrate", "arm acc+sensor", "arm integrate", "obs+reward+done", "store"]
+    # label of the interval that ENDS at stamp k
+    PHASES = ["_", "load state", "action+fk+dynamics+chol", "osc", "smooth acc", "lattice stage+rhs", "lattice solve (MFMA)", "collision",
+              "site accel + Lambda^-1", "contact rows", "pgs", "wrench", "lattice integrate", "arm acc+sensor", "arm integrate",
+              "obs+reward+done", "store"]
 
     def profile_step(self, step):
         """Diagnostics: shader-clock ticks spent in each phase of one step kernel by wave 0 of workgroup 0."""
         ticks = (C.c_uint64 * 17)()
         self._check(self.lib.usim_profile_step(self._handle, C.byref(self._io), int(step), ticks, 17))
         t = list(ticks)
-        return {name: t[i + 1] - t[i] for i, name in enumerate(self.PHASES[1:]) if t[i + 1] and t[i]}
+        out, prev = {}, t[0]
+        for k in range(1, 17):
+            if t[k] and prev:
+                out[self.PHASES[k]] = t[k] - prev
+            if t[k]:
+                prev = t[k]
+        return out
 
     def alloc_block(self, nsteps, with_actions=True):
         """Device tensors of one rollout block: obs [T,n,19], act [T,n,A], rew [T,n], done [T,n] (uint8)."""
