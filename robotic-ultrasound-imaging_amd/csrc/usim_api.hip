@@ -432,8 +432,8 @@ int usim_get_state(usim_handle* h, float* scalars, float* lattice) {
         }
         if (lattice && h->n_el)
             for (int e = 0; e < h->n_el; ++e) {
-                lattice[((size_t)i * h->n_el + e) * 2] = buf[(size_t)(F_S + e) * h->npad + i];
-                lattice[((size_t)i * h->n_el + e) * 2 + 1] = buf[(size_t)(F_SD + e) * h->npad + i];
+                lattice[((size_t)i * h->n_el + e) * 2] = buf[(size_t)F_LAT * h->npad + (size_t)i * LAT_ENV_WORDS + LAT_S + e];
+                lattice[((size_t)i * h->n_el + e) * 2 + 1] = buf[(size_t)F_LAT * h->npad + (size_t)i * LAT_ENV_WORDS + LAT_SD + e];
             }
     }
     return USIM_OK;
@@ -454,8 +454,8 @@ int usim_set_state(usim_handle* h, const float* scalars, const float* lattice) {
         }
         if (lattice && h->n_el)
             for (int e = 0; e < h->n_el; ++e) {
-                buf[(size_t)(F_S + e) * h->npad + i] = lattice[((size_t)i * h->n_el + e) * 2];
-                buf[(size_t)(F_SD + e) * h->npad + i] = lattice[((size_t)i * h->n_el + e) * 2 + 1];
+                buf[(size_t)F_LAT * h->npad + (size_t)i * LAT_ENV_WORDS + LAT_S + e] = lattice[((size_t)i * h->n_el + e) * 2];
+                buf[(size_t)F_LAT * h->npad + (size_t)i * LAT_ENV_WORDS + LAT_SD + e] = lattice[((size_t)i * h->n_el + e) * 2 + 1];
             }
     }
     HIPCHK(h, hipMemcpy(h->state, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice));

@@ -1,10 +1,11 @@
 // usim_device.h -- data layout shared by the HIP kernels (usim_kernels.hip) and the host side of the C ABI
 // (usim_api.hip).  gfx950 only.
 //
-// HBM layout: every per-environment quantity is a float32 (or int32 bit pattern) array
+// HBM layout: every per-environment scalar is a float32 (or int32 bit pattern) array
 // over environments, `field f of env i` at state[f * n_pad + i] -- struct-of-arrays with the environment as
 // the fastest index, so a wave64 touching one field of 64 consecutive environments reads one aligned 256-byte
-// row.  n_pad is n rounded up to the workgroup width.
+// row.  n_pad is n rounded up to the workgroup width.  The lattice state (s, sdot of the 99 elements) is the
+// exception: it is stored environment-major, because there the lanes of a wave walk the elements of one environment.
 #pragma once
 #include <stdint.h>
 
@@ -26,10 +27,13 @@ enum Field : int {
     F_Q = 0, F_QD = 7, F_Q0 = 14, F_TS = 21, F_TE = 24, F_U0 = 27, F_VBAR = 28, F_FZBAR = 29, F_FZPREV = 30,
     F_DFZ = 31, F_KST = 32, F_KDMP = 33, F_MU = 34, F_T = 35, F_TOUCH = 36, F_EPISODE = 37, F_EPRET = 38,
     F_STATUS = 39, F_NSCALAR = 40,
-    F_S = 40,                       // s[e]   at F_S + e
-    F_SD = 40 + N_TOP,              // sd[e]  at F_SD + e
-    F_TOTAL_TOP = 40 + 2 * N_TOP
+    F_LAT = 40,                     // first row of the lattice region (soft torso): LAT_ENV_WORDS rows of npad words, addressed
+                                    // per environment: env i owns words [i * LAT_ENV_WORDS, (i + 1) * LAT_ENV_WORDS) of the region
+    F_TOTAL_TOP = 40 + 200
 };
+// lattice region, environment-major (the 16 lanes of a group read 16 consecutive words): s[e] at LAT_S + e, sdot[e] at LAT_SD + e
+constexpr int LAT_ENV_WORDS = 200, LAT_S = 0, LAT_SD = 100;
+static_assert(F_TOTAL_TOP == F_LAT + LAT_ENV_WORDS && LAT_SD + N_TOP <= LAT_ENV_WORDS, "lattice region");
 
 // model constants (host-built in fp64, narrowed once; passed to the kernels by value -> kernarg/SGPRs)
 struct DevModel {

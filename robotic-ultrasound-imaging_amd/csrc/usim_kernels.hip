@@ -334,6 +334,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
     const bool auto_reset = (flags & LF_AUTO_RESET) != 0;
 #define ST(f) st[(size_t)(f) * npad + ei]
 #define STI(f) (reinterpret_cast<int*>(st))[(size_t)(f) * npad + ei]
+#define LAT(w) st[(size_t)F_LAT * npad + (size_t)ei * LAT_ENV_WORDS + (w)]
 #define EB(off) lds[TB_WORDS + eb * GE_STRIDE + (off)]
 // phase timeline probe (diagnostics only): wave 0 of workgroup 0 stamps the shader clock when io.dbg is set
 #ifdef USIM_TSTAMP_NOWAIT   // experiment builds: do not drain outstanding memory operations at the stamps
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
     for (int i = 0; i < NE; ++i) {
         const int e = gl + i * G;
         s_pre[i] = 0.f; sd_pre[i] = 0.f;
-        if (TORSO && MODE == 0 && e < N_TOP) { s_pre[i] = ST(F_S + e); sd_pre[i] = ST(F_SD + e); }
+        if (TORSO && MODE == 0 && e < N_TOP) { s_pre[i] = LAT(LAT_S + e); sd_pre[i] = LAT(LAT_SD + e); }
     }
 
     TSTAMP(1);
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                         sdn = EB(GE_SD + e) + dt * a;
                         sn = EB(GE_S + e) + dt * sdn;
                     }
-                    if (valid && (pass == 0 || !refill)) { ST(F_SD + e) = sdn; ST(F_S + e) = sn; }
+                    if (valid && (pass == 0 || !refill)) { LAT(LAT_SD + e) = sdn; LAT(LAT_S + e) = sn; }
                 }
 #pragma unroll
                 for (int k = 0; k < MAXC; ++k) R.con_shell[k] = (k < nc) ? tb_shell[cel[k]] : -1;
@@ -1026,7 +1027,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
 #pragma unroll
             for (int a = 0; a < OBS_DIM; ++a) io.obs[(size_t)ei * OBS_DIM + a] = BK(sl, BOBS + a);
         }
-        if (TORSO && valid) for (int e = gl; e < N_TOP; e += G) { ST(F_S + e) = 0.f; ST(F_SD + e) = 0.f; }
+        if (TORSO && valid) for (int e = gl; e < N_TOP; e += G) { LAT(LAT_S + e) = 0.f; LAT(LAT_SD + e) = 0.f; }
         // the slot just consumed is free again: order the episode that will occupy it (computed by the next bulk refill,
         // which runs at least every BANK_DEPTH steps, i.e. before this environment can come round to the slot again)
         if (store) { const int idx = atomicAdd(io.count, 1); io.items[idx] = make_int2(env, episode + BANK_DEPTH); }
@@ -1044,6 +1045,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
     }
 #undef ST
 #undef STI
+#undef LAT
 #undef EB
     if (refill) group_sync();                         // next item reuses the per-environment LDS block
     }   // item loop
