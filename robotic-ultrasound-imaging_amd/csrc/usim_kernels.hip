@@ -383,9 +383,21 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
     if (!reset_only) {
         if (flags & LF_RANDOM_ACT) {
             uint32_t gid = (uint32_t)(C.env_offset + ei);
-            u4 r1 = philox(gid, (uint32_t)rstep, (uint32_t)((unsigned long long)rstep >> 32), 1u, C.key0, C.key1);
-            u4 r2 = philox(gid, (uint32_t)rstep, (uint32_t)((unsigned long long)rstep >> 32), 2u, C.key0, C.key1);
-            uint32_t rr[8] = {r1.a, r1.b, r1.c, r1.d, r2.a, r2.b, r2.c, r2.d};
+            uint32_t rr[8];
+            if constexpr (G == 16) {
+                // the two counter blocks are evaluated side by side by the even and odd lanes of the group, then shared
+                // (not for G = 8, where the extra live values push the kernel into scratch)
+                u4 r = philox(gid, (uint32_t)rstep, (uint32_t)((unsigned long long)rstep >> 32), 1u + (uint32_t)(gl & 1), C.key0, C.key1);
+                const float ra = __uint_as_float(r.a), rb = __uint_as_float(r.b), rc = __uint_as_float(r.c), rd = __uint_as_float(r.d);
+                rr[0] = __float_as_uint(group_bcast<G>(ra, 0)); rr[1] = __float_as_uint(group_bcast<G>(rb, 0));
+                rr[2] = __float_as_uint(group_bcast<G>(rc, 0)); rr[3] = __float_as_uint(group_bcast<G>(rd, 0));
+                rr[4] = __float_as_uint(group_bcast<G>(ra, 1)); rr[5] = __float_as_uint(group_bcast<G>(rb, 1));
+                rr[6] = __float_as_uint(group_bcast<G>(rc, 1)); rr[7] = 0u;
+            } else {
+                u4 r1 = philox(gid, (uint32_t)rstep, (uint32_t)((unsigned long long)rstep >> 32), 1u, C.key0, C.key1);
+                u4 r2 = philox(gid, (uint32_t)rstep, (uint32_t)((unsigned long long)rstep >> 32), 2u, C.key0, C.key1);
+                rr[0] = r1.a; rr[1] = r1.b; rr[2] = r1.c; rr[3] = r1.d; rr[4] = r2.a; rr[5] = r2.b; rr[6] = r2.c; rr[7] = r2.d;
+            }
 #pragma unroll
             for (int a = 0; a < 7; ++a) {
                 float u = u01(rr[a]);
@@ -681,6 +693,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                     //      coupling g, reference acceleration, regulariser, force; Km[c] = Linv[e_own][e_c] / m ----
                     const bool own = gl < nc;
                     float w[3][6], Liw[3][6], g[3], aref[3], invD[3], Rd[3], f[3] = {0.f, 0.f, 0.f}, ae = 0.f, Km[MAXC];
+                    float Bc[3] = {0.f, 0.f, 0.f};        // off-diagonal Delassus entries of the contact's own rows: (t1,n), (t2,n), (t2,t1)
 #pragma unroll
                     for (int c = 0; c < MAXC; ++c) Km[c] = 0.f;
 #pragma unroll
@@ -730,10 +743,18 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                             Rd[d] = (d == 0) ? Rn : Rn * (1.0f / IMPRATIO);
                             invD[d] = rcp_(Aii + Rd[d]);
                         }
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) {
+                            const int d1 = (p == 0) ? 1 : 2, d0 = (p == 2) ? 1 : 0;
+                            float b = g[d1] * g[d0] * linv_ee;
+#pragma unroll
+                            for (int a = 0; a < 6; ++a) b = fmaf(w[d1][a], Liw[d0][a], b);
+                            Bc[p] = b;
+                        }
                     }
                     TSTAMP(9);
                     // ---- projected Gauss-Seidel on the dual over the contact rows (fixed sweeps, cold start).  Contacts are
-                    //      visited in ascending order; the owner lane updates its three rows and the cone projection, then
+                    //      visited in ascending order; the owner lane relaxes its three rows and projects on the cone, then
                     //      the new site acceleration and the element impulse are broadcast to the group through DPP ----
                     for (int it = 0; it < C.pgs_iters; ++it) {
 #pragma unroll
@@ -741,39 +762,33 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                             if (k < ncmax) {
                                 float Gk = 0.f;
                                 if (gl == k && own) {
+                                    // The three rows of a contact are relaxed in order (normal, t1, t2), each seeing the updates of the rows
+                                    // before it.  All three residuals are formed from the state at the start of the visit (independent dot
+                                    // products), the earlier rows' updates enter through the 3 x 3 Delassus block Bc of the contact, and the
+                                    // site acceleration / element impulse are updated once, after the cone projection.
+                                    float c[3];
 #pragma unroll
                                     for (int d = 0; d < 3; ++d) {
-                                        // three independent partial sums keep the dependent chain short (one wave per SIMD)
                                         float r0 = fmaf(Rd[d], f[d], fmaf(g[d], ae, -aref[d]));
                                         // even / odd split: the packed-fp32 pairs (alpha[0],alpha[1]) ... match the pairs of the update below
                                         float r1 = fmaf(w[d][4], alpha[4], fmaf(w[d][2], alpha[2], w[d][0] * alpha[0]));
                                         float r2 = fmaf(w[d][5], alpha[5], fmaf(w[d][3], alpha[3], w[d][1] * alpha[1]));
-                                        float res = r0 + (r1 + r2);
-                                        float fn = f[d] - res * invD[d];
-                                        if (d == 0) fn = fmaxf(fn, 0.f);
-                                        float df = fn - f[d];
-                                        f[d] = fn;
-#pragma unroll
-                                        for (int a = 0; a < 6; ++a) alpha[a] = fmaf(Liw[d][a], df, alpha[a]);
-                                        float gd = g[d] * df;
-                                        ae = fmaf(Km[k], gd, ae);
-                                        Gk += gd;
+                                        c[d] = r0 + (r1 + r2);
                                     }
+                                    const float f0n = fmaxf(fmaf(-c[0], invD[0], f[0]), 0.f), df0 = f0n - f[0];
+                                    const float df1u = -fmaf(Bc[0], df0, c[1]) * invD[1];
+                                    const float df2u = -fmaf(Bc[2], df1u, fmaf(Bc[1], df0, c[2])) * invD[2];
+                                    float t1 = f[1] + df1u, t2 = f[2] + df2u;
                                     // elliptic cone: |f_t| <= mu f_n
-                                    float ft2 = f[1] * f[1] + f[2] * f[2], lim = mu * f[0];
-                                    if (ft2 > lim * lim) {
-                                        float sc = lim * rsq_(ft2);
+                                    const float ft2 = fmaf(t1, t1, t2 * t2), lim = mu * f0n;
+                                    const float sc = (ft2 > lim * lim) ? lim * rsq_(ft2) : 1.0f;
+                                    t1 *= sc; t2 *= sc;
+                                    const float df1 = t1 - f[1], df2 = t2 - f[2];
+                                    f[0] = f0n; f[1] = t1; f[2] = t2;
 #pragma unroll
-                                        for (int d = 1; d < 3; ++d) {
-                                            float df = f[d] * sc - f[d];
-                                            f[d] += df;
-#pragma unroll
-                                            for (int a = 0; a < 6; ++a) alpha[a] = fmaf(Liw[d][a], df, alpha[a]);
-                                            float gd = g[d] * df;
-                                            ae = fmaf(Km[k], gd, ae);
-                                            Gk += gd;
-                                        }
-                                    }
+                                    for (int a = 0; a < 6; ++a) alpha[a] = fmaf(Liw[2][a], df2, fmaf(Liw[1][a], df1, fmaf(Liw[0][a], df0, alpha[a])));
+                                    Gk = fmaf(g[2], df2, fmaf(g[1], df1, g[0] * df0));
+                                    ae = fmaf(Km[k], Gk, ae);
                                 }
 #pragma unroll
                                 for (int a = 0; a < 6; ++a) alpha[a] = group_bcast<G>(alpha[a], k);
