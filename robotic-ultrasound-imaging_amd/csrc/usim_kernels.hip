@@ -821,20 +821,33 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                 }
                 TSTAMP(11);
                 // ---- element accelerations a = a~ + Linv[:, e_c] gf_c, semi-implicit Euler, write back ----
+                {
+                    float acc_e[NE];
 #pragma unroll
-                for (int i = 0; i < NE; ++i) {
-                    const int e = gl + i * G;
-                    if (e >= N_TOP) continue;
-                    float sdn = 0.f, sn = 0.f;
+                    for (int i = 0; i < NE; ++i) { const int e = gl + i * G; acc_e[i] = (pass == 0 && e < N_TOP) ? EB(GE_A + e) : 0.f; }
                     if (pass == 0) {
-                        float a = EB(GE_A + e);
 #pragma unroll
-                        for (int k = 0; k < MAXC; ++k)          // slots beyond this environment's count carry gf = 0 and element 0
-                            if (k < ncmax) a = fmaf(lds[TB_LINV + e * LROW + cel[k]], gf[k], a);
-                        sdn = EB(GE_SD + e) + dt * a;
-                        sn = EB(GE_S + e) + dt * sdn;
+                        for (int k = 0; k < MAXC; ++k) {     // contact outer (one wave-uniform test per slot), elements inner; slots beyond this
+                            if (k < ncmax) {                 // environment's count carry gf = 0 and element 0
+#pragma unroll
+                                for (int i = 0; i < NE; ++i) {
+                                    const int e = (gl + i * G < N_TOP) ? gl + i * G : N_TOP - 1;
+                                    acc_e[i] = fmaf(lds[TB_LINV + e * LROW + cel[k]], gf[k], acc_e[i]);
+                                }
+                            }
+                        }
                     }
-                    if (valid && (pass == 0 || !refill)) { LAT(LAT_SD + e) = sdn; LAT(LAT_S + e) = sn; }
+#pragma unroll
+                    for (int i = 0; i < NE; ++i) {
+                        const int e = gl + i * G;
+                        if (e >= N_TOP) continue;
+                        float sdn = 0.f, sn = 0.f;
+                        if (pass == 0) {
+                            sdn = EB(GE_SD + e) + dt * acc_e[i];
+                            sn = EB(GE_S + e) + dt * sdn;
+                        }
+                        if (valid && (pass == 0 || !refill)) { LAT(LAT_SD + e) = sdn; LAT(LAT_S + e) = sn; }
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < MAXC; ++k) R.con_shell[k] = (k < nc) ? tb_shell[cel[k]] : -1;
