@@ -689,16 +689,15 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                         alpha[a] = s; vs[a] = u;
                     }
                     TSTAMP(8);
-                    // ---- contact k lives in the registers of lane k of its group: row directions w, Lambda^-1 w, element
-                    //      coupling g, reference acceleration, regulariser, force; Km[c] = Linv[e_own][e_c] / m ----
+                    // ---- contact k lives in the registers of lane k of its group.  Set-up: row directions w, Lambda^-1 w, element
+                    //      coupling g, reference acceleration, regulariser; Km[c] = Linv[e_own][e_c] / m ----
                     const bool own = gl < nc;
-                    float w[3][6], Liw[3][6], g[3], aref[3], invD[3], Rd[3], f[3] = {0.f, 0.f, 0.f}, ae = 0.f, Km[MAXC];
-                    float Bc[3] = {0.f, 0.f, 0.f};        // off-diagonal Delassus entries of the contact's own rows: (t1,n), (t2,n), (t2,t1)
+                    float w[3][6], Liw[3][6], g[3], invD[3], Rd[3], f[3] = {0.f, 0.f, 0.f}, cres[3] = {0.f, 0.f, 0.f}, Km[MAXC];
 #pragma unroll
                     for (int c = 0; c < MAXC; ++c) Km[c] = 0.f;
 #pragma unroll
                     for (int d = 0; d < 3; ++d) {
-                        g[d] = 0.f; aref[d] = 0.f; invD[d] = 0.f; Rd[d] = 0.f;
+                        g[d] = 0.f; invD[d] = 0.f; Rd[d] = 0.f;
 #pragma unroll
                         for (int a = 0; a < 6; ++a) { w[d][a] = 0.f; Liw[d][a] = 0.f; }
                     }
@@ -720,80 +719,86 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                         float Rn = (1.f - dimp) * rcp_(dimp) * M.invw;
 #pragma unroll
                         for (int c = 0; c < MAXC; ++c) if (c < nc) Km[c] = lds[TB_LINV + e * LROW + cel[c]] * (1.0f / ELEM_MASS);
-                        float linv_ee = lds[TB_LINV + e * LROW + e] * (1.0f / ELEM_MASS);
-                        ae = EB(GE_A + e);
+                        const float ae0 = EB(GE_A + e);
 #pragma unroll
                         for (int d = 0; d < 3; ++d) {
                             f3 dir = (d == 0) ? nn : (d == 1 ? t1 : t2);
                             f3 rx = cross(rr, dir);
                             w[d][0] = dir.x; w[d][1] = dir.y; w[d][2] = dir.z; w[d][3] = rx.x; w[d][4] = rx.y; w[d][5] = rx.z;
                             g[d] = -dot(dir, ax);
-                            float vrel = g[d] * sde - dir.z * vz;
-                            float Aii = g[d] * g[d] * linv_ee;
+                            float vrel = g[d] * sde - dir.z * vz, wa = 0.f;
 #pragma unroll
                             for (int a = 0; a < 6; ++a) {
                                 float s = 0.f;
 #pragma unroll
                                 for (int bb = 0; bb < 6; ++bb) s = fmaf((a >= bb) ? Li[PK(a, bb)] : Li[PK(bb, a)], w[d][bb], s);
                                 Liw[d][a] = s;
-                                Aii = fmaf(w[d][a], s, Aii);
                                 vrel = fmaf(w[d][a], vs[a], vrel);
+                                wa = fmaf(w[d][a], alpha[a], wa);
                             }
-                            aref[d] = -bcon * vrel - (d == 0 ? kk * dist : 0.f);
+                            const float aref = -bcon * vrel - (d == 0 ? kk * dist : 0.f);
                             Rd[d] = (d == 0) ? Rn : Rn * (1.0f / IMPRATIO);
-                            invD[d] = rcp_(Aii + Rd[d]);
-                        }
-#pragma unroll
-                        for (int p = 0; p < 3; ++p) {
-                            const int d1 = (p == 0) ? 1 : 2, d0 = (p == 2) ? 1 : 0;
-                            float b = g[d1] * g[d0] * linv_ee;
-#pragma unroll
-                            for (int a = 0; a < 6; ++a) b = fmaf(w[d1][a], Liw[d0][a], b);
-                            Bc[p] = b;
+                            cres[d] = fmaf(g[d], ae0, wa) - aref;             // residual of row d at zero force
                         }
                     }
                     TSTAMP(9);
-                    // ---- projected Gauss-Seidel on the dual over the contact rows (fixed sweeps, cold start).  Contacts are
-                    //      visited in ascending order; the owner lane relaxes its three rows and projects on the cone, then
-                    //      the new site acceleration and the element impulse are broadcast to the group through DPP ----
+                    // ---- Delassus blocks: B[k][d][d'] = d(residual of row d of this lane's contact) / d(force on row d' of contact k)
+                    //      = w_d . Lambda^-1 w^k_d' + g_d Km[k] g^k_d' (+ the regulariser on the diagonal of the lane's own block).  Lane k
+                    //      shares Lambda^-1 w^k and g^k through DPP once; the sweeps below then need three broadcasts per visit. ----
+                    float B[MAXC][3][3];
+#pragma unroll
+                    for (int k = 0; k < MAXC; ++k) {
+#pragma unroll
+                        for (int d = 0; d < 3; ++d)
+#pragma unroll
+                            for (int dd = 0; dd < 3; ++dd) B[k][d][dd] = 0.f;
+                        if (k < ncmax) {
+                            float gk[3];
+#pragma unroll
+                            for (int dd = 0; dd < 3; ++dd) gk[dd] = group_bcast<G>(g[dd], k) * Km[k];
+#pragma unroll
+                            for (int dd = 0; dd < 3; ++dd) {
+                                float Lk[6];
+#pragma unroll
+                                for (int a = 0; a < 6; ++a) Lk[a] = group_bcast<G>(Liw[dd][a], k);
+#pragma unroll
+                                for (int d = 0; d < 3; ++d) {
+                                    float r1 = fmaf(w[d][4], Lk[4], fmaf(w[d][2], Lk[2], w[d][0] * Lk[0]));
+                                    float r2 = fmaf(w[d][5], Lk[5], fmaf(w[d][3], Lk[3], w[d][1] * Lk[1]));
+                                    B[k][d][dd] = fmaf(g[d], gk[dd], r1 + r2);
+                                }
+                            }
+                            if (gl == k) {
+#pragma unroll
+                                for (int d = 0; d < 3; ++d) { B[k][d][d] += Rd[d]; invD[d] = rcp_(B[k][d][d]); }
+                            }
+                        }
+                    }
+                    // ---- projected Gauss-Seidel on the dual over the contact rows (fixed sweeps, cold start).  Contacts are visited in
+                    //      ascending order.  The owner relaxes its three rows in order (normal, t1, t2; the earlier rows' updates enter
+                    //      through its own block), projects on the cone and shares the three force increments; every lane then moves its
+                    //      residuals by its block for that contact. ----
                     for (int it = 0; it < C.pgs_iters; ++it) {
 #pragma unroll
                         for (int k = 0; k < MAXC; ++k) {
                             if (k < ncmax) {
-                                float Gk = 0.f;
+                                float d0 = 0.f, d1 = 0.f, d2 = 0.f;
                                 if (gl == k && own) {
-                                    // The three rows of a contact are relaxed in order (normal, t1, t2), each seeing the updates of the rows
-                                    // before it.  All three residuals are formed from the state at the start of the visit (independent dot
-                                    // products), the earlier rows' updates enter through the 3 x 3 Delassus block Bc of the contact, and the
-                                    // site acceleration / element impulse are updated once, after the cone projection.
-                                    float c[3];
-#pragma unroll
-                                    for (int d = 0; d < 3; ++d) {
-                                        float r0 = fmaf(Rd[d], f[d], fmaf(g[d], ae, -aref[d]));
-                                        // even / odd split: the packed-fp32 pairs (alpha[0],alpha[1]) ... match the pairs of the update below
-                                        float r1 = fmaf(w[d][4], alpha[4], fmaf(w[d][2], alpha[2], w[d][0] * alpha[0]));
-                                        float r2 = fmaf(w[d][5], alpha[5], fmaf(w[d][3], alpha[3], w[d][1] * alpha[1]));
-                                        c[d] = r0 + (r1 + r2);
-                                    }
-                                    const float f0n = fmaxf(fmaf(-c[0], invD[0], f[0]), 0.f), df0 = f0n - f[0];
-                                    const float df1u = -fmaf(Bc[0], df0, c[1]) * invD[1];
-                                    const float df2u = -fmaf(Bc[2], df1u, fmaf(Bc[1], df0, c[2])) * invD[2];
-                                    float t1 = f[1] + df1u, t2 = f[2] + df2u;
+                                    const float f0n = fmaxf(fmaf(-cres[0], invD[0], f[0]), 0.f);
+                                    d0 = f0n - f[0];
+                                    const float d1u = -fmaf(B[k][1][0], d0, cres[1]) * invD[1];
+                                    const float d2u = -fmaf(B[k][2][1], d1u, fmaf(B[k][2][0], d0, cres[2])) * invD[2];
+                                    float t1 = f[1] + d1u, t2 = f[2] + d2u;
                                     // elliptic cone: |f_t| <= mu f_n
                                     const float ft2 = fmaf(t1, t1, t2 * t2), lim = mu * f0n;
                                     const float sc = (ft2 > lim * lim) ? lim * rsq_(ft2) : 1.0f;
                                     t1 *= sc; t2 *= sc;
-                                    const float df1 = t1 - f[1], df2 = t2 - f[2];
+                                    d1 = t1 - f[1]; d2 = t2 - f[2];
                                     f[0] = f0n; f[1] = t1; f[2] = t2;
-#pragma unroll
-                                    for (int a = 0; a < 6; ++a) alpha[a] = fmaf(Liw[2][a], df2, fmaf(Liw[1][a], df1, fmaf(Liw[0][a], df0, alpha[a])));
-                                    Gk = fmaf(g[2], df2, fmaf(g[1], df1, g[0] * df0));
-                                    ae = fmaf(Km[k], Gk, ae);
                                 }
+                                d0 = group_bcast<G>(d0, k); d1 = group_bcast<G>(d1, k); d2 = group_bcast<G>(d2, k);
 #pragma unroll
-                                for (int a = 0; a < 6; ++a) alpha[a] = group_bcast<G>(alpha[a], k);
-                                Gk = group_bcast<G>(Gk, k);
-                                if (own && gl != k) ae = fmaf(Km[k], Gk, ae);
+                                for (int d = 0; d < 3; ++d) cres[d] = fmaf(B[k][d][2], d2, fmaf(B[k][d][1], d1, fmaf(B[k][d][0], d0, cres[d])));
                             }
                         }
                     }
