@@ -768,7 +768,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                                     B[k][d][dd] = fmaf(g[d], gk[dd], r1 + r2);
                                 }
                             }
-                            if (gl == k) {
+                            if (gl == k && own) {            // lanes without a contact keep invD = 0: their solve below yields zeros
 #pragma unroll
                                 for (int d = 0; d < 3; ++d) { B[k][d][d] += Rd[d]; invD[d] = rcp_(B[k][d][d]); }
                             }
@@ -782,20 +782,19 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
 #pragma unroll
                         for (int k = 0; k < MAXC; ++k) {
                             if (k < ncmax) {
-                                float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-                                if (gl == k && own) {
-                                    const float f0n = fmaxf(fmaf(-cres[0], invD[0], f[0]), 0.f);
-                                    d0 = f0n - f[0];
-                                    const float d1u = -fmaf(B[k][1][0], d0, cres[1]) * invD[1];
-                                    const float d2u = -fmaf(B[k][2][1], d1u, fmaf(B[k][2][0], d0, cres[2])) * invD[2];
-                                    float t1 = f[1] + d1u, t2 = f[2] + d2u;
-                                    // elliptic cone: |f_t| <= mu f_n
-                                    const float ft2 = fmaf(t1, t1, t2 * t2), lim = mu * f0n;
-                                    const float sc = (ft2 > lim * lim) ? lim * rsq_(ft2) : 1.0f;
-                                    t1 *= sc; t2 *= sc;
-                                    d1 = t1 - f[1]; d2 = t2 - f[2];
-                                    f[0] = f0n; f[1] = t1; f[2] = t2;
-                                }
+                                // every lane runs the solve on its own rows (no divergence); only lane k's increments are shared and kept
+                                const float f0n = fmaxf(fmaf(-cres[0], invD[0], f[0]), 0.f);
+                                float d0 = f0n - f[0];
+                                const float d1u = -fmaf(B[k][1][0], d0, cres[1]) * invD[1];
+                                const float d2u = -fmaf(B[k][2][1], d1u, fmaf(B[k][2][0], d0, cres[2])) * invD[2];
+                                float t1 = f[1] + d1u, t2 = f[2] + d2u;
+                                // elliptic cone: |f_t| <= mu f_n
+                                const float ft2 = fmaf(t1, t1, t2 * t2), lim = mu * f0n;
+                                const float sc = (ft2 > lim * lim) ? lim * rsq_(ft2) : 1.0f;
+                                t1 *= sc; t2 *= sc;
+                                float d1 = t1 - f[1], d2 = t2 - f[2];
+                                const bool mine = gl == k;
+                                f[0] = mine ? f0n : f[0]; f[1] = mine ? t1 : f[1]; f[2] = mine ? t2 : f[2];
                                 d0 = group_bcast<G>(d0, k); d1 = group_bcast<G>(d1, k); d2 = group_bcast<G>(d2, k);
 #pragma unroll
                                 for (int d = 0; d < 3; ++d) cres[d] = fmaf(B[k][d][2], d2, fmaf(B[k][d][1], d1, fmaf(B[k][d][0], d0, cres[d])));
