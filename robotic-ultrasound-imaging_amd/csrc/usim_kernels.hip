@@ -1069,11 +1069,16 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
     // ---------------- store state ----------------
     if (store && !(MODE == 1 && (refill || !need))) {
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) { ST(F_Q + i) = q[i]; ST(F_QD + i) = qd[i]; ST(F_Q0 + i) = q0[i]; }
-        ST(F_TS) = ts.x; ST(F_TS + 1) = ts.y; ST(F_TS + 2) = ts.z; ST(F_TE) = te.x; ST(F_TE + 1) = te.y; ST(F_TE + 2) = te.z;
-        ST(F_U0) = u0; ST(F_VBAR) = vbar; ST(F_FZBAR) = fzbar; ST(F_FZPREV) = fzprev; ST(F_DFZ) = dfz;
-        ST(F_KST) = kst; ST(F_KDMP) = kdmp; ST(F_MU) = mu; ST(F_EPRET) = epret;
+        for (int i = 0; i < NJ; ++i) { ST(F_Q + i) = q[i]; ST(F_QD + i) = qd[i]; }
+        ST(F_VBAR) = vbar; ST(F_FZBAR) = fzbar; ST(F_FZPREV) = fzprev; ST(F_DFZ) = dfz; ST(F_EPRET) = epret;
         STI(F_T) = t; STI(F_TOUCH) = touched; STI(F_EPISODE) = episode; STI(F_STATUS) = status;
+        if (MODE == 1 || need) {
+            // per-episode constants change only when an episode starts
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) ST(F_Q0 + i) = q0[i];
+            ST(F_TS) = ts.x; ST(F_TS + 1) = ts.y; ST(F_TS + 2) = ts.z; ST(F_TE) = te.x; ST(F_TE + 1) = te.y; ST(F_TE + 2) = te.z;
+            ST(F_U0) = u0; ST(F_KST) = kst; ST(F_KDMP) = kdmp; ST(F_MU) = mu;
+        }
     }
 #undef ST
 #undef STI
