@@ -78,7 +78,7 @@ enum LaunchFlags : int { LF_AUTO_RESET = 1, LF_RANDOM_ACT = 4 };
 // reset bank: BANK_DEPTH ring slots per environment (slot = episode mod depth), each holding a ready-made initial state and
 // the reset observation of one future episode (a pure function of seed, global env id and episode index)
 enum BankField : int { BQ0 = 0, BTS = 7, BTE = 10, BU0 = 13, BKST = 14, BKDMP = 15, BMU = 16, BFZ = 17, BOBS = 18, BSTATUS = 37, BANK_WORDS = 38 };
-constexpr int BANK_DEPTH = 32;
+constexpr int BANK_DEPTH = 64;
 constexpr int BANK_ROWS = BANK_DEPTH * BANK_WORDS;
 
 }  // namespace usim
