@@ -14,12 +14,15 @@
 //   soft torso   G = 8 / 16 : 16 environments per workgroup (4096 envs -> 256 workgroups, one per CU, G/4 waves
 //                each).  All lanes of a group carry the same 7-DoF arm state (the arm mathematics is replicated, those
 //                lanes would otherwise idle) and split the 99-element lattice, the collision tests and the contacts:
-//                  - the lattice inverse (99 x 100 fp32) and the element tables are workgroup-resident in LDS and read
-//                    as 16-byte row chunks; per-environment scratch is a 548-word LDS block (548 mod 64 = 36 puts the
-//                    16-byte windows of the 16 environments on disjoint bank groups);
+//                  - the lattice inverse (99 x 100 fp32) and the element tables are workgroup-resident in LDS; per-environment
+//                    scratch is a 548-word LDS block (548 mod 64 = 36 puts the 16-byte windows of the 16 environments on
+//                    disjoint bank groups);
+//                  - the lattice right-hand side is a 5-point stencil on a zero-bordered grid, the lattice solve
+//                    A~ = Linv X (X = the right-hand sides of the wave's environments) runs on the matrix cores
+//                    (v_mfma_f32_4x4x1, step kernel) -- the one dense contraction of the path;
 //                  - contacts keep ascending shell-id order through a wave ballot;
-//                  - contact k lives in the registers of lane k; the Gauss-Seidel sweep visits contacts in order and
-//                    broadcasts the updated site acceleration with DPP row_newbcast (no LDS round trip per row).
+//                  - contact k lives in the registers of lane k; the dual problem is solved on 3 x 3 Delassus blocks held
+//                    per lane, a Gauss-Seidel visit broadcasts three force increments with DPP row_newbcast.
 // Per-environment state is read and written once per step as rows of the SoA state block in HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
