@@ -189,7 +189,6 @@ static int build_model(usim_handle* h) {
     std::vector<float> tb(TB_WORDS, 0.f);
     for (int i = 0; i < N_TOP; ++i) for (int j = 0; j < N_TOP; ++j) tb[TB_LINV + (size_t)i * LROW + j] = (float)Li[(size_t)i * N_TOP + j];
     for (int i = 0; i < N_TOP * 3; ++i) { tb[TB_POS + i] = elpos[i]; tb[TB_AXIS + i] = elaxis[i]; }
-    std::memcpy(&tb[TB_NBR], nbr.data(), nbr.size() * sizeof(int));
     std::memcpy(&tb[TB_SHELL], shell.data(), shell.size() * sizeof(int));
     HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(c_tables), tb.data(), tb.size() * sizeof(float)));
     return USIM_OK;

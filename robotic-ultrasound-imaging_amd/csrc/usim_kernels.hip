@@ -36,9 +36,8 @@ constexpr int LROW = 100;                             // row stride of the latti
 constexpr int TB_LINV = 0;                            // float [99][100]
 constexpr int TB_POS = N_TOP * LROW;                  // float [99][3] nominal surface point rel. torso centre (padded to 300)
 constexpr int TB_AXIS = TB_POS + 300;                 // float [99][3] slide axis
-constexpr int TB_NBR = TB_AXIS + 300;                 // int   [99][4] neighbour element, -1 pinned, -2 none (padded to 400)
-constexpr int TB_SHELL = TB_NBR + 400;                // int   [99]    shell id (contact-pair index convention)
-constexpr int TB_WORDS = TB_SHELL + 100;              // 11000 words
+constexpr int TB_SHELL = TB_AXIS + 300;               // int   [99]    shell id (contact-pair index convention)
+constexpr int TB_WORDS = TB_SHELL + 100;              // 10600 words (the lattice topology itself is implicit: 9 x 11 grid stencil)
 __constant__ __attribute__((aligned(16))) float c_tables[TB_WORDS];
 
 // per-environment LDS block (word offsets); GE_X must stay 16-byte aligned
@@ -110,7 +109,6 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                      const f3 Kx, const f3 Ksy, const f3 Ksz, unsigned long long* dbg) {
 #define LSTAMP(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = __builtin_readcyclecounter(); } while (0)
 #define EBF(off) lds[TB_WORDS + eb * GE_STRIDE + (off)]
-    const int* tb_nbr = reinterpret_cast<const int*>(lds + TB_NBR);
     float dz, vz, az;
     torso_motion(C, tsim, dz, vz, az);
                                     // ---- stage s, sdot and the spring-damper potential u = k_t s + b_t sdot: lane gl of the group owns elements
