@@ -50,9 +50,9 @@ constexpr int GE_U_WORDS = 144;                       // (LAT_NA + 2) * (LAT_NC 
 constexpr int CG_WORDS = 8;                           // contact record: n3, r3, element, distance
 constexpr int GE_CG = 400;                            // contact records 8 x 8
 constexpr int GE_WS = 464;                            // per-contact wrench + element impulse 8 x 8 (before that: candidate records 8..15)
-constexpr int MAXCAND = 16;                           // penetrating elements recorded before the MAXC deepest are kept
+constexpr int MAXCAND = 16;                           // penetrating elements recorded before the MAXC deepest are kept (+ one spare record for misses)
 constexpr int GE_STRIDE = 548;                        // 548 mod 64 = 36: disjoint 16-byte bank windows for 16 environments
-static_assert(GE_WS + MAXC * 8 <= GE_STRIDE && GE_CG + MAXCAND * CG_WORDS <= GE_STRIDE && GE_U + GE_U_WORDS <= GE_STRIDE, "per-environment LDS block overflow");
+static_assert(GE_WS + MAXC * 8 <= GE_STRIDE && GE_CG + (MAXCAND + 1) * CG_WORDS <= GE_STRIDE && GE_U + GE_U_WORDS <= GE_STRIDE, "per-environment LDS block overflow");
 static_assert((LAT_NA + 2) * (LAT_NC + 2) <= GE_U_WORDS && LAT_NA * LAT_NC == N_TOP, "padded lattice grid");
 
 template <int G> struct GroupGeom {
@@ -151,14 +151,46 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                     if (gl == 0) EBF(GE_X + N_TOP) = 0.f;          // pad word read by the 16-byte row chunks
                     group_sync();
                     LSTAMP(5);
+                                    // ---- collision round i: probe capsule vs the cap spheres of elements i G .. i G + G - 1 (one per lane); the wave
+                    //      ballot gives every hit its slot so that the contact list stays sorted by ascending shell id.  Straight-line code
+                    //      (a miss writes its record to a spare slot), so that the rounds can be scheduled between the matrix instructions
+                    //      of the lattice solve ----
+                    f3 cc = Kx - Ksz * C.probe_r;                       // capsule centre one radius behind the tip
+                    f3 p1 = cc - Ksy * C.probe_hl, d1 = Ksy * (2.f * C.probe_hl);
+                    const float inv_dd = rcp_(dot(d1, d1));
+                    int nc = 0;
+                    auto collide_round = [&](const int i) {
+                        const int eraw = i * G + gl, e = eraw < N_TOP ? eraw : N_TOP - 1;
+                        const f3 ax = mk(lds[TB_AXIS + 3 * e], lds[TB_AXIS + 3 * e + 1], lds[TB_AXIS + 3 * e + 2]);
+                        const float se = EBF(GE_S + e);
+                        // element collision geometry = the cap sphere (centre `tip`, radius ELEM_R); DESIGN.md section 2
+                        const f3 tip = mk(M.torso[0] + lds[TB_POS + 3 * e], M.torso[1] + lds[TB_POS + 3 * e + 1], M.torso[2] + lds[TB_POS + 3 * e + 2] + dz) + ax * (se - ELEM_R);
+                        const f3 c1 = madd(p1, d1, clampf(dot(d1, tip - p1) * inv_dd, 0.f, 1.f));      // closest point of the probe segment
+                        const f3 dd = c1 - tip;
+                        const float len = sqrt_(dot(dd, dd));
+                        const float dist = len - (C.probe_r + ELEM_R);
+                        const bool hit = (eraw < N_TOP) && (dist < 0.f);
+                        const f3 nn = (len > 1e-9f) ? dd * rcp_(len) : mk(0, 0, 1);
+                        const f3 rr = tip + nn * (ELEM_R + 0.5f * dist) - Kx;
+                        const unsigned long long bal = __ballot(hit);
+                        const unsigned gm = (unsigned)(bal >> gbase) & ((1u << G) - 1u);
+                        const int slot = nc + __popc(gm & ((1u << gl) - 1u));
+                        const int sl = (hit && slot < MAXCAND) ? slot : MAXCAND;          // MAXCAND = the spare record
+                        float4* rec = reinterpret_cast<float4*>(&EBF(GE_CG + sl * CG_WORDS));
+                        rec[0] = make_float4(nn.x, nn.y, nn.z, rr.x);
+                        rec[1] = make_float4(rr.y, rr.z, __int_as_float(e), dist);
+                        nc += __popc(gm);
+                    };
                                     // ---- a~ = Linv * rhs ----
                     if constexpr (MM) {
                         // Matrix-core form (every lane of the wave is active here): the wave's environments are the columns of one dense
                         // product A~[99 x EPW] = Linv[99 x 100] X[100 x EPW], issued as v_mfma_f32_4x4x1 (16 blocks of 4 rows x 4 columns
                         // per instruction).  Lane l feeds Linv row l (and row 64 + l) as the A operand and the rhs of environment l % 4 as
                         // the B operand; it receives rows 4 (l / 4) .. + 3 of that environment (layout: tools/probe/mfma_4x4x1_layout.hip).
+                        // The k loop is unrolled in NE pieces with one collision round after each: the rounds do not depend on the
+                        // product and fill the issue slots the matrix pipeline leaves free.
                         typedef float v4f __attribute__((ext_vector_type(4)));
-                        constexpr int EPW = 64 / G, NSET = (EPW >= 4 && EPW <= 8) ? EPW / 4 : 1;
+                        constexpr int EPW = 64 / G, NSET = (EPW >= 4 && EPW <= 8) ? EPW / 4 : 1, NCH = LROW / 4;
                         const int lane = gbase + gl, ebw = eb - gbase / G, blk = lane >> 2;
                         const int r1 = (64 + lane < N_TOP) ? 64 + lane : N_TOP - 1;
                         const float4* la0 = reinterpret_cast<const float4*>(&lds[TB_LINV + lane * LROW]);
@@ -170,21 +202,25 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                             xb[u] = reinterpret_cast<const float4*>(&lds[TB_WORDS + (ebw + 4 * u + (lane & 3)) * GE_STRIDE + GE_X]);
                             acc0[u] = (v4f){0.f, 0.f, 0.f, 0.f}; acc1[u] = (v4f){0.f, 0.f, 0.f, 0.f};
                         }
-    #pragma unroll 5
-                        for (int c = 0; c < LROW / 4; ++c) {
-                            const float4 a0 = la0[c], a1 = la1[c];
     #pragma unroll
-                            for (int u = 0; u < NSET; ++u) {
-                                const float4 b = xb[u][c];
-                                acc0[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.x, b.x, acc0[u], 0, 0, 0);
-                                acc1[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.x, b.x, acc1[u], 0, 0, 0);
-                                acc0[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.y, b.y, acc0[u], 0, 0, 0);
-                                acc1[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.y, b.y, acc1[u], 0, 0, 0);
-                                acc0[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.z, b.z, acc0[u], 0, 0, 0);
-                                acc1[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.z, b.z, acc1[u], 0, 0, 0);
-                                acc0[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.w, b.w, acc0[u], 0, 0, 0);
-                                acc1[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.w, b.w, acc1[u], 0, 0, 0);
+                        for (int i = 0; i < NE; ++i) {
+    #pragma unroll
+                            for (int c = (i * NCH) / NE; c < ((i + 1) * NCH) / NE; ++c) {
+                                const float4 a0 = la0[c], a1 = la1[c];
+    #pragma unroll
+                                for (int u = 0; u < NSET; ++u) {
+                                    const float4 b = xb[u][c];
+                                    acc0[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.x, b.x, acc0[u], 0, 0, 0);
+                                    acc1[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.x, b.x, acc1[u], 0, 0, 0);
+                                    acc0[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.y, b.y, acc0[u], 0, 0, 0);
+                                    acc1[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.y, b.y, acc1[u], 0, 0, 0);
+                                    acc0[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.z, b.z, acc0[u], 0, 0, 0);
+                                    acc1[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.z, b.z, acc1[u], 0, 0, 0);
+                                    acc0[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.w, b.w, acc0[u], 0, 0, 0);
+                                    acc1[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.w, b.w, acc1[u], 0, 0, 0);
+                                }
                             }
+                            collide_round(i);
                         }
     #pragma unroll
                         for (int u = 0; u < NSET; ++u) {
@@ -225,44 +261,9 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                                 if (i0 + j < NE && r < N_TOP) EBF(GE_A + r) = acc[j] + bcc[j];
                             }
                         }
-                    }
-                    LSTAMP(6);
-                                    // ---- collision: probe capsule vs the 99 cap spheres; the G lanes test G consecutive elements at a time, the
-                    //      wave ballot gives every hit its slot so that the contact list stays sorted by ascending shell id ----
-                    f3 cc = Kx - Ksz * C.probe_r;                       // capsule centre one radius behind the tip
-                    f3 p1 = cc - Ksy * C.probe_hl, d1 = Ksy * (2.f * C.probe_hl);
-                    const float inv_dd = rcp_(dot(d1, d1));
-                    int nc = 0;
+                        LSTAMP(6);
     #pragma unroll
-                    for (int i = 0; i < NE; ++i) {
-                        const int e = i * G + gl;
-                        bool hit = false;
-                        f3 nn = mk(0, 0, 1), rr = mk(0, 0, 0); float dist = 0.f;
-                        if (e < N_TOP) {
-                            f3 ax = mk(lds[TB_AXIS + 3 * e], lds[TB_AXIS + 3 * e + 1], lds[TB_AXIS + 3 * e + 2]);
-                            float se = EBF(GE_S + e);
-                            // element collision geometry = the cap sphere (centre `tip`, radius ELEM_R); DESIGN.md section 2
-                            f3 tip = mk(M.torso[0] + lds[TB_POS + 3 * e], M.torso[1] + lds[TB_POS + 3 * e + 1], M.torso[2] + lds[TB_POS + 3 * e + 2] + dz) + ax * (se - ELEM_R);
-                            f3 c1 = madd(p1, d1, clampf(dot(d1, tip - p1) * inv_dd, 0.f, 1.f));      // closest point of the probe segment
-                            f3 dd = c1 - tip;
-                            float len = sqrt_(dot(dd, dd));
-                            dist = len - (C.probe_r + ELEM_R);
-                            hit = dist < 0.f;
-                            if (hit) {
-                                nn = (len > 1e-9f) ? dd * rcp_(len) : mk(0, 0, 1);
-                                rr = tip + nn * (ELEM_R + 0.5f * dist) - Kx;
-                            }
-                        }
-                        const unsigned long long bal = __ballot(hit);
-                        const unsigned gm = (unsigned)(bal >> gbase) & ((1u << G) - 1u);
-                        const int slot = nc + __popc(gm & ((1u << gl) - 1u));
-                        if (hit && slot < MAXCAND) {
-                            const int b = GE_CG + slot * CG_WORDS;
-                            EBF(b + 0) = nn.x; EBF(b + 1) = nn.y; EBF(b + 2) = nn.z;
-                            EBF(b + 3) = rr.x; EBF(b + 4) = rr.y; EBF(b + 5) = rr.z;
-                            EBF(b + 6) = __int_as_float(e); EBF(b + 7) = dist;
-                        }
-                        nc += __popc(gm);
+                        for (int i = 0; i < NE; ++i) collide_round(i);
                     }
                     if (nc > MAXC) {
                         // rare: more penetrating elements than contact slots.  Keep the MAXC deepest of the first MAXCAND candidates
