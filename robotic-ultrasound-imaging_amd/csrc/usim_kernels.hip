@@ -471,7 +471,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
 #pragma unroll
                 for (int i = 0; i < NJ; ++i) q[i] = INITQ[i];
                 for (int it = 0; it < C.ik_iters; ++it) {
-                    Kin K; fk(M, q, K);
+                    Kin K; fk<G == 1>(M, q, K);
                     f3 gx = mk(M.grot[0], M.grot[3], M.grot[6]), gy = mk(M.grot[1], M.grot[4], M.grot[7]), gz = mk(M.grot[2], M.grot[5], M.grot[8]);
                     f3 eo = (cross(K.sx, gx) + cross(K.sy, gy) + cross(K.sz, gz)) * 0.5f;
                     f3 ep = target - K.x;
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
         float obs[OBS_DIM];
         float pos_err_norm = 0.f, ori_err = 0.f;
         if (active) {
-            Kin K; fk(M, q, K);
+            Kin K; fk<G == 1>(M, q, K);
             Dyn D; dynamics(M, K, qd, D);
             // site Jacobian J = [Jv; Jw]
             float J[6][NJ];
@@ -1135,7 +1135,7 @@ __global__ void usim_invweight_kernel(const DevModel M, float* out) {
     float q[NJ], qd[NJ];
 #pragma unroll
     for (int i = 0; i < NJ; ++i) { q[i] = INITQ[i]; qd[i] = 0.f; }
-    Kin K; fk(M, q, K);
+    Kin K; fk<false>(M, q, K);
     Dyn D; dynamics(M, K, qd, D);
     float idm[NJ];
     chol_packed<NJ>(D.M, idm);
