@@ -655,6 +655,14 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
 #pragma unroll
                 for (int i = 0; i < NJ; ++i) tau[i] = 0.f;      // reset: sim.forward() with zero ctrl
             }
+            if (pass == 0 && store && io.log) {
+                // torque and action channels of the episode record leave the registers here instead of living to the end of the step
+                float* L = io.log + (size_t)ei * LOG_WIDTH;
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) L[33 + i] = tau[i];
+#pragma unroll
+                for (int a = 0; a < 7; ++a) L[46 + a] = act[a];
+            }
             TSTAMP(3);
             // ---------------- smooth acceleration ----------------
             float qs[NJ];
@@ -903,21 +911,24 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
             TSTAMP(13);
             // ---------------- integrate the arm: mj_Euler with implicit joint damping ----------------
             if (pass == 0) {
-                // (M + h D) x = M qacc: the factorisation of M + h D does not depend on the contact solve, so the scheduler can
-                // overlap it with the lattice/contact phases; only one triangular solve pair stays on the tail of the step
-                float rhs[NJ], Ld[28], idd[NJ];
+                // (M + h D) x = M qacc with D = d I, h d = 2e-5: two steps of x <- qacc - h d M^-1 x from x = qacc reuse the factor of M
+                // (contraction h d / lambda_min(M) < 4e-3 per step: remainder below 1e-7 relative) -- no second factorisation, and the
+                // mass matrix itself is dead before the contact phase
+                float rhs[NJ];
+                {
+                    const float hd = dt * JOINT_DAMP;
+                    float xk[NJ];
 #pragma unroll
-                for (int i = 0; i < NJ; ++i) {
-                    float sm = 0.f;
+                    for (int i = 0; i < NJ; ++i) xk[i] = qacc[i];
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) sm = fmaf((i >= j) ? D.M[PK(i, j)] : D.M[PK(j, i)], qacc[j], sm);
-                    rhs[i] = sm;
+                    for (int itx = 0; itx < 2; ++itx) {
+                        chol_solve<NJ>(Lm, idm, xk);
+#pragma unroll
+                        for (int i = 0; i < NJ; ++i) xk[i] = fmaf(-hd, xk[i], qacc[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NJ; ++i) rhs[i] = xk[i];
                 }
-#pragma unroll
-                for (int k = 0; k < 28; ++k) Ld[k] = D.M[k];
-#pragma unroll
-                for (int i = 0; i < NJ; ++i) Ld[PK(i, i)] += dt * JOINT_DAMP;
-                chol_packed<NJ>(Ld, idd); chol_solve<NJ>(Ld, idd, rhs);
 #pragma unroll
                 for (int i = 0; i < NJ; ++i) { qd[i] = fmaf(dt, rhs[i], qd[i]); q[i] = fmaf(dt, qd[i], q[i]); }
                 // hand velocity: Jacobian from before the integration, qvel from after (mj_step data semantics)
@@ -992,11 +1003,9 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                         L[19] = ori_err * 5.0f;                                                 // distance_quat (ori_err = 0.2 * distance)
                         L[20] = fz; L[21] = 5.0f; L[22] = fzbar; L[23] = dfz; L[24] = 0.f; L[25] = contact ? 1.f : 0.f;
 #pragma unroll
-                        for (int i = 0; i < NJ; ++i) { L[26 + i] = q[i]; L[33 + i] = tau[i]; }
+                        for (int i = 0; i < NJ; ++i) L[26 + i] = q[i];
                         L[40] = (float)(t - 1) * inv_h * 100.f;
                         L[41] = pos_rew; L[42] = ori_rew; L[43] = vel_rew; L[44] = force_rew; L[45] = dforce_rew;
-#pragma unroll
-                        for (int a = 0; a < 7; ++a) L[46 + a] = act[a];
                     }
                     if (R.overflow) status |= 1;
                     {
