@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--randomize", action="store_true", help="BASELINE configs[4]: per-env randomised stiffness/damping + probe friction")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--lanes-per-env", type=int, default=0, choices=[0, 8, 16], help="soft-torso kernel mapping (0 = automatic)")
     args = ap.parse_args()
 
     import torch
@@ -93,10 +94,19 @@ def main():
     dmod = import_module("robotic-ultrasound-imaging_amd.distributed")
     n = args.envs_per_gpu
     extra = {"friction_randomization": 1} if args.randomize else {}
+    with_gather = use_dist and not args.no_gather
+    if with_gather and args.workload == "soft" and args.lanes_per_env == 0:
+        # With 16 lanes per environment the step kernel fills every SIMD of the chip (1024 waves, whole register file each); the
+        # resident workgroups of the overlapped all-gather would then push part of every step into a second round (measured with a
+        # stand-in kernel: 29 -> 45-49 us/step, tools/gpu_interference.py).  8 lanes per environment leave half of the SIMDs to
+        # the collective: 31 us/step with or without it.
+        extra["lanes_per_env"] = 8
+    elif args.lanes_per_env:
+        extra["lanes_per_env"] = args.lanes_per_env
     env = usim.UltrasoundVecEnv(n, device=device, seed=3, env_offset=rank * n, torso=args.workload, **extra, **usim.default_robosuite_kwargs())
     T = max(1, min(args.block, args.steps))
     blocks = [env.alloc_block(T), env.alloc_block(T)]      # double-buffered: gather block b while simulating b^1
-    gather = dmod.RolloutGather(device=device) if (use_dist and not args.no_gather) else None
+    gather = dmod.RolloutGather(device=device) if with_gather else None
 
     env.reset_tensor()
     step = 0
@@ -165,7 +175,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD_NAME[args.workload], "envs_per_gpu": n, "global_envs": n * world,
                        "controller": "OSC_POSE impedance_mode=tracking", "rollout_block": T, "domain_randomisation": "stiffness+damping" + ("+friction" if args.randomize else ""),
-                       "parallelism": f"env-shard x{world}" + (" + RCCL all-gather of transition blocks" if gather is not None else "")},
+                       "parallelism": f"env-shard x{world}" + (" + RCCL all-gather of transition blocks" if gather is not None else ""),
+                       "lanes_per_env": int(extra.get("lanes_per_env", 0)) or ("auto" if args.workload == "soft" else 1)},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": "profiles/r01/traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch)" if traffic else None,
                          "algorithmic_bytes_per_launch": ALGO_BYTES[args.workload] * n, "algorithmic_bytes_per_env_step": ALGO_BYTES[args.workload],

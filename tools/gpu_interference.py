@@ -1,0 +1,28 @@
+"""How does the step kernel cope with a collective's resident workgroups?  A spinner kernel holds B workgroups busy on a side stream
+while K steps are timed on the main stream, for 16 and 8 lanes per environment (4096 envs).
+usage: python tools/gpu_interference.py"""
+import ctypes as C, importlib, sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import torch
+usim = importlib.import_module("robotic-ultrasound-imaging_amd")
+spin = C.CDLL(str(ROOT / "tools" / "probe" / "libspin.so"))
+spin.spin_launch.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+sink = torch.zeros(1, dtype=torch.int32, device="cuda")
+side = torch.cuda.Stream()
+K = 256
+for lpe in (16, 8):
+    env = usim.UltrasoundVecEnv(4096, torso="soft", lanes_per_env=lpe, **usim.default_robosuite_kwargs())
+    env.reset_tensor(); env.rollout_random(0, 128); torch.cuda.synchronize()
+    for blocks in (0, 4, 16, 32, 64):
+        torch.cuda.synchronize()
+        if blocks:
+            spin.spin_launch(blocks, 40000, C.c_void_p(side.cuda_stream), C.c_void_p(sink.data_ptr()))   # 40 ms, longer than the timed steps
+            time.sleep(0.002)
+        t0 = time.perf_counter()
+        env.rollout_random(1000, K); torch.cuda.current_stream().synchronize()
+        dt = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        print(f"lanes {lpe:2d}  spinner workgroups {blocks:3d}: {dt / K * 1e6:6.1f} us/step", flush=True)
+    env.close()

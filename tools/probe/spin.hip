@@ -1,0 +1,16 @@
+// Probe: a kernel that holds `blocks` workgroups (256 threads, a few registers) busy for `usec` microseconds -- a stand-in for the
+// resident workgroups of a collective running next to the step kernel (tools/gpu_interference.py).
+// hipcc --offload-arch=gfx950 -O2 -shared -fPIC -o tools/probe/libspin.so tools/probe/spin.hip
+#include <hip/hip_runtime.h>
+__global__ void spin_kernel(long long ticks, int* sink) {
+    asm volatile("v_mov_b32 v127, 0" ::: "v127");            // claim 128 VGPRs: the register footprint of a typical collective kernel
+    const long long t0 = wall_clock64();
+    int acc = 0;
+    while (wall_clock64() - t0 < ticks) acc += 1;
+    if (acc == -1) *sink = acc;
+}
+extern "C" int spin_launch(int blocks, int usec, void* stream, int* sink_dev) {
+    // wall_clock64 counts at 100 MHz
+    hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long long)usec * 100, sink_dev);
+    return (int)hipGetLastError();
+}
