@@ -27,6 +27,8 @@ DI float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 DI float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
 DI float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
 DI float rsq_(float x) { return __builtin_amdgcn_rsqf(x); }
+// exp for the reward terms (arguments in [-1e4, 0]): v_exp_f32 on x log2(e), relative error ~ |x| 2^-24
+DI float exp_(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 // symmetric 3x3 (xx,xy,xz,yy,yz,zz) times vector
 DI f3 symmul(const float* I, f3 v) {
     return mk(I[0] * v.x + I[1] * v.y + I[2] * v.z, I[1] * v.x + I[3] * v.y + I[4] * v.z, I[2] * v.x + I[4] * v.y + I[5] * v.z);

@@ -964,16 +964,16 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                     float pe0 = 90.f * (xw.x - tpw.x), pe1 = 90.f * (xw.y - tpw.y);
                     pe0 *= pe0; pe1 *= pe1;
                     pos_err_norm = sqrt_(pe0 * pe0 + pe1 * pe1);
-                    float pos_rew = 5.f * expf(-pos_err_norm);
+                    float pos_rew = 5.f * exp_(-pos_err_norm);
                     float qc[4] = {qe[3], qe[0], qe[1], qe[2]};
                     ori_err = 0.2f * distance_quat_goal(qc, M.ghat, M.geps);
-                    float ori_rew = expf(-ori_err);
+                    float ori_rew = exp_(-ori_err);
                     float ve = 45.f * (vbar - 0.04f); ve *= ve;
-                    float vel_rew = expf(-ve);
+                    float vel_rew = exp_(-ve);
                     float fe = 0.7f * (fzbar - 5.f); fe *= fe;
-                    float force_rew = contact ? 3.f * expf(-fe) : 0.f;
+                    float force_rew = contact ? 3.f * exp_(-fe) : 0.f;
                     float de = 0.01f * dfz; de *= de;
-                    float dforce_rew = contact ? 2.f * expf(-de) : 0.f;
+                    float dforce_rew = contact ? 2.f * exp_(-de) : 0.f;
                     float reward = pos_rew + ori_rew + vel_rew + force_rew + dforce_rew;
                     done = t >= C.horizon;
                     // ---------------- bookkeeping (ultrasound.py:528-546) ----------------
