@@ -911,23 +911,18 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
             TSTAMP(13);
             // ---------------- integrate the arm: mj_Euler with implicit joint damping ----------------
             if (pass == 0) {
-                // (M + h D) x = M qacc with D = d I, h d = 2e-5: two steps of x <- qacc - h d M^-1 x from x = qacc reuse the factor of M
-                // (contraction h d / lambda_min(M) < 4e-3 per step: remainder below 1e-7 relative) -- no second factorisation, and the
-                // mass matrix itself is dead before the contact phase
+                // (M + h D) x = M qacc with D = d I, h d = 2e-5: x = qacc - h d M^-1 x.  One step from x = qacc reuses the factor of M; the
+                // contraction is h d / lambda_min(M) = 2.8e-4 (lambda_min(M) = 0.071 kg m^2 over the workspace), so the remainder
+                // is 8e-8 relative -- fp32 rounding.  No second factorisation, and the mass matrix is dead before the contact phase.
                 float rhs[NJ];
                 {
                     const float hd = dt * JOINT_DAMP;
                     float xk[NJ];
 #pragma unroll
                     for (int i = 0; i < NJ; ++i) xk[i] = qacc[i];
+                    chol_solve<NJ>(Lm, idm, xk);
 #pragma unroll
-                    for (int itx = 0; itx < 2; ++itx) {
-                        chol_solve<NJ>(Lm, idm, xk);
-#pragma unroll
-                        for (int i = 0; i < NJ; ++i) xk[i] = fmaf(-hd, xk[i], qacc[i]);
-                    }
-#pragma unroll
-                    for (int i = 0; i < NJ; ++i) rhs[i] = xk[i];
+                    for (int i = 0; i < NJ; ++i) rhs[i] = fmaf(-hd, xk[i], qacc[i]);
                 }
 #pragma unroll
                 for (int i = 0; i < NJ; ++i) { qd[i] = fmaf(dt, rhs[i], qd[i]); q[i] = fmaf(dt, qd[i], q[i]); }
