@@ -125,12 +125,19 @@ def main():
 
     sync()
     t0 = time.perf_counter()
-    done_s, b, dev_ms = 0, 0, 0.0
+    done_s, b = 0, 0
+    # kernel-duration leg of the roofline: HIP events around every block of step launches, recorded on the launch stream (the
+    # simulator is launched on torch's current stream, so torch events are events of that stream); read after the timed region,
+    # the host never blocks inside it
+    evs = []
     while done_s < args.steps:                             # EXACTLY args.steps timed steps
         k = min(T, args.steps - done_s)
-        dev_ms += env.time_steps(step, k, blocks[b]) if gather is None else 0.0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        env.rollout_random(step, k, blocks[b])             # with the gather: simulate block b while block b^1 is in flight
+        e1.record()
+        evs.append((e0, e1))
         if gather is not None:
-            env.rollout_random(step, k, blocks[b])         # simulate block b while the gather of block b^1 is in flight
             gather.wait()                                  # block b^1 is gathered before the next iteration overwrites it
             gather.gather_async(blocks[b])
         step += k; done_s += k; b ^= 1
@@ -142,16 +149,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
-    # kernel-duration leg of the roofline: HIP events around the same launches on the launch stream (rank 0, N == 1 path)
-    if gather is not None:
-        kern_steps = min(2 * T, args.steps)
-        dev_ms, done_k = 0.0, 0
-        while done_k < kern_steps:                          # never more than T slices into a T-slice block
-            k = min(T, kern_steps - done_k)
-            dev_ms += env.time_steps(step + done_k, k, blocks[0]); done_k += k
-    else:
-        kern_steps = args.steps
+    dev_ms = sum(a.elapsed_time(b_) for a, b_ in evs)
+    kern_steps = args.steps
     avg_kernel_s = dev_ms * 1e-3 / kern_steps
     achieved_gbs = ALGO_BYTES[args.workload] * n / avg_kernel_s / 1e9
     valu_tflops = ALGO_FLOPS[args.workload] * n / avg_kernel_s / 1e12
