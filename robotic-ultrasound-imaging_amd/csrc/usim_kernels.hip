@@ -62,6 +62,8 @@ template <int G> struct GroupGeom {
     static constexpr int NT = 64 * WAVES;
     static constexpr int LDS_WORDS = TB_WORDS + EPB * GE_STRIDE;
 };
+// two workgroups of the 8-lane mapping share a CU at 8192 envs/GPU (2 waves each): both must fit the 160 KB of LDS
+static_assert(2 * GroupGeom<8>::LDS_WORDS * 4 <= 160 * 1024, "LDS block too large for two workgroups per CU");
 
 DI void group_sync() {
     // the lanes of a group exchange data through LDS inside one wave: order the LDS traffic, no s_barrier needed
