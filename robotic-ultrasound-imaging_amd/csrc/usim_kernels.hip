@@ -757,13 +757,9 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                     // ---- Delassus blocks: B[k][d][d'] = d(residual of row d of this lane's contact) / d(force on row d' of contact k)
                     //      = w_d . Lambda^-1 w^k_d' + g_d Km[k] g^k_d' (+ the regulariser on the diagonal of the lane's own block).  Lane k
                     //      shares Lambda^-1 w^k and g^k through DPP once; the sweeps below then need three broadcasts per visit. ----
-                    float B[MAXC][3][3];
+                    float B[MAXC][3][3];            // B[k] is written and read only under k < ncmax
 #pragma unroll
                     for (int k = 0; k < MAXC; ++k) {
-#pragma unroll
-                        for (int d = 0; d < 3; ++d)
-#pragma unroll
-                            for (int dd = 0; dd < 3; ++dd) B[k][d][dd] = 0.f;
                         if (k < ncmax) {
                             float gk[3];
 #pragma unroll
