@@ -228,3 +228,31 @@ def test_contact_slot_overflow_parity(usim, lanes):
         assert np.abs(obs_g.cpu().numpy()[alive, 12:19] - obs_o[alive, 12:19]).max() < 5e-5
     assert (con_o[:, 0] == 8).sum() > 10 and alive.sum() > n // 2
     env.close()
+
+
+def test_reset_bank_ring_wraps(usim):
+    """80 episodes per environment -- more than the 64 prepared episodes of the reset bank: the slots refilled by the bulk refill
+    launches (one per 64 steps) must hold exactly the episodes the oracle draws when it gets there"""
+    n, H, steps = 48, 5, 400
+    kw = usim.default_robosuite_kwargs(); kw["horizon"] = H; kw["early_termination"] = False
+    kw.update(deterministic_trajectory=False)
+    env = usim.UltrasoundVecEnv(n, device="cuda:0", seed=11, torso="soft", **kw)
+    ora = Oracle(n, precision="f64", torso="top", seed=11, horizon=H, early_termination=0, deterministic_trajectory=0)
+    og, oo = env.reset(), ora.reset()
+    assert np.allclose(og[:, 12:19], oo[:, 12:19], atol=2e-6)
+    ndone = 0
+    for k in range(steps):
+        a = ora.random_actions(k)
+        obs_o, rew_o, done_o, term_o, con_o = ora.step(a)
+        obs_g, rew_g, done_g, infos = env.step(a.astype(np.float32))
+        assert np.array_equal(done_g, done_o) and done_o.all() == ((k + 1) % H == 0)
+        ndone += int(done_o[0])
+        # reset observations of the freshly adopted episodes (pose channels) and terminal observations of the finished ones
+        assert np.abs(obs_g[:, 12:19] - obs_o[:, 12:19]).max() < 2e-5, k
+        if done_o[0]:
+            tg = np.stack([i["terminal_observation"] for i in infos])
+            assert np.abs(tg[:, 12:19] - term_o[:, 12:19]).max() < 2e-5, k
+    assert ndone == steps // H and ndone > 64
+    sg, so = env.get_state(), ora.get_state()
+    assert np.array_equal(sg["episode"], so["episode"]) and np.allclose(sg["traj_start"], so["traj_start"], atol=1e-6)
+    env.close()
