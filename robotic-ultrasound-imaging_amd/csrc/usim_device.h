@@ -31,6 +31,10 @@ enum Field : int {
                                     // per environment: env i owns words [i * LAT_ENV_WORDS, (i + 1) * LAT_ENV_WORDS) of the region
     F_TOTAL_TOP = 40 + 200
 };
+// index of scalar field f of environment i inside the scalar region (rows 0 .. F_NSCALAR-1 of the block).  With one environment per lane
+// (rigid torso) the region is field-major: a wave reads one contiguous row per field.  In the grouped kernels (soft torso) all lanes of a
+// group read the same environment, so the region is environment-major: ten 16-byte loads fetch the 40 words of an environment.
+__host__ __device__ inline size_t scalar_index(bool env_major, int f, size_t i, size_t npad) { return env_major ? i * F_NSCALAR + f : (size_t)f * npad + i; }
 // lattice region, environment-major (the 16 lanes of a group read 16 consecutive words): s[e] at LAT_S + e, sdot[e] at LAT_SD + e
 constexpr int LAT_ENV_WORDS = 200, LAT_S = 0, LAT_SD = 100;
 static_assert(F_TOTAL_TOP == F_LAT + LAT_ENV_WORDS && LAT_SD + N_TOP <= LAT_ENV_WORDS, "lattice region");
