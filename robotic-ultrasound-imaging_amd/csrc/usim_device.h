@@ -1,11 +1,11 @@
 // usim_device.h -- data layout shared by the HIP kernels (usim_kernels.hip) and the host side of the C ABI
 // (usim_api.hip).  gfx950 only.
 //
-// HBM layout: every per-environment scalar is a float32 (or int32 bit pattern) array
-// over environments, `field f of env i` at state[f * n_pad + i] -- struct-of-arrays with the environment as
-// the fastest index, so a wave64 touching one field of 64 consecutive environments reads one aligned 256-byte
-// row.  n_pad is n rounded up to the workgroup width.  The lattice state (s, sdot of the 99 elements) is the
-// exception: it is stored environment-major, because there the lanes of a wave walk the elements of one environment.
+// HBM layout: one float32 block per handle (ints as bit patterns), n_pad = n rounded up to the workgroup
+// width.  Rigid torso (one environment per lane): the 40 scalars are field-major, `field f of env i` at state[f * n_pad + i], so a
+// wave64 touching one field of 64 consecutive environments reads one aligned 256-byte row.  Soft torso (a group of lanes per
+// environment): scalars and lattice state are environment-major (scalar_index(), LAT_*), because all lanes of a group read the same
+// environment.  The reset bank behind them is field-major in both cases.
 #pragma once
 #include <stdint.h>
 
