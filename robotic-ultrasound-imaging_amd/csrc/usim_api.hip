@@ -317,7 +317,7 @@ static int bank_refill(usim_handle* h, hipStream_t s) {
 // order episodes +1..+BANK_DEPTH for the selected environments and compute them
 static int bank_fill(usim_handle* h, const uint8_t* mask_dev, hipStream_t s) {
     const int total = h->n * BANK_DEPTH;
-    hipLaunchKernelGGL(usim_bank_items_kernel, dim3((total + 255) / 256), dim3(256), 0, s, h->state, h->n, h->npad, h->n_el != 0 ? 1 : 0, mask_dev, h->d_items, h->d_count);
+    hipLaunchKernelGGL(usim_bank_items_kernel, dim3((total + 255) / 256), dim3(256), 0, s, h->state, h->n, mask_dev, h->d_items, h->d_count);
     HIPCHK(h, hipGetLastError());
     return bank_refill(h, s);
 }
@@ -424,9 +424,9 @@ int usim_get_state(usim_handle* h, float* scalars, float* lattice) {
     HIPCHK(h, hipMemcpy(buf.data(), h->state, buf.size() * sizeof(float), hipMemcpyDeviceToHost));
     const int int_fields[4] = {F_T, F_TOUCH, F_EPISODE, F_STATUS};
     for (int i = 0; i < h->n; ++i) {
-        for (int f = 0; f < F_NSCALAR; ++f) scalars[(size_t)i * USIM_NSCALAR + f] = buf[scalar_index(h->n_el != 0, f, i, h->npad)];
+        for (int f = 0; f < F_NSCALAR; ++f) scalars[(size_t)i * USIM_NSCALAR + f] = buf[scalar_index(f, i)];
         for (int k = 0; k < 4; ++k) {
-            int v; std::memcpy(&v, &buf[scalar_index(h->n_el != 0, int_fields[k], i, h->npad)], 4);
+            int v; std::memcpy(&v, &buf[scalar_index(int_fields[k], i)], 4);
             scalars[(size_t)i * USIM_NSCALAR + int_fields[k]] = (float)v;
         }
         if (lattice && h->n_el)
@@ -446,10 +446,10 @@ int usim_set_state(usim_handle* h, const float* scalars, const float* lattice) {
     HIPCHK(h, hipMemcpy(buf.data(), h->state, buf.size() * sizeof(float), hipMemcpyDeviceToHost));
     const int int_fields[4] = {F_T, F_TOUCH, F_EPISODE, F_STATUS};
     for (int i = 0; i < h->n; ++i) {
-        for (int f = 0; f < F_NSCALAR; ++f) buf[scalar_index(h->n_el != 0, f, i, h->npad)] = scalars[(size_t)i * USIM_NSCALAR + f];
+        for (int f = 0; f < F_NSCALAR; ++f) buf[scalar_index(f, i)] = scalars[(size_t)i * USIM_NSCALAR + f];
         for (int k = 0; k < 4; ++k) {
             int v = (int)scalars[(size_t)i * USIM_NSCALAR + int_fields[k]];
-            std::memcpy(&buf[scalar_index(h->n_el != 0, int_fields[k], i, h->npad)], &v, 4);
+            std::memcpy(&buf[scalar_index(int_fields[k], i)], &v, 4);
         }
         if (lattice && h->n_el)
             for (int e = 0; e < h->n_el; ++e) {

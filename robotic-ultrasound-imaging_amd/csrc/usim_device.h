@@ -2,10 +2,10 @@
 // (usim_api.hip).  gfx950 only.
 //
 // HBM layout: one float32 block per handle (ints as bit patterns), n_pad = n rounded up to the workgroup
-// width.  Rigid torso (one environment per lane): the 40 scalars are field-major, `field f of env i` at state[f * n_pad + i], so a
-// wave64 touching one field of 64 consecutive environments reads one aligned 256-byte row.  Soft torso (a group of lanes per
-// environment): scalars and lattice state are environment-major (scalar_index(), LAT_*), because all lanes of a group read the same
-// environment.  The reset bank behind them is field-major in both cases.
+// width.  The per-environment state is environment-major: 40 scalar words per environment (scalar_index()), then -- soft torso --
+// 200 lattice words per environment (LAT_*).  Each environment is read and written by one lane (rigid torso) or one group of lanes
+// (soft torso) with 16-byte accesses off a single address.  The reset bank behind the state is field-major (row = slot word,
+// column = environment); it is touched only when an episode ends.
 #pragma once
 #include <stdint.h>
 
@@ -31,10 +31,9 @@ enum Field : int {
                                     // per environment: env i owns words [i * LAT_ENV_WORDS, (i + 1) * LAT_ENV_WORDS) of the region
     F_TOTAL_TOP = 40 + 200
 };
-// index of scalar field f of environment i inside the scalar region (rows 0 .. F_NSCALAR-1 of the block).  With one environment per lane
-// (rigid torso) the region is field-major: a wave reads one contiguous row per field.  In the grouped kernels (soft torso) all lanes of a
-// group read the same environment, so the region is environment-major: ten 16-byte loads fetch the 40 words of an environment.
-__host__ __device__ inline size_t scalar_index(bool env_major, int f, size_t i, size_t npad) { return env_major ? i * F_NSCALAR + f : (size_t)f * npad + i; }
+// index of scalar field f of environment i inside the scalar region (the first F_NSCALAR * n_pad words of the block): environment-major,
+// ten 16-byte accesses move the 40 words of an environment with one address register pair
+__host__ __device__ inline size_t scalar_index(int f, size_t i) { return i * F_NSCALAR + f; }
 // lattice region, environment-major (the 16 lanes of a group read 16 consecutive words): s[e] at LAT_S + e, sdot[e] at LAT_SD + e
 constexpr int LAT_ENV_WORDS = 200, LAT_S = 0, LAT_SD = 100;
 static_assert(F_TOTAL_TOP == F_LAT + LAT_ENV_WORDS && LAT_SD + N_TOP <= LAT_ENV_WORDS, "lattice region");

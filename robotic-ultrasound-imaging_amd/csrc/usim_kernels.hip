@@ -336,8 +336,8 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
     const int ei = valid ? env : (refill ? 0 : n - 1);               // clamp so that every lane has something to read; stores are guarded
     constexpr bool reset_only = (MODE == 1);
     const bool auto_reset = (flags & LF_AUTO_RESET) != 0;
-#define ST(f) st[scalar_index(TORSO != 0, (f), (size_t)ei, (size_t)npad)]
-#define STI(f) (reinterpret_cast<int*>(st))[scalar_index(TORSO != 0, (f), (size_t)ei, (size_t)npad)]
+#define ST(f) st[scalar_index((f), (size_t)ei)]
+#define STI(f) (reinterpret_cast<int*>(st))[scalar_index((f), (size_t)ei)]
 #define LAT(w) st[(size_t)F_LAT * npad + (size_t)ei * LAT_ENV_WORDS + (w)]
 #define EB(off) lds[TB_WORDS + eb * GE_STRIDE + (off)]
 // phase timeline probe (diagnostics only): wave 0 of workgroup 0 stamps the shader clock when io.dbg is set
@@ -364,14 +364,11 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
 
     TSTAMP(0);
     // ---------------- load state ----------------
-    float sv[F_NSCALAR];                               // the 40 scalar words of the environment, in Field order
-    if constexpr (TORSO != 0) {
-        const float4* sp = reinterpret_cast<const float4*>(st + (size_t)ei * F_NSCALAR);      // environment-major: ten 16-byte loads
+    float sv[F_NSCALAR];                               // the 40 scalar words of the environment, in Field order: ten 16-byte loads
+    {
+        const float4* sp = reinterpret_cast<const float4*>(st + scalar_index(0, (size_t)ei));
 #pragma unroll
         for (int v = 0; v < F_NSCALAR / 4; ++v) { const float4 x = sp[v]; sv[4 * v] = x.x; sv[4 * v + 1] = x.y; sv[4 * v + 2] = x.z; sv[4 * v + 3] = x.w; }
-    } else {
-#pragma unroll
-        for (int f = 0; f < F_NSCALAR; ++f) sv[f] = ST(f);
     }
     float q[NJ], qd[NJ], q0[NJ];
 #pragma unroll
@@ -1081,9 +1078,9 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
     TSTAMP(15);
     // ---------------- store state ----------------
     if (store && !(MODE == 1 && (refill || !need))) {
-        if constexpr (TORSO != 0) {
-            // environment-major: 16-byte stores of the quads that hold a changed word (q, qd | running statistics | counters); the quads
-            // of per-episode constants only when an episode starts
+        {
+            // 16-byte stores of the quads that hold a changed word (q, qd | running statistics | counters); the quads of per-episode
+            // constants only when an episode starts
             float o[F_NSCALAR];
 #pragma unroll
             for (int i = 0; i < NJ; ++i) { o[F_Q + i] = q[i]; o[F_QD + i] = qd[i]; o[F_Q0 + i] = q0[i]; }
@@ -1091,24 +1088,12 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
             o[F_U0] = u0; o[F_VBAR] = vbar; o[F_FZBAR] = fzbar; o[F_FZPREV] = fzprev; o[F_DFZ] = dfz;
             o[F_KST] = kst; o[F_KDMP] = kdmp; o[F_MU] = mu; o[F_EPRET] = epret;
             o[F_T] = __int_as_float(t); o[F_TOUCH] = __int_as_float(touched); o[F_EPISODE] = __int_as_float(episode); o[F_STATUS] = __int_as_float(status);
-            float4* sp = reinterpret_cast<float4*>(st + (size_t)ei * F_NSCALAR);
+            float4* sp = reinterpret_cast<float4*>(st + scalar_index(0, (size_t)ei));
             const bool all = (MODE == 1) || need;
 #pragma unroll
             for (int v = 0; v < F_NSCALAR / 4; ++v) {
                 const bool changed = (v <= 3) || v == 7 || v == 8 || v == 9;      // words 0-15 (q, qd, q0[0..1]), 28-31, 32-39
                 if (changed || all) sp[v] = make_float4(o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NJ; ++i) { ST(F_Q + i) = q[i]; ST(F_QD + i) = qd[i]; }
-            ST(F_VBAR) = vbar; ST(F_FZBAR) = fzbar; ST(F_FZPREV) = fzprev; ST(F_DFZ) = dfz; ST(F_EPRET) = epret;
-            STI(F_T) = t; STI(F_TOUCH) = touched; STI(F_EPISODE) = episode; STI(F_STATUS) = status;
-            if (MODE == 1 || need) {
-                // per-episode constants change only when an episode starts
-#pragma unroll
-                for (int i = 0; i < NJ; ++i) ST(F_Q0 + i) = q0[i];
-                ST(F_TS) = ts.x; ST(F_TS + 1) = ts.y; ST(F_TS + 2) = ts.z; ST(F_TE) = te.x; ST(F_TE + 1) = te.y; ST(F_TE + 2) = te.z;
-                ST(F_U0) = u0; ST(F_KST) = kst; ST(F_KDMP) = kdmp; ST(F_MU) = mu;
             }
         }
     }
@@ -1133,12 +1118,12 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
 }
 
 // work items (env, episode + k), k = 1..BANK_DEPTH, for the environments selected by mask (reset / set_state paths)
-__global__ void usim_bank_items_kernel(const float* __restrict__ st, int n, int npad, int env_major, const uint8_t* __restrict__ mask, int2* items, int* count) {
+__global__ void usim_bank_items_kernel(const float* __restrict__ st, int n, const uint8_t* __restrict__ mask, int2* items, int* count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * BANK_DEPTH) return;
     const int env = i / BANK_DEPTH, k = i % BANK_DEPTH + 1;
     if (mask && !mask[env]) return;
-    const int episode = reinterpret_cast<const int*>(st)[scalar_index(env_major != 0, F_EPISODE, env, npad)];
+    const int episode = reinterpret_cast<const int*>(st)[scalar_index(F_EPISODE, (size_t)env)];
     items[atomicAdd(count, 1)] = make_int2(env, episode + k);
 }
 
