@@ -4,8 +4,7 @@
 // HBM layout: one float32 block per handle (ints as bit patterns), n_pad = n rounded up to the workgroup
 // width.  The per-environment state is environment-major: 40 scalar words per environment (scalar_index()), then -- soft torso --
 // 200 lattice words per environment (LAT_*).  Each environment is read and written by one lane (rigid torso) or one group of lanes
-// (soft torso) with 16-byte accesses off a single address.  The reset bank behind the state is field-major (row = slot word,
-// column = environment); it is touched only when an episode ends.
+// (soft torso) with 16-byte accesses off a single address.  The reset bank behind the state is environment-major as well.
 #pragma once
 #include <stdint.h>
 
@@ -82,6 +81,7 @@ enum LaunchFlags : int { LF_AUTO_RESET = 1, LF_RANDOM_ACT = 4 };
 // the reset observation of one future episode (a pure function of seed, global env id and episode index)
 enum BankField : int { BQ0 = 0, BTS = 7, BTE = 10, BU0 = 13, BKST = 14, BKDMP = 15, BMU = 16, BFZ = 17, BOBS = 18, BSTATUS = 37, BANK_WORDS = 38 };
 constexpr int BANK_DEPTH = 64;
-constexpr int BANK_ROWS = BANK_DEPTH * BANK_WORDS;
+constexpr int BANK_STRIDE = 40;                       // words per slot (BANK_WORDS rounded up to 16 bytes)
+constexpr int BANK_ROWS = BANK_DEPTH * BANK_STRIDE;   // the bank is environment-major too: env i owns BANK_ROWS words, slot s at s * BANK_STRIDE
 
 }  // namespace usim

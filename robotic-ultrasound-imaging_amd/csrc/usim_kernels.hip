@@ -346,8 +346,8 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
 #else
 #define TSTAMP(k) do { if (io.dbg && blockIdx.x == 0 && threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); io.dbg[k] = __builtin_readcyclecounter(); } } while (0)
 #endif
-#define BK(slot, f) st[(size_t)(io.bank_row0 + (slot) * BANK_WORDS + (f)) * npad + ei]
-#define BKI(slot, f) (reinterpret_cast<int*>(st))[(size_t)(io.bank_row0 + (slot) * BANK_WORDS + (f)) * npad + ei]
+#define BK(slot, f) st[(size_t)io.bank_row0 * npad + ((size_t)ei * BANK_DEPTH + (slot)) * BANK_STRIDE + (f)]
+#define BKI(slot, f) (reinterpret_cast<int*>(st))[(size_t)io.bank_row0 * npad + ((size_t)ei * BANK_DEPTH + (slot)) * BANK_STRIDE + (f)]
     if (TORSO && item0 == (refill ? (int)blockIdx.x * EPB : 0)) {
         // workgroup-resident copy of the lattice tables (inverse 99 x 100, element positions/axes/neighbours/shell ids):
         // 16-byte loads, all issued before the first LDS store
