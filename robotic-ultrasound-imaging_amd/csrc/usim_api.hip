@@ -470,6 +470,10 @@ int usim_set_state(usim_handle* h, const float* scalars, const float* lattice) {
 
 int usim_profile_step(usim_handle* h, const usim_step_io* s, int64_t step, uint64_t* ticks, int max_ticks) {
     if (!h || !ticks || max_ticks < 17) return USIM_ERR_INVALID;
+#if !defined(USIM_TSTAMP) && !defined(USIM_TSTAMP_NOWAIT)
+    h->hip_err = "usim_profile_step needs the profiling build (make -C csrc prof -> libusim_prof.so)";
+    return USIM_ERR_UNSUPPORTED;
+#endif
     DeviceGuard guard(h->device);
     DevIO io; int rc = fill_io(s, io, false);
     if (rc) return rc;

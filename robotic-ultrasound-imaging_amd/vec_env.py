@@ -173,7 +173,8 @@ class UltrasoundVecEnv:
               "obs+reward+done", "store"]
 
     def profile_step(self, step):
-        """Diagnostics: shader-clock ticks spent in each phase of one step kernel by wave 0 of workgroup 0."""
+        """Diagnostics: shader-clock ticks spent in each phase of one step kernel by wave 0 of workgroup 0 (profiling build of the
+        library only: `make -C csrc prof`, USIM_LIB=.../libusim_prof.so)."""
         ticks = (C.c_uint64 * 17)()
         self._check(self.lib.usim_profile_step(self._handle, C.byref(self._io), int(step), ticks, 17))
         t = list(ticks)

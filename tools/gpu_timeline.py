@@ -1,6 +1,11 @@
-import importlib, sys
+import importlib, os, subprocess, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
+# the phase stamps live in the profiling build of the library only
+PROF = ROOT / "robotic-ultrasound-imaging_amd" / "lib" / "libusim_prof.so"
+if not PROF.exists():
+    subprocess.run(["make", "-C", str(ROOT / "robotic-ultrasound-imaging_amd" / "csrc"), "prof"], check=True)
+os.environ["USIM_LIB"] = str(PROF)
 sys.path.insert(0, str(ROOT))
 import numpy as np, torch
 usim = importlib.import_module("robotic-ultrasound-imaging_amd")
