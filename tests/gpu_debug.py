@@ -1,4 +1,5 @@
-"""Ad-hoc GPU vs oracle comparison (development aid; the judged checks live in tests/)."""
+"""Ad-hoc verbose GPU vs oracle comparison (development aid, run by hand: `python tests/gpu_debug.py`; not collected by pytest -- the
+judged checks are the test_gpu_* modules).  Lives under tests/ because it uses the oracle."""
 import importlib, sys, time
 from pathlib import Path
 import numpy as np
