@@ -3,7 +3,9 @@
 // hipcc --offload-arch=gfx950 -O2 -shared -fPIC -o tools/probe/libspin.so tools/probe/spin.hip
 #include <hip/hip_runtime.h>
 __global__ void spin_kernel(long long ticks, int* sink) {
-    asm volatile("v_mov_b32 v127, 0" ::: "v127");            // claim 128 VGPRs: the register footprint of a typical collective kernel
+    // claim 264 registers per lane (256 VGPRs + 8 AGPRs): the footprint of RCCL's rcclGenericKernel on gfx950 (261-280, read from the
+    // code object metadata of the librccl.so that ships with PyTorch)
+    asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a7, v255" ::: "v255", "a7");
     const long long t0 = wall_clock64();
     int acc = 0;
     while (wall_clock64() - t0 < ticks) acc += 1;
