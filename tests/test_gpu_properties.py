@@ -238,3 +238,19 @@ def test_numerical_fault_guard_and_action_sanitising(usim):
     _, _, d, _, _ = ora.step(ora.random_actions(0))
     assert d[1] and int(ora.get_state()["episode"][1]) == int(so["episode"][1]) + 1
     env.close(); ref.close()
+
+
+def test_config3_global_batch_equals_its_shards(usim):
+    """BASELINE configs[3]: 32768 environments sharded 8 x 4096.  With the same lane mapping the first and the last 4096-env shard
+    (env_offset = 0 / 28672) reproduce their slice of one 32768-env handle bit for bit -- no state is shared between environments."""
+    kw = usim.default_robosuite_kwargs()
+    whole = usim.UltrasoundVecEnv(32768, device="cuda:0", seed=3, torso="soft", lanes_per_env=8, **kw)
+    first = usim.UltrasoundVecEnv(4096, device="cuda:0", seed=3, torso="soft", lanes_per_env=8, env_offset=0, **kw)
+    last = usim.UltrasoundVecEnv(4096, device="cuda:0", seed=3, torso="soft", lanes_per_env=8, env_offset=28672, **kw)
+    rw, rf, rl = _rollout_hash(whole, 24), _rollout_hash(first, 24), _rollout_hash(last, 24)
+    for (ow, rww, dw), (of, rwf, df), (ol, rwl, dl) in zip(rw, rf, rl):
+        assert torch.equal(ow[:4096], of) and torch.equal(rww[:4096], rwf) and torch.equal(dw[:4096], df)
+        assert torch.equal(ow[28672:], ol) and torch.equal(rww[28672:], rwl) and torch.equal(dw[28672:], dl)
+    assert not torch.isnan(rw[-1][0]).any()
+    for e in (whole, first, last):
+        e.close()
