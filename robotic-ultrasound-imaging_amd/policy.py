@@ -135,6 +135,24 @@ class MlpActorCritic(torch.nn.Module):
     def forward(self, obs):
         return self.action_net(self.policy_net(obs)), self.value_net(self.value_net_body(obs)).squeeze(-1)
 
+    @staticmethod
+    def _log_prob(mean, log_std, act):
+        var = torch.exp(2.0 * log_std)
+        return (-0.5 * ((act - mean) ** 2 / var) - log_std - 0.9189385332046727).sum(-1)       # DiagGaussianDistribution.log_prob
+
+    @torch.no_grad()
+    def sample(self, obs, generator=None):
+        """ActorCriticPolicy.forward as collect_rollouts uses it: (unclipped action sample, value, log-probability)"""
+        mean, value = self.forward(obs)
+        act = mean + torch.exp(self.log_std) * torch.randn(mean.shape, device=mean.device, generator=generator)
+        return act, value, self._log_prob(mean, self.log_std, act)
+
+    def evaluate_actions(self, obs, act):
+        """ActorCriticPolicy.evaluate_actions: (values, log-probabilities, entropy) with gradients, for a PPO update"""
+        mean, value = self.forward(obs)
+        ent = (0.5 + 0.9189385332046727 + self.log_std).sum(-1).expand(mean.shape[0])
+        return value, self._log_prob(mean, self.log_std, act), ent
+
     @torch.no_grad()
     def predict(self, obs, deterministic=True, low=None, high=None, generator=None):
         """PPO.predict: Gaussian mean (or a sample), clipped to the action box like SB3 does before env.step"""
@@ -173,3 +191,84 @@ def policy_rollout(env, policy, vecnorm, steps, deterministic=False, seed=0):
            "episodes": float(ep_n), "mean_episode_return": float(ep_r / ep_n) if ep_n > 0 else float("nan"),
            "mean_episode_length": float(ep_l / ep_n) if ep_n > 0 else float("nan")}
     return out
+
+
+class DeviceRolloutBuffer:
+    """stable_baselines3.common.buffers.RolloutBuffer on the device (src/rl.py:143 builds PPO with SB3's defaults: n_steps 2048,
+    gamma 0.99, gae_lambda 0.95): [T, n, ...] tensors filled step by step, GAE(lambda) returns/advantages, flattened minibatches.
+    Nothing leaves the GPU between env.step_tensor() and the learner."""
+
+    def __init__(self, buffer_size, num_envs, obs_dim=19, act_dim=6, device="cuda:0", gamma=0.99, gae_lambda=0.95):
+        self.buffer_size, self.n_envs, self.gamma, self.gae_lambda = int(buffer_size), int(num_envs), float(gamma), float(gae_lambda)
+        self.device = torch.device(device)
+        T, n = self.buffer_size, self.n_envs
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=self.device)
+        self.observations, self.actions = z(T, n, obs_dim), z(T, n, act_dim)
+        self.rewards, self.episode_starts, self.values, self.log_probs = z(T, n), z(T, n), z(T, n), z(T, n)
+        self.advantages, self.returns = z(T, n), z(T, n)
+        self.reset()
+
+    def reset(self):
+        self.pos, self.full = 0, False
+
+    def add(self, obs, action, reward, episode_start, value, log_prob):
+        if self.pos >= self.buffer_size:
+            raise RuntimeError("rollout buffer is full")
+        t = self.pos
+        self.observations[t].copy_(obs); self.actions[t].copy_(action); self.rewards[t].copy_(reward)
+        self.episode_starts[t].copy_(episode_start.to(torch.float32)); self.values[t].copy_(value); self.log_probs[t].copy_(log_prob)
+        self.pos += 1
+        self.full = self.pos == self.buffer_size
+
+    def compute_returns_and_advantage(self, last_values, dones):
+        """GAE exactly as RolloutBuffer.compute_returns_and_advantage: `dones` are the done flags of the last stored step"""
+        last_gae = torch.zeros(self.n_envs, dtype=torch.float32, device=self.device)
+        for step in reversed(range(self.buffer_size)):
+            if step == self.buffer_size - 1:
+                next_non_terminal, next_values = 1.0 - dones.to(torch.float32), last_values
+            else:
+                next_non_terminal, next_values = 1.0 - self.episode_starts[step + 1], self.values[step + 1]
+            delta = self.rewards[step] + self.gamma * next_values * next_non_terminal - self.values[step]
+            last_gae = delta + self.gamma * self.gae_lambda * next_non_terminal * last_gae
+            self.advantages[step] = last_gae
+        self.returns = self.advantages + self.values
+
+    def get(self, batch_size=None, generator=None):
+        """minibatches of the flattened [T * n] samples (swap_and_flatten order: env-major), shuffled like SB3"""
+        if not self.full:
+            raise RuntimeError("rollout buffer is not full")
+        N = self.buffer_size * self.n_envs
+        flat = lambda x: x.transpose(0, 1).reshape(N, *x.shape[2:])
+        data = tuple(flat(x) for x in (self.observations, self.actions, self.values, self.log_probs, self.advantages, self.returns))
+        perm = torch.randperm(N, device=self.device, generator=generator)
+        bs = N if batch_size is None else int(batch_size)
+        for i in range(0, N, bs):
+            idx = perm[i:i + bs]
+            yield tuple(x[idx] for x in data)
+
+
+@torch.no_grad()
+def collect_rollouts(env, policy, vecnorm, buffer, obs=None, episode_start=None, generator=None):
+    """OnPolicyAlgorithm.collect_rollouts for one buffer: sample actions from the policy on normalised observations, clip them to
+    the action box for the env, store the unclipped sample, normalise rewards, bootstrap with the value of the last observation.
+    (SB3 also bootstraps time-limit truncations with the terminal observation's value; the reference's GymWrapper does not report
+    truncations, so that branch never fires there either.)  Returns (next raw obs, next episode_start) to continue from."""
+    dev = env.device
+    low, high = torch.as_tensor(env.action_space.low, device=dev), torch.as_tensor(env.action_space.high, device=dev)
+    if obs is None:
+        obs = env.reset_tensor()
+    if episode_start is None:
+        episode_start = torch.ones(env.num_envs, dtype=torch.bool, device=dev)
+    buffer.reset()
+    done = episode_start
+    for _ in range(buffer.buffer_size):
+        nobs = vecnorm.normalize_obs(obs)
+        act, value, logp = policy.sample(nobs, generator)
+        obs, rew, done = env.step_tensor(torch.max(torch.min(act, high), low))
+        nrew = vecnorm.normalize_reward(rew, done)
+        buffer.add(nobs, act, nrew, episode_start, value, logp)
+        episode_start = done.bool().clone()
+        obs = obs.clone()
+    _, last_value = policy.forward(vecnorm.normalize_obs(obs))
+    buffer.compute_returns_and_advantage(last_value, done.bool())
+    return obs, episode_start
