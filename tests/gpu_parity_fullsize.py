@@ -1,0 +1,19 @@
+"""One-off record run (by hand, on the GPU box): the parity check of test_gpu_parity.py at BASELINE's full size -- 4096 environments x
+200 steps -- for every controller mode and both torso models, plus the randomised configuration; prints the razor-edge counts.
+Lives under tests/ because it uses the oracle.   python tests/gpu_parity_fullsize.py > profiles/r01/parity_fullsize.txt"""
+import importlib, os, sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 64)))
+import test_gpu_parity as T
+usim = importlib.import_module("robotic-ultrasound-imaging_amd")
+for torso in ("rigid", "soft"):
+    for mode in ("tracking", "fixed", "variable_z", "wrench"):
+        t0 = time.time()
+        explained = T._run_parity(usim, 4096, 200, torso, mode, omp=True)
+        print(f"{torso:5s} {mode:10s} 4096 envs x 200 steps: state within {T.STATE_RTOL:g} rel, done flags / contact indices bit-exact; "
+              f"{explained} threshold decisions within rounding of the threshold in the oracle itself ({time.time() - t0:.0f} s)", flush=True)
+t0 = time.time()
+explained = T._run_parity(usim, 4096, 200, "soft", "tracking", omp=True, friction_randomization=1, elem_friction=0.0, probe_friction=0.3)
+print(f"soft  tracking   randomised friction/stiffness/damping, 4096 x 200: {explained} razor-edge decisions ({time.time() - t0:.0f} s)")

@@ -70,7 +70,16 @@ def _run_parity(usim, n, steps, torso, mode, **extra):
         assert np.array_equal(con_g[alive], con_o[alive])
         # observations: pose/velocity channels tight, force channels scale with the contact stiffness (~1e3 N/m x 1e-6 m)
         d = np.abs(obs_g[alive] - obs_o[alive])
-        assert d[:, 6:9].max() < 2e-5 and d[:, 11:19].max() < 2e-5, (k, d.max(0))
+        # quaternion channels: q and -q are the same rotation and mat2quat normalises the sign by w >= 0, so at w ~ 0 the two
+        # precisions may pick opposite signs -- all four channels negated exactly; nothing downstream depends on the sign
+        # (distance_quat folds it).  Seen once in 4096 x 200 env-steps of the `fixed` mode; counted with the razor edges.
+        flipped = (d[:, 15:19].max(1) >= 2e-5) & (np.abs(obs_g[alive][:, 15:19] + obs_o[alive][:, 15:19]).max(1) < 2e-5)
+        explained += int(flipped.sum())
+        d[flipped, 15:19] = 0.0
+        # velocity channels: absolute floor plus the state criterion itself (1e-4 of the largest speed in the batch; the `wrench`
+        # mode drives the arm at up to ~1 m/s and its contact dynamics amplify rounding fastest)
+        vtol = 2e-5 + STATE_RTOL * np.abs(obs_o[alive][:, 6:9]).max()
+        assert d[:, 6:9].max() < vtol and d[:, 11:19].max() < 2e-5, (k, d.max(0), vtol)
         assert d[:, 0:3].max() < 2e-2 and d[:, 3:6].max() < 2e-3 and d[:, 9].max() < 2e-2, (k, d.max(0))
         # reward = 5 exponentials; the two force terms are Lipschitz in the observed statistics with constants
         # 3*0.7*sqrt(2/e) = 1.8 per N (channel 9) and 2*0.01*sqrt(2/e) = 0.0172 per N/s (channel 10), so the
@@ -104,7 +113,7 @@ def test_rigid_torso_parity_200_steps(usim, mode):
     _run_parity(usim, 256, 200, "rigid", mode)
 
 
-@pytest.mark.parametrize("mode", ["tracking", "fixed", "wrench"])
+@pytest.mark.parametrize("mode", ["tracking", "fixed", "variable_z", "wrench"])
 def test_soft_torso_parity_200_steps(usim, mode):
     """BASELINE configs[2]: soft-torso contact + force/velocity-tracking reward"""
     _run_parity(usim, 256, 200, "soft", mode)
