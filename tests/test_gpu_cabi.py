@@ -50,3 +50,15 @@ def test_error_conventions_on_device(usim):
     sc2 = np.zeros_like(sc)
     assert lib.usim_get_state(h, sc2.ctypes.data, None) == 0 and np.array_equal(sc, sc2)
     lib.usim_destroy(h)
+
+
+def test_profile_step_needs_the_profiling_build(usim):
+    """the phase stamps are compiled into libusim_prof.so only (make -C csrc prof); the production library says so instead of
+    returning zeros"""
+    env = usim.UltrasoundVecEnv(64, device="cuda:0", seed=1, **usim.default_robosuite_kwargs())
+    env.reset_tensor()
+    with pytest.raises(RuntimeError, match="(?i)unsupported|profiling build"):
+        env.profile_step(0)
+    obs, rew, done = env.step_tensor(env.random_actions_tensor(0))      # the handle is still usable
+    assert torch.isfinite(obs).all()
+    env.close()
