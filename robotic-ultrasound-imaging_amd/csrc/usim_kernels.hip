@@ -824,8 +824,9 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                         }
                     }
                     TSTAMP(10);
-                    // ---- contact wrench on the site and impulse along each element axis: owners publish, everyone sums ----
-                    if (own) {
+                    // ---- contact wrench on the site and impulse along each element axis: the first MAXC lanes publish (lanes without a
+                    //      contact hold w = g = f = 0, i.e. publish zeros), everyone sums the slots the wave uses ----
+                    if (gl < MAXC) {
                         f3 Fw = mk(w[0][0] * f[0] + w[1][0] * f[1] + w[2][0] * f[2], w[0][1] * f[0] + w[1][1] * f[1] + w[2][1] * f[2],
                                    w[0][2] * f[0] + w[1][2] * f[1] + w[2][2] * f[2]);
                         f3 Tw = mk(w[0][3] * f[0] + w[1][3] * f[1] + w[2][3] * f[2], w[0][4] * f[0] + w[1][4] * f[1] + w[2][4] * f[2],
@@ -837,7 +838,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                     group_sync();
 #pragma unroll
                     for (int k = 0; k < MAXC; ++k) {
-                        if (k < ncmax && k < nc) {
+                        if (k < ncmax) {
                             const int b = GE_WS + k * 8;
 #pragma unroll
                             for (int a = 0; a < 6; ++a) W[a] += EB(b + a);
