@@ -1,7 +1,7 @@
 """Learnability check: a from-scratch PPO (clip objective, GAE, Adam; SB3's default hyper-parameters where they matter) trained on the
 batched simulator through the device-side collector of policy.py.  Not part of the product path (the reference's training loop is
 stable-baselines3 and stays the caller); it answers one question: does reward per step climb from the random-gain level (5.6) towards
-what the reference's own policy earns on it (8.1)?   usage: python tools/ppo_demo.py [iterations] [n_envs] [n_steps]"""
+what the reference's own policy earns on it (8.1)?   usage: python tools/ppo_demo.py [iterations] [n_envs] [n_steps] [impedance_mode]"""
 import importlib, sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -13,8 +13,11 @@ pol = importlib.import_module("robotic-ultrasound-imaging_amd.policy")
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+mode = sys.argv[4] if len(sys.argv) > 4 else "tracking"
 torch.manual_seed(0)
-env = usim.UltrasoundVecEnv(n, device="cuda:0", seed=3, **usim.default_robosuite_kwargs())
+kw = usim.default_robosuite_kwargs(); kw["controller_configs"] = dict(kw["controller_configs"], impedance_mode=mode)
+env = usim.UltrasoundVecEnv(n, device="cuda:0", seed=3, **kw)
+print(f"mode {mode}, {n} envs x {T} steps per iteration", flush=True)
 dev = env.device
 policy = pol.MlpActorCritic(19, env.action_dim).to(dev)
 for m in policy.modules():                                      # SB3: orthogonal init, gain sqrt(2) (0.01 for the action head, 1 for the value head)
