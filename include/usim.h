@@ -101,7 +101,9 @@ typedef struct usim_step_io {
 int usim_default_config(usim_config* c);
 
 /* Replaces suite.make("Ultrasound", **options) + GymWrapper (src/rl.py:36-40) for n environments on HIP
- * device `device`.  Environments start un-reset; call usim_reset first. */
+ * device `device`.  Environments start un-reset; call usim_reset first.  Every handle owns its model tables (lattice inverse,
+ * element geometry) in device memory: any number of handles, with the same or different configurations (torso_shape, torso, mode),
+ * may be alive on one GPU at the same time.  The upload is complete when usim_create returns. */
 int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** out);
 void usim_destroy(usim_handle* h);
 

@@ -25,6 +25,7 @@ struct usim_handle {
     DevModel M;
     DevCfg C;
     float* state = nullptr;
+    float* d_tables = nullptr;        // lattice table block of this handle (DevModel::tables)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // reset bank machinery
     int2* d_items = nullptr;          // refill work list, capacity 2 * n * BANK_DEPTH
@@ -190,7 +191,10 @@ static int build_model(usim_handle* h) {
     for (int i = 0; i < N_TOP; ++i) for (int j = 0; j < N_TOP; ++j) tb[TB_LINV + (size_t)i * LROW + j] = (float)Li[(size_t)i * N_TOP + j];
     for (int i = 0; i < N_TOP * 3; ++i) { tb[TB_POS + i] = elpos[i]; tb[TB_AXIS + i] = elaxis[i]; }
     std::memcpy(&tb[TB_SHELL], shell.data(), shell.size() * sizeof(int));
-    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(c_tables), tb.data(), tb.size() * sizeof(float)));
+    // per-handle copy (synchronous: complete before usim_create returns, so no stream of the caller can race with it)
+    HIPCHK(h, hipMalloc(&h->d_tables, tb.size() * sizeof(float)));
+    HIPCHK(h, hipMemcpy(h->d_tables, tb.data(), tb.size() * sizeof(float), hipMemcpyHostToDevice));
+    M.tables = h->d_tables;
     return USIM_OK;
 }
 
@@ -295,6 +299,7 @@ void usim_destroy(usim_handle* h) {
     DeviceGuard guard(h->device);
     (void)hipDeviceSynchronize();
     if (h->state) (void)hipFree(h->state);
+    if (h->d_tables) (void)hipFree(h->d_tables);
     if (h->d_items) (void)hipFree(h->d_items);
     if (h->d_count) (void)hipFree(h->d_count);
 

@@ -48,6 +48,7 @@ struct DevModel {
     float ghat[4], geps;            // unit goal quaternion (w,x,y,z) and 1 - |goal_quat|
     float base[3];                  // robot base in world coordinates
     float invw, wfix, wten;         // contact regulariser scale, lattice soft-equality weights
+    const float* tables;            // this handle's lattice table block in HBM (TB_WORDS words, 16-byte aligned; soft torso only)
 };
 
 struct DevCfg {

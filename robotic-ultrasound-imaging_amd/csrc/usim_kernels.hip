@@ -31,14 +31,14 @@
 
 namespace usim {
 
-// lattice tables, laid out exactly as their workgroup-resident LDS copy (uploaded once per device by usim_create)
+// lattice tables, laid out exactly as their workgroup-resident LDS copy.  One device buffer per handle (DevModel::tables, built and
+// uploaded by usim_create): handles with different torso shapes can live side by side on one GPU
 constexpr int LROW = 100;                             // row stride of the lattice inverse (pad word zero)
 constexpr int TB_LINV = 0;                            // float [99][100]
 constexpr int TB_POS = N_TOP * LROW;                  // float [99][3] nominal surface point rel. torso centre (padded to 300)
 constexpr int TB_AXIS = TB_POS + 300;                 // float [99][3] slide axis
 constexpr int TB_SHELL = TB_AXIS + 300;               // int   [99]    shell id (contact-pair index convention)
 constexpr int TB_WORDS = TB_SHELL + 100;              // 10600 words (the lattice topology itself is implicit: 9 x 11 grid stencil)
-__constant__ __attribute__((aligned(16))) float c_tables[TB_WORDS];
 
 // per-environment LDS block (word offsets); GE_X must stay 16-byte aligned
 constexpr int GE_X = 0;                               // rhs[100] of the lattice solve
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
     if (TORSO && item0 == (refill ? (int)blockIdx.x * EPB : 0)) {
         // workgroup-resident copy of the lattice tables (inverse 99 x 100, element positions/axes/neighbours/shell ids):
         // 16-byte loads, all issued before the first LDS store
-        const float4* src = reinterpret_cast<const float4*>(c_tables);
+        const float4* src = reinterpret_cast<const float4*>(M.tables);
         float4* dst = reinterpret_cast<float4*>(lds);
         constexpr int NV = TB_WORDS / 4, PER = (NV + NTT - 1) / NTT;
         float4 tmp[PER];

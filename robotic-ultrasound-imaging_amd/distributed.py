@@ -81,5 +81,9 @@ class RolloutGather:
         out, ev = self._pending
         self._pending = None
         if ev is not None:
-            torch.cuda.current_stream(self.device).wait_event(ev)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            # `out` was allocated on the side stream and is consumed on the caller's: tell the caching allocator, or the block could
+            # be handed to the next gather while the caller's kernels still read it
+            out.record_stream(cur)
         return out

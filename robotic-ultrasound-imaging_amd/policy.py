@@ -5,27 +5,61 @@ The reference evaluates a checkpoint with `VecNormalize.load(...)`, `PPO.load(..
 The shipped artefacts are `trained_rl_models/<name>.zip` (SB3 1.1.0a5: json `data` + `policy.pth` state dict of an
 ActorCriticPolicy with net_arch [dict(pi=[256,128], vf=[256,128])], tanh activations) and `vec_normalize_<name>.pkl`
 (obs_rms / ret_rms, clip 10, gamma 0.99, eps 1e-8).  Neither SB3 nor gym is imported: the zip is read with zipfile +
-torch.load(weights_only=True), the pickle with stub classes."""
+torch.load(weights_only=True), the pickle with a restricted unpickler that maps the four SB3 / gym classes to local stand-ins
+(sys.modules is never touched).  save_sb3_zip / save_vecnormalize_pkl write the same formats (the model.save / env.save step at the
+end of src/rl.py's training branch, :157-158)."""
 import io
 import json
 import pickle
-import sys
-import types
 import zipfile
 
 import numpy as np
 import torch
 
+# the four classes a VecNormalize pickle of stable-baselines3 refers to (besides numpy's array reconstructors)
+_SB3_CLASSES = (("gym.spaces.box", "Box"), ("gym.spaces.space", "Space"),
+                ("stable_baselines3.common.running_mean_std", "RunningMeanStd"),
+                ("stable_baselines3.common.vec_env.vec_normalize", "VecNormalize"))
 
-def _stub(modname, clsname):
-    parts = modname.split(".")
-    for i in range(1, len(parts) + 1):
-        name = ".".join(parts[:i])
-        if name not in sys.modules:
-            sys.modules[name] = types.ModuleType(name)
-    if not hasattr(sys.modules[modname], clsname):
-        setattr(sys.modules[modname], clsname,
-                type(clsname, (), {"__module__": modname, "__setstate__": lambda self, st: self.__dict__.update(st)}))
+
+def _make_stub(modname, clsname):
+    # local stand-in for one SB3 / gym class: carries the original (module, name) for the writer, never registered in sys.modules
+    return type(clsname, (), {"__module__": __name__, "_pickle_global": (modname, clsname),
+                              "__setstate__": lambda self, st: self.__dict__.update(st)})
+
+
+_STUBS = {key: _make_stub(*key) for key in _SB3_CLASSES}
+# numpy's array / dtype / scalar reconstructors (both spellings of the private multiarray module)
+_NUMPY_GLOBALS = {("numpy", "dtype"), ("numpy", "ndarray"), ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+                  ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar")}
+
+
+class _CheckpointUnpickler(pickle.Unpickler):
+    """Resolves only the four SB3 / gym classes (to local stubs) and numpy's array reconstructors; everything else is refused, and
+    sys.modules is left alone (a later `import stable_baselines3` in the same process finds the real package)."""
+
+    def find_class(self, module, name):
+        if (module, name) in _STUBS:
+            return _STUBS[(module, name)]
+        if (module, name) in _NUMPY_GLOBALS:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"refusing to load {module}.{name} from a VecNormalize checkpoint")
+
+
+class _CheckpointPickler(pickle._Pickler):
+    """Writes the stub classes under the (module, name) of the SB3 / gym class they stand for, so that the file loads with
+    VecNormalize.load on a machine that has stable-baselines3."""
+
+    def save_global(self, obj, name=None):
+        target = getattr(obj, "_pickle_global", None) if isinstance(obj, type) else None
+        if target is None:
+            return super().save_global(obj, name)
+        self.save(target[0]); self.save(target[1])
+        self.write(pickle.STACK_GLOBAL)
+        self.memoize(obj)
+
+    dispatch = dict(pickle._Pickler.dispatch)
+    dispatch[type] = save_global
 
 
 def load_sb3_zip(path):
@@ -36,18 +70,63 @@ def load_sb3_zip(path):
     return sd, data
 
 
+def save_sb3_zip(path, policy, data=None):
+    """Write `policy` (MlpActorCritic) in the on-disk layout of `PPO.save` (src/rl.py:157): zip{data json, policy.pth state dict under
+    SB3's layer names, pytorch_variables.pth, _stable_baselines3_version}.  `data` is the json dictionary of the checkpoint; pass the
+    one returned by load_sb3_zip for a reference checkpoint (it carries the serialized policy class and spaces PPO.load asks for) --
+    without it only the numeric hyper-parameters of src/rl.py are written, enough for load_sb3_zip / policy.load_state_dict."""
+    sd = policy.to_sb3_state_dict()
+    if data is None:
+        data = {"gamma": 0.99, "gae_lambda": 0.95, "n_steps": 2048, "n_envs": None,
+                "policy_kwargs": {"activation_fn": "tanh", "net_arch": [{"pi": list(policy.pi_sizes), "vf": list(policy.vf_sizes)}]}}
+    buf, var = io.BytesIO(), io.BytesIO()
+    torch.save(sd, buf); torch.save(None, var)
+    with zipfile.ZipFile(path, "w") as z:
+        z.writestr("data", json.dumps(data, indent=4))
+        z.writestr("policy.pth", buf.getvalue())
+        z.writestr("pytorch_variables.pth", var.getvalue())
+        z.writestr("_stable_baselines3_version", "1.1.0a5")
+
+
 def load_vecnormalize_pkl(path):
-    """-> dict(obs_mean, obs_var, count, ret_mean, ret_var, clip_obs, clip_reward, gamma, epsilon)"""
-    for mod, cls in (("gym.spaces.box", "Box"), ("gym.spaces.space", "Space"),
-                     ("stable_baselines3.common.running_mean_std", "RunningMeanStd"),
-                     ("stable_baselines3.common.vec_env.vec_normalize", "VecNormalize")):
-        _stub(mod, cls)
+    """-> dict(obs_mean, obs_var, count, ret_mean, ret_var, ret_count, clip_obs, clip_reward, gamma, epsilon)"""
     with open(path, "rb") as f:
-        v = pickle.load(f).__dict__
+        v = _CheckpointUnpickler(f).load().__dict__
     o, r = v["obs_rms"].__dict__, v["ret_rms"].__dict__
     return {"obs_mean": np.asarray(o["mean"], dtype=np.float64), "obs_var": np.asarray(o["var"], dtype=np.float64), "count": float(o["count"]),
-            "ret_mean": float(r["mean"]), "ret_var": float(r["var"]), "clip_obs": float(v["clip_obs"]), "clip_reward": float(v["clip_reward"]),
+            "ret_mean": float(r["mean"]), "ret_var": float(r["var"]), "ret_count": float(r["count"]),
+            "clip_obs": float(v["clip_obs"]), "clip_reward": float(v["clip_reward"]),
             "gamma": float(v["gamma"]), "epsilon": float(v["epsilon"])}
+
+
+def _box(low, high, dtype=np.float32):
+    b = _STUBS[("gym.spaces.box", "Box")]()
+    low, high = np.asarray(low, dtype=dtype), np.asarray(high, dtype=dtype)
+    b.__dict__.update(dtype=np.dtype(dtype), shape=tuple(low.shape), low=low, high=high, bounded_below=np.isfinite(low),
+                      bounded_above=np.isfinite(high), _np_random=None)
+    return b
+
+
+def save_vecnormalize_pkl(path, stats, num_envs, action_low, action_high, training=True, norm_reward=True):
+    """Write running statistics in the layout of `VecNormalize.save` (src/rl.py:158; the fields VecNormalize.__getstate__ keeps):
+    loads with VecNormalize.load where stable-baselines3 is installed, and with load_vecnormalize_pkl here.  `stats` is the
+    dictionary load_vecnormalize_pkl returns / DeviceVecNormalize.stats() builds."""
+    def rms(mean, var, count):
+        r = _STUBS[("stable_baselines3.common.running_mean_std", "RunningMeanStd")]()
+        r.__dict__.update(mean=mean, var=var, count=float(count))
+        return r
+    n_obs = len(stats["obs_mean"])
+    v = _STUBS[("stable_baselines3.common.vec_env.vec_normalize", "VecNormalize")]()
+    v.__dict__.update(
+        num_envs=int(num_envs), observation_space=_box(np.full(n_obs, -np.inf), np.full(n_obs, np.inf)), action_space=_box(action_low, action_high),
+        obs_keys=None, obs_spaces=None,
+        obs_rms=rms(np.asarray(stats["obs_mean"], dtype=np.float64), np.asarray(stats["obs_var"], dtype=np.float64), stats["count"]),
+        ret_rms=rms(np.float64(stats["ret_mean"]), np.float64(stats["ret_var"]), stats.get("ret_count", stats["count"])),
+        clip_obs=float(stats["clip_obs"]), clip_reward=float(stats["clip_reward"]), gamma=float(stats["gamma"]), epsilon=float(stats["epsilon"]),
+        training=bool(training), norm_obs=True, norm_reward=bool(norm_reward),
+        old_obs=np.zeros((int(num_envs), n_obs), dtype=np.float32), old_reward=np.zeros(int(num_envs), dtype=np.float32))
+    with open(path, "wb") as f:
+        _CheckpointPickler(f, protocol=4).dump(v)
 
 
 class DeviceVecNormalize:
@@ -75,8 +154,14 @@ class DeviceVecNormalize:
         self.obs_count = stats["count"]
         self.ret_mean = torch.as_tensor(stats["ret_mean"], dtype=torch.float64, device=self.obs_mean.device)
         self.ret_var = torch.as_tensor(stats["ret_var"], dtype=torch.float64, device=self.obs_mean.device)
-        self.ret_count = stats["count"]
+        self.ret_count = stats.get("ret_count", stats["count"])
         return self
+
+    def stats(self):
+        """the dictionary load_vecnormalize_pkl returns, for save_vecnormalize_pkl"""
+        return {"obs_mean": self.obs_mean.cpu().numpy(), "obs_var": self.obs_var.cpu().numpy(), "count": float(self.obs_count),
+                "ret_mean": float(self.ret_mean), "ret_var": float(self.ret_var), "ret_count": float(self.ret_count),
+                "clip_obs": self.clip_obs, "clip_reward": self.clip_reward, "gamma": self.gamma, "epsilon": self.epsilon}
 
     @staticmethod
     def _update(mean, var, count, batch):
@@ -115,6 +200,7 @@ class MlpActorCritic(torch.nn.Module):
                 layers += [torch.nn.Linear(d, h), torch.nn.Tanh()]
                 d = h
             return torch.nn.Sequential(*layers)
+        self.pi_sizes, self.vf_sizes = tuple(pi), tuple(vf)
         self.policy_net, self.value_net_body = mlp(pi), mlp(vf)
         self.action_net = torch.nn.Linear(pi[-1], act_dim)
         self.value_net = torch.nn.Linear(vf[-1], 1)
@@ -131,6 +217,16 @@ class MlpActorCritic(torch.nn.Module):
             mapped[k2] = torch.as_tensor(v)
         self.load_state_dict(mapped)
         return self
+
+    def to_sb3_state_dict(self):
+        """state dict under the layer names of SB3's ActorCriticPolicy (the inverse of from_sb3_state_dict)"""
+        out = {}
+        for k, v in self.state_dict().items():
+            k2 = k.replace("value_net_body.", "mlp_extractor.value_net.")
+            if k2.startswith("policy_net."):
+                k2 = "mlp_extractor." + k2
+            out[k2] = v.detach().cpu().clone()
+        return out
 
     def forward(self, obs):
         return self.action_net(self.policy_net(obs)), self.value_net(self.value_net_body(obs)).squeeze(-1)
@@ -269,6 +365,11 @@ def collect_rollouts(env, policy, vecnorm, buffer, obs=None, episode_start=None,
         buffer.add(nobs, act, nrew, episode_start, value, logp)
         episode_start = done.bool().clone()
         obs = obs.clone()
-    _, last_value = policy.forward(vecnorm.normalize_obs(obs))
+    # SB3 bootstraps with the value of the stored, already normalised `_last_obs`: the statistics are not updated a second time
+    was_training, vecnorm.training = vecnorm.training, False
+    try:
+        _, last_value = policy.forward(vecnorm.normalize_obs(obs))
+    finally:
+        vecnorm.training = was_training
     buffer.compute_returns_and_advantage(last_value, done.bool())
     return obs, episode_start

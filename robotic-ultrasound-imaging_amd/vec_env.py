@@ -43,7 +43,7 @@ class UltrasoundVecEnv:
 
     metadata = {"render.modes": []}
 
-    def __init__(self, num_envs, device="cuda:0", seed=3, env_offset=0, monitor=True, **robosuite_kwargs):
+    def __init__(self, num_envs, device="cuda:0", seed=3, env_offset=0, monitor=True, report_truncation=False, **robosuite_kwargs):
         self.lib = _lib.load()
         if not robosuite_kwargs:
             robosuite_kwargs = default_robosuite_kwargs()
@@ -52,6 +52,9 @@ class UltrasoundVecEnv:
         self._dev = _dev_index(device)
         self.device = torch.device("cuda", self._dev)
         self._monitor = monitor
+        # The reference stack (robosuite GymWrapper + Monitor, src/rl.py:36-40) never emits "TimeLimit.truncated", so SB3 does not
+        # bootstrap horizon-end rewards there.  Opt in to get the key (gym TimeLimit convention) for other training set-ups.
+        self._report_truncation = bool(report_truncation)
         self._env_offset = int(env_offset)
         self._handle = C.c_void_p()
         self._create(seed)
@@ -262,7 +265,8 @@ class UltrasoundVecEnv:
                 infos[i]["terminal_observation"] = term[i].copy()
                 if self._monitor:                                # SB3 Monitor (src/rl.py:39)
                     infos[i]["episode"] = {"r": float(ep_r[i]), "l": int(ep_l[i]), "t": now}
-                infos[i]["TimeLimit.truncated"] = bool(ep_l[i] >= self.horizon)
+                if self._report_truncation:
+                    infos[i]["TimeLimit.truncated"] = bool(ep_l[i] >= self.horizon)
         return obs, rew, done, infos
 
     def step(self, actions):

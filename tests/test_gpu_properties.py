@@ -7,7 +7,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _env(usim, n, torso="soft", **kw):
-    return usim.UltrasoundVecEnv(n, device="cuda:0", seed=kw.pop("seed", 3), torso=torso, **usim.default_robosuite_kwargs(), **kw)
+    opts = dict(usim.default_robosuite_kwargs())
+    seed = kw.pop("seed", 3)
+    opts.update(kw)
+    return usim.UltrasoundVecEnv(n, device="cuda:0", seed=seed, torso=torso, **opts)
 
 
 def _rollout_hash(env, steps):
@@ -95,12 +98,20 @@ def test_vecenv_protocol_and_auto_reset(usim):
             ep = infos[i]["episode"]
             assert 1 <= ep["l"] <= 20 and 0 <= ep["r"] <= 12.0001 * ep["l"] and ep["t"] >= 0
             assert np.all(obs[i, 6:9] == 0) and obs[i, 10] == 0 and abs(obs[i, 11] + 0.04) < 1e-7    # reset observation returned
-            assert infos[i]["TimeLimit.truncated"] == (ep["l"] == 20)
+            assert "TimeLimit.truncated" not in infos[i]          # the reference stack never emits it (src/rl.py:36-40); opt-in below
         for i in np.nonzero(~done)[0][:4]:
             assert infos[i] == {}
         total_done += int(done.sum())
         assert done.all() == (k in (19, 39))      # the horizon ends every episode together
     assert total_done == 2 * n
+    env_t = usim.UltrasoundVecEnv(4, device="cuda:0", seed=11, torso="soft", report_truncation=True, **kw)
+    env_t.reset()
+    for k in range(20):
+        _, _, done_t, infos_t = env_t.step(np.stack([env_t.action_space.sample(rng) for _ in range(4)]))
+        for i in np.nonzero(done_t)[0]:
+            assert infos_t[i]["TimeLimit.truncated"] == (infos_t[i]["episode"]["l"] == 20)
+    assert done_t.all()
+    env_t.close()
     assert env.get_attr("horizon") == [20] * n and env.env_is_wrapped(object) == [False] * n
     with pytest.raises(ValueError):
         env.step(np.zeros((n, 5), dtype=np.float32))
@@ -254,3 +265,24 @@ def test_config3_global_batch_equals_its_shards(usim):
     assert not torch.isnan(rw[-1][0]).any()
     for e in (whole, first, last):
         e.close()
+
+
+def test_two_live_handles_with_different_torso_shapes_do_not_share_tables(usim):
+    """The lattice tables (element positions / axes, lattice inverse, shell ids) belong to the handle: a box-torso env steps the same
+    whether or not a cylinder-torso env was created after it on the same GPU (and vice versa)."""
+    def run(env, steps=40):
+        out = _rollout_hash(env, steps)
+        return torch.stack([o for o, _, _ in out]), env.contacts.clone()
+    box_alone = _env(usim, 128, use_box_torso=True)
+    ref_box, ref_box_con = run(box_alone); box_alone.close()
+    cyl_alone = _env(usim, 128, use_box_torso=False)
+    ref_cyl, ref_cyl_con = run(cyl_alone); cyl_alone.close()
+    assert not torch.equal(ref_box, ref_cyl)
+    box = _env(usim, 128, use_box_torso=True)
+    cyl = _env(usim, 128, use_box_torso=False)          # created while `box` is alive
+    got_box, got_box_con = run(box)
+    got_cyl, got_cyl_con = run(cyl)
+    again_box, _ = run(box)                              # and box again after the cylinder env has stepped
+    assert torch.equal(got_box, ref_box) and torch.equal(again_box, ref_box) and torch.equal(got_box_con, ref_box_con)
+    assert torch.equal(got_cyl, ref_cyl) and torch.equal(got_cyl_con, ref_cyl_con)
+    box.close(); cyl.close()
