@@ -1,0 +1,472 @@
+"""Lane-level model of the distributed arm mathematics of the 16-lanes-per-environment step kernel (test infrastructure).
+
+`plain_*` is the textbook formulation (serial chain, dense 7 x 7 algebra) in float64 numpy.  `Lanes` executes the algorithm of
+robotic-ultrasound-imaging_amd/csrc/usim_arm16.h the way the hardware does: every "register" is a vector over the 16 lanes of a
+group, and lanes exchange data only through the three DPP patterns the kernel uses (row broadcast of one lane, row shift right / left
+with a fill value for lanes that have no source) plus the two LDS transposes.  tests/test_arm_lane_algebra.py checks that both give the
+same numbers; the GPU parity tests then check the HIP transcription against the oracle.
+
+Robot chains are tables (`panda_chain`, `ur5e_chain`): per link a fixed transform from the parent link frame, a joint about the local
+z axis, mass, centre of mass and inertia in the link frame."""
+import numpy as np
+
+GRAV = 9.81
+NL = 16          # lanes of a group
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# robot chains
+# ------------------------------------------------------------------------------------------------------------------
+def _rx(k):      # rotation about x by k * 90 degrees
+    c, s = [(1, 0), (0, 1), (-1, 0), (0, -1)][k % 4]
+    return np.array([[1, 0, 0], [0, c, -s], [0, s, c]], dtype=float)
+
+
+def _rz(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=float)
+
+
+def _add_body(m_a, c_a, I_a, m_b, c_b, I_b):
+    m = m_a + m_b
+    c = (m_a * c_a + m_b * c_b) / m
+    I = I_a + I_b
+    for mm, cc in ((m_a, c_a), (m_b, c_b)):
+        d = cc - c
+        I = I + mm * (d @ d * np.eye(3) - np.outer(d, d))
+    return m, c, I
+
+
+def panda_chain():
+    """Panda + hand + ultrasound probe (the model of usim_api.hip build_model / usim_devmath.h): 7 links, link 7 carries the composite of
+    link7 + hand + probe.  Returns dict with per-link arrays and the end-effector constants in the link-7 frame."""
+    lpos = np.array([[0, 0, 0.333], [0, 0, 0], [0, -0.316, 0], [0.0825, 0, 0], [-0.0825, 0.384, 0], [0, 0, 0], [0.088, 0, 0]], dtype=float)
+    rotx = [0, -1, 1, 1, -1, 1, 1]
+    lcom = np.array([[0, 0, -0.07], [0, -0.1, 0], [0.04, 0, -0.05], [-0.04, 0.05, 0], [0, 0, -0.15], [0.06, 0, 0], [0, 0, 0]], dtype=float)
+    mass = np.array([3.0, 3.0, 2.0, 2.0, 2.0, 1.5, 0.0])
+    iso = np.array([0.3, 0.3, 0.2, 0.2, 0.2, 0.1, 0.0])
+    Rh = _rz(-np.pi / 4)
+    hand = np.array([0, 0, 0.107])
+    site7 = hand + Rh @ np.array([-0.004, -0.063, 0.128])
+    pcom7 = site7 + Rh @ np.array([0.0013, 0.021, -0.043])
+    pI7 = Rh @ np.diag([1.6e-3, 1.6e-3, 2.0e-4]) @ Rh.T
+    m, c, I = _add_body(0.5, np.array([0, 0, 0.08]), 0.05 * np.eye(3), 0.5, hand, 0.05 * np.eye(3))
+    m, c, I = _add_body(m, c, I, 1.0, pcom7, pI7)
+    mass[6] = m
+    lcom[6] = c
+    inertia = np.array([iso[i] * np.eye(3) for i in range(7)])
+    inertia[6] = I
+    return {"nj": 7, "lpos": lpos, "rfix": np.array([_rx(k) for k in rotx]), "lcom": lcom, "mass": mass, "inertia": inertia,
+            "site": site7, "site_rot": Rh, "hand": hand, "pcom": pcom7, "pI": pI7, "pmass": 1.0,
+            "qmin": np.array([-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973]),
+            "qmax": np.array([2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973]),
+            "taumax": np.array([80.0, 80, 80, 80, 12, 12, 12]),
+            "initq": np.array([0, np.pi / 16.0, 0, -np.pi / 2.0 - np.pi / 3.0, 0, np.pi - 0.2, np.pi / 4])}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# plain formulation (serial chain)
+# ------------------------------------------------------------------------------------------------------------------
+def plain_fk(ch, q):
+    nj = ch["nj"]
+    R, p = np.eye(3), np.zeros(3)
+    o, Rs, c = [], [], []
+    for i in range(nj):
+        p = p + R @ ch["lpos"][i]
+        R = R @ ch["rfix"][i] @ _rz(q[i])
+        o.append(p.copy()); Rs.append(R.copy()); c.append(p + R @ ch["lcom"][i])
+    Rs_ = R @ ch["site_rot"]
+    return {"o": np.array(o), "R": np.array(Rs), "z": np.array([r[:, 2] for r in Rs]), "c": np.array(c),
+            "x": p + R @ ch["site"], "S": Rs_, "hand": p + R @ ch["hand"]}
+
+
+def plain_dynamics(ch, K, qd):
+    """RNE with zero joint acceleration (gravity as base acceleration) and the mass matrix by CRBA about the base origin."""
+    nj = ch["nj"]
+    w, al, a, op = np.zeros(3), np.zeros(3), np.array([0, 0, GRAV]), np.zeros(3)
+    F, Nc = [], []
+    for i in range(nj):
+        r = K["o"][i] - op
+        a = a + np.cross(al, r) + np.cross(w, np.cross(w, r))
+        al = al + np.cross(w, K["z"][i]) * qd[i]
+        w = w + K["z"][i] * qd[i]
+        rc = K["c"][i] - K["o"][i]
+        ac = a + np.cross(al, rc) + np.cross(w, np.cross(w, rc))
+        Iw = K["R"][i] @ ch["inertia"][i] @ K["R"][i].T
+        Fi = ch["mass"][i] * ac
+        F.append(Fi); Nc.append(Iw @ al + np.cross(w, Iw @ w) + np.cross(K["c"][i], Fi))
+        op = K["o"][i]
+    w7, al7, a7 = w, al, a
+    bias = np.zeros(nj); M = np.zeros((nj, nj))
+    fa, na = np.zeros(3), np.zeros(3)
+    cm, chh, Io = 0.0, np.zeros(3), np.zeros((3, 3))
+    for i in reversed(range(nj)):
+        fa = fa + F[i]; na = na + Nc[i]
+        bias[i] = K["z"][i] @ (na - np.cross(K["o"][i], fa))
+        m, c = ch["mass"][i], K["c"][i]
+        cm += m; chh = chh + m * c
+        Io = Io + K["R"][i] @ ch["inertia"][i] @ K["R"][i].T + m * (c @ c * np.eye(3) - np.outer(c, c))
+        vo = np.cross(K["o"][i], K["z"][i])
+        n = Io @ K["z"][i] + np.cross(chh, vo)
+        f = vo * cm + np.cross(K["z"][i], chh)
+        for j in range(i + 1):
+            M[i, j] = M[j, i] = K["z"][j] @ n + np.cross(K["o"][j], K["z"][j]) @ f
+    return {"M": M, "bias": bias, "w7": w7, "al7": al7, "a7": a7}
+
+
+def plain_jacobian(K):
+    nj = len(K["o"])
+    J = np.zeros((6, nj))
+    for j in range(nj):
+        J[:3, j] = np.cross(K["z"][j], K["x"] - K["o"][j]); J[3:, j] = K["z"][j]
+    return J
+
+
+def plain_controller(ch, K, D, J, q, qd, q0, gpos, G, kp, kd, wrench_override=None):
+    """OSC_POSE torque with uncoupled position / orientation and the nullspace posture term (robosuite osc.py)."""
+    Minv = np.linalg.inv(D["M"])
+    Li = J @ Minv @ J.T
+    v6 = J @ qd
+    eo = 0.5 * (np.cross(K["S"][:, 0], G[:, 0]) + np.cross(K["S"][:, 1], G[:, 1]) + np.cross(K["S"][:, 2], G[:, 2]))
+    e = np.concatenate([gpos - K["x"], eo])
+    F = e * kp - v6 * kd
+    if wrench_override is not None:
+        F = np.asarray(wrench_override, dtype=float)
+    wr = np.concatenate([np.linalg.solve(Li[:3, :3], F[:3]), np.linalg.solve(Li[3:, 3:], F[3:])])
+    pt = 10.0 * (q0 - q) - 2.0 * np.sqrt(10.0) * qd
+    jb = np.linalg.solve(Li, J @ pt)
+    tau = D["bias"] + D["M"] @ pt + J.T @ (wr - jb)
+    return {"tau": np.clip(tau, -ch["taumax"], ch["taumax"]), "Li": Li, "Minv": Minv, "v6": v6}
+
+
+def plain_after_contact(ch, K, D, J, C, qd, q, W, dt, joint_damp=0.1):
+    """smooth + constrained acceleration, probe torque sensor, Euler step with the one-step implicit damping, hand velocity"""
+    qs = C["Minv"] @ (C["tau"] - D["bias"] - joint_damp * qd)
+    alpha = J @ qs
+    qacc = qs + C["Minv"] @ (J.T @ W)
+    aq = J @ qacc
+    alq = aq[3:]
+    R7, o7 = K["R"][-1], K["o"][-1]
+    al = D["al7"] + alq
+    a7 = D["a7"] + aq[:3] - np.cross(alq, K["x"] - o7)
+    rc = R7 @ ch["pcom"]
+    ac = a7 + np.cross(al, rc) + np.cross(D["w7"], np.cross(D["w7"], rc))
+    Ipw = R7 @ ch["pI"] @ R7.T
+    N = Ipw @ al + np.cross(D["w7"], Ipw @ D["w7"])
+    Fp = ac * ch["pmass"]
+    tw = N + np.cross(o7 + rc - K["x"], Fp) - W[3:]
+    tq = K["S"].T @ tw
+    xk = C["Minv"] @ qacc
+    rhs = qacc - dt * joint_damp * xk
+    qd_new = qd + dt * rhs
+    q_new = q + dt * qd_new
+    vs2 = J @ qd_new
+    hv = vs2[:3] + np.cross(vs2[3:], K["hand"] - K["x"])
+    return {"qs": qs, "alpha": alpha, "qacc": qacc, "tq": tq, "q": q_new, "qd": qd_new, "hv": hv}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# lane formulation: registers are vectors over the 16 lanes of a group
+# ------------------------------------------------------------------------------------------------------------------
+def bc(v, k):                      # DPP row_newbcast:k
+    return np.full(NL, v[k])
+
+
+def shr(v, d, old=0.0):            # DPP row_shr:d ; lanes without a source keep `old`
+    out = np.array(np.broadcast_to(old, (NL,)), dtype=float).copy()
+    out[d:] = v[:NL - d]
+    return out
+
+
+def shl(v, d, old=0.0):            # DPP row_shl:d
+    out = np.array(np.broadcast_to(old, (NL,)), dtype=float).copy()
+    out[:NL - d] = v[d:]
+    return out
+
+
+def qbc(v, k):                     # DPP quad_perm:[k,k,k,k]
+    return v[(np.arange(NL) // 4) * 4 + k]
+
+
+def prefix(v):                     # inclusive prefix sum over the row (three shifted adds)
+    for d in (1, 2, 4):
+        v = v + shr(v, d)
+    return v
+
+
+def suffix(v):                     # inclusive suffix sum over lanes 0..7 (lanes above hold zeros)
+    for d in (1, 2, 4):
+        v = v + shl(v, d)
+    return v
+
+
+def cross3(a, b):
+    return [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]
+
+
+TASK_LANE = [0, 1, 2, 4, 5, 6]     # lane that owns task-space row a (position rows in quad 0, orientation rows in quad 1)
+
+
+def lane_tables(ch):
+    """per-lane constants: lanes 0..nj-1 the links, lane 7 the eef site (child of the last link), the rest identity with zero mass
+    (the three-step scan reaches seven lanes back, so lane 7 is the last one that sees the whole chain)"""
+    nj = ch["nj"]
+    T = {"rfix": np.tile(np.eye(3), (NL, 1, 1)), "lpos": np.zeros((NL, 3)), "lcom": np.zeros((NL, 3)), "mass": np.zeros(NL),
+         "inertia": np.zeros((NL, 3, 3)), "joint": np.zeros(NL)}
+    for i in range(nj):
+        T["rfix"][i], T["lpos"][i], T["lcom"][i], T["mass"][i], T["inertia"][i], T["joint"][i] = ch["rfix"][i], ch["lpos"][i], ch["lcom"][i], ch["mass"][i], ch["inertia"][i], 1.0
+    assert nj <= 7                  # a shorter chain leaves identity links up to lane 6: the site stays in lane 7
+    T["rfix"][7], T["lpos"][7] = ch["site_rot"], ch["site"]
+    return T
+
+
+class Lanes:
+    """one group of 16 lanes stepping the arm mathematics of one environment"""
+
+    def __init__(self, ch):
+        self.ch, self.T = ch, lane_tables(ch)
+        self.nj = ch["nj"]
+        self.lane = np.arange(NL)
+
+    # ---- kinematics: world frame of every link by a scan over the composition of the local transforms ----
+    def fk(self, q):
+        T, nj = self.T, self.nj
+        ql = np.zeros(NL); ql[:nj] = q
+        s, c = np.sin(ql) * T["joint"], np.where(T["joint"] > 0, np.cos(ql), 1.0)
+        Rf = T["rfix"]
+        R = [[None] * 3 for _ in range(3)]            # R[r][col] lane vectors: local rotation = rfix * Rz(q)
+        for r in range(3):
+            R[r][0] = Rf[:, r, 0] * c + Rf[:, r, 1] * s
+            R[r][1] = Rf[:, r, 1] * c - Rf[:, r, 0] * s
+            R[r][2] = Rf[:, r, 2].copy()
+        p = [T["lpos"][:, r].copy() for r in range(3)]
+        for d in (1, 2, 4):
+            # T_l <- T_{l-d} o T_l ; lanes l < d read the identity (fill values of the shift)
+            RL = [[shr(R[r][k], d, 1.0 if r == k else 0.0) for k in range(3)] for r in range(3)]
+            pL = [shr(p[r], d, 0.0) for r in range(3)]
+            Rn = [[RL[r][0] * R[0][cc] + RL[r][1] * R[1][cc] + RL[r][2] * R[2][cc] for cc in range(3)] for r in range(3)]
+            pn = [pL[r] + RL[r][0] * p[0] + RL[r][1] * p[1] + RL[r][2] * p[2] for r in range(3)]
+            R, p = Rn, pn
+        self.R, self.o = R, p
+        self.z = [R[r][2] for r in range(3)]
+        self.rc = [R[r][0] * T["lcom"][:, 0] + R[r][1] * T["lcom"][:, 1] + R[r][2] * T["lcom"][:, 2] for r in range(3)]
+        self.c = [self.o[r] + self.rc[r] for r in range(3)]
+        # the site frame is lane 7's; the hand origin is a fixed point of the last link (every lane evaluates it on its own frame)
+        self.x = [bc(p[r], 7) for r in range(3)]
+        self.S = [[bc(R[r][k], 7) for k in range(3)] for r in range(3)]
+        hd = self.ch["hand"]
+        self.hand = [bc(p[r] + R[r][0] * hd[0] + R[r][1] * hd[1] + R[r][2] * hd[2], nj - 1) for r in range(3)]
+        return self
+
+    # ---- dynamics: RNE as prefix / suffix sums over the joint lanes, CRBA with suffix sums of the link inertias ----
+    def dynamics(self, qd):
+        T, nj = self.T, self.nj
+        qdl = np.zeros(NL); qdl[:nj] = qd
+        z, o, c, rc, R = self.z, self.o, self.c, self.rc, self.R
+        zq = [z[r] * qdl for r in range(3)]
+        w = [prefix(zq[r]) for r in range(3)]
+        wp = [w[r] - zq[r] for r in range(3)]                          # angular velocity of the parent link
+        dal = cross3(wp, zq)
+        al = [prefix(dal[r]) for r in range(3)]
+        alp = [al[r] - dal[r] for r in range(3)]
+        r_ = [o[r] - shr(o[r], 1, 0.0) for r in range(3)]
+        t1 = cross3(wp, r_)
+        t2 = cross3(alp, r_); t3 = cross3(wp, t1)
+        da = [t2[r] + t3[r] for r in range(3)]
+        da[2] = da[2] + np.where(self.lane == 0, GRAV, 0.0)           # gravity enters as the base acceleration
+        a = [prefix(da[r]) for r in range(3)]
+        u1 = cross3(w, rc)
+        u2 = cross3(al, rc); u3 = cross3(w, u1)
+        ac = [a[r] + u2[r] + u3[r] for r in range(3)]
+        F = [T["mass"] * ac[r] for r in range(3)]
+        # world inertia of every link: Iw = R I R^T (symmetric, six entries)
+        I = T["inertia"]
+        RI = [[R[r][0] * I[:, 0, k] + R[r][1] * I[:, 1, k] + R[r][2] * I[:, 2, k] for k in range(3)] for r in range(3)]
+        Iw = {}
+        for r in range(3):
+            for k in range(r, 3):
+                Iw[(r, k)] = RI[r][0] * R[k][0] + RI[r][1] * R[k][1] + RI[r][2] * R[k][2]
+        sym = lambda A, v: [A[(0, 0)] * v[0] + A[(0, 1)] * v[1] + A[(0, 2)] * v[2], A[(0, 1)] * v[0] + A[(1, 1)] * v[1] + A[(1, 2)] * v[2],
+                            A[(0, 2)] * v[0] + A[(1, 2)] * v[1] + A[(2, 2)] * v[2]]
+        Ial, Iww = sym(Iw, al), sym(Iw, w)
+        g = cross3(w, Iww); cf = cross3(c, F)
+        Nc = [Ial[r] + g[r] + cf[r] for r in range(3)]
+        fa = [suffix(F[r]) for r in range(3)]
+        na = [suffix(Nc[r]) for r in range(3)]
+        of = cross3(o, fa)
+        self.bias = z[0] * (na[0] - of[0]) + z[1] * (na[1] - of[1]) + z[2] * (na[2] - of[2])
+        self.w, self.al, self.a = w, al, a                              # lane nj-1 holds the last link's (torque sensor)
+        # composite inertia about the base origin
+        m = T["mass"]
+        cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2]
+        Io = {(0, 0): Iw[(0, 0)] + m * (cc - c[0] * c[0]), (0, 1): Iw[(0, 1)] - m * c[0] * c[1], (0, 2): Iw[(0, 2)] - m * c[0] * c[2],
+              (1, 1): Iw[(1, 1)] + m * (cc - c[1] * c[1]), (1, 2): Iw[(1, 2)] - m * c[1] * c[2], (2, 2): Iw[(2, 2)] + m * (cc - c[2] * c[2])}
+        cm = suffix(m)
+        chh = [suffix(m * c[r]) for r in range(3)]
+        Ic = {k: suffix(v) for k, v in Io.items()}
+        vo = cross3(o, z)
+        n1 = sym(Ic, z); n2 = cross3(chh, vo)
+        n = [n1[r] + n2[r] for r in range(3)]
+        f2 = cross3(z, chh)
+        f = [vo[r] * cm + f2[r] for r in range(3)]
+        self.vo = vo
+        # lower triangle of row i in lane i: M[i][j] = z_j . n_i + vo_j . f_i
+        Ml = [sum(bc(z[r], j) * n[r] + bc(vo[r], j) * f[r] for r in range(3)) for j in range(nj)]
+        # LDS symmetrisation: lane i writes M[i][j] to [i][j] and [j][i] (j <= i), then reads its full row
+        lds = np.zeros((8, 8))
+        for i in range(nj):
+            for j in range(i + 1):
+                lds[i, j] = lds[j, i] = Ml[j][i]
+        self.M = [np.concatenate([lds[:, j], np.zeros(8)]) for j in range(nj)]        # M[j]: entry j of every lane's row
+        for j in range(nj):
+            self.M[j][nj:] = 0.0                                                          # lanes that own no link: zero rows
+        return self
+
+    def inverse(self):
+        """in-place Gauss-Jordan inverse of the symmetric positive definite M, row i in lane i, no pivoting"""
+        nj = self.nj
+        A = [m.copy() for m in self.M]
+        for k in range(nj):
+            mk = (self.lane == k).astype(float)
+            p = bc(A[k], k)
+            rp = 1.0 / p
+            g = (A[k] - mk) * rp
+            A[k] = mk.copy()
+            for c in range(nj):
+                A[c] = A[c] - g * bc(A[c], k)
+        self.Minv = A
+        return self
+
+    def task_space(self):
+        nj = self.nj
+        z, o, x = self.z, self.o, self.x
+        d = [x[r] - o[r] for r in range(3)]
+        jv = cross3(z, d)
+        Jc = jv + [z[0], z[1], z[2]]                                    # column j of J in lane j: Jc[a]
+        for a in range(6):
+            Jc[a] = np.where(self.lane < nj, Jc[a], 0.0)
+        self.Jc = Jc
+        # X = Minv J^T : row i in lane i
+        X = [sum(self.Minv[j] * bc(Jc[a], j) for j in range(nj)) for a in range(6)]
+        self.X = X
+        # LDS transpose: J row a in task lane TASK_LANE[a]
+        lds = np.zeros((6, 8))
+        for j in range(nj):
+            for a in range(6):
+                lds[a, j] = Jc[a][j]
+        Jr = [np.zeros(NL) for _ in range(nj)]
+        for a in range(6):
+            for j in range(nj):
+                Jr[j][TASK_LANE[a]] = lds[a, j]
+        self.Jr = Jr                                                    # Jr[j] lane vector: J[a(lane)][j]
+        # Lambda^-1 row a in task lane: Li[b] = sum_j J[a][j] X[j][b]
+        self.Li = [sum(Jr[j] * bc(X[b], j) for j in range(nj)) for b in range(6)]
+        return self
+
+    def jrow_times(self, v):
+        """sum_j J[a][j] v_j for joint-lane vector v -> task lanes"""
+        return sum(self.Jr[j] * bc(v, j) for j in range(self.nj))
+
+    def jcol_times(self, t):
+        """sum_a J[a][j] t_a for task-lane vector t -> joint lanes"""
+        return sum(self.Jc[a] * bc(t, TASK_LANE[a]) for a in range(6))
+
+    def mat_times(self, A, v):
+        return sum(A[j] * bc(v, j) for j in range(self.nj))
+
+    def controller(self, q, qd, q0, gpos, G, kp, kd, wrench_override=None):
+        nj, lane = self.nj, self.lane
+        ql, qdl, q0l = (np.concatenate([np.asarray(v, dtype=float), np.zeros(NL - nj)]) for v in (q, qd, q0))
+        self.qdl = qdl
+        blk = (lane >= 4)
+        comp = lane % 4                                                 # component handled by a task lane
+        pick = lambda v: np.where(comp == 0, v[0], np.where(comp == 1, v[1], v[2]))
+        v6 = self.jrow_times(qdl)
+        S = self.S
+        eo_parts = [cross3([S[0][k], S[1][k], S[2][k]], [np.full(NL, G[0, k]), np.full(NL, G[1, k]), np.full(NL, G[2, k])]) for k in range(3)]
+        eo = [0.5 * (eo_parts[0][r] + eo_parts[1][r] + eo_parts[2][r]) for r in range(3)]
+        ep = [gpos[r] - self.x[r] for r in range(3)]
+        e = np.where(blk, pick(eo), pick(ep))
+        a_of_lane = np.where(blk, 3 + comp, comp).clip(0, 5)
+        kpl, kdl = np.asarray(kp)[a_of_lane], np.asarray(kd)[a_of_lane]
+        F = e * kpl - v6 * kdl
+        if wrench_override is not None:
+            F = np.asarray(wrench_override, dtype=float)[a_of_lane]
+        self.v6 = v6
+        # 3x3 block solves inside the quads (Gauss-Jordan on [B | F], rows in lanes 0..2 / 4..6)
+        # idle lanes (3, 7 and the upper half of the row) carry unit rows so that every quad has regular pivots
+        is_task = np.isin(lane, TASK_LANE)
+        B = [np.where(is_task, np.where(blk, self.Li[3 + c], self.Li[c]), (comp == c).astype(float)) for c in range(3)]
+        rhs = np.where(is_task, F, 0.0)
+        for k in range(3):
+            mk = (comp == k).astype(float)
+            p = qbc(B[k], k)
+            g = (B[k] - mk) / p
+            for c in range(k + 1, 3):
+                B[c] = B[c] - g * qbc(B[c], k)
+            rhs = rhs - g * qbc(rhs, k)
+        wr = rhs
+        # nullspace posture torque
+        pt = 10.0 * (q0l - ql) - 2.0 * np.sqrt(10.0) * qdl
+        y = self.mat_times(self.M, pt)
+        jb = self.jrow_times(pt)
+        A = [np.where(is_task, self.Li[c], 0.0) for c in range(6)]     # idle lanes: zero rows, never pivots
+        jb = np.where(is_task, jb, 0.0)
+        for k in range(6):
+            lk = TASK_LANE[k]
+            mk = (lane == lk).astype(float)
+            p = bc(A[k], lk)
+            g = (A[k] - mk) / p
+            for c in range(k + 1, 6):
+                A[c] = A[c] - g * bc(A[c], lk)
+            jb = jb - g * bc(jb, lk)
+        tau = self.bias + y + self.jcol_times(wr - jb)
+        tmax = np.concatenate([self.ch["taumax"], np.full(NL - nj, 1.0)])
+        self.tau = np.clip(tau, -tmax, tmax)
+        self.wr = wr
+        return self
+
+    def after_contact(self, q, qd, W, dt, joint_damp=0.1):
+        nj, ch = self.nj, self.ch
+        ql, qdl = (np.concatenate([np.asarray(v, dtype=float), np.zeros(NL - nj)]) for v in (q, qd))
+        qs = self.mat_times(self.Minv, self.tau - self.bias - joint_damp * qdl)
+        alpha = self.jrow_times(qs)
+        z0 = sum(self.Jc[a] * W[a] for a in range(6))
+        qacc = qs + self.mat_times(self.Minv, z0)
+        aq_t = self.jrow_times(qacc)
+        aq = [bc(aq_t, TASK_LANE[a]) for a in range(6)]
+        # torque sensor on the last link's own registers (lane nj-1); every lane runs the same code
+        R, o, w, al0, a0, x = self.R, self.o, self.w, self.al, self.a, self.x
+        alq = aq[3:]
+        al = [al0[r] + alq[r] for r in range(3)]
+        xo = [x[r] - o[r] for r in range(3)]
+        cx = cross3(alq, xo)
+        a7 = [a0[r] + aq[r] - cx[r] for r in range(3)]
+        pc = ch["pcom"]
+        rc = [R[r][0] * pc[0] + R[r][1] * pc[1] + R[r][2] * pc[2] for r in range(3)]
+        u1 = cross3(w, rc); u2 = cross3(al, rc); u3 = cross3(w, u1)
+        ac = [a7[r] + u2[r] + u3[r] for r in range(3)]
+        pI = ch["pI"]
+        def rot_inertia(v):
+            l = [R[0][k] * v[0] + R[1][k] * v[1] + R[2][k] * v[2] for k in range(3)]
+            t = [pI[k, 0] * l[0] + pI[k, 1] * l[1] + pI[k, 2] * l[2] for k in range(3)]
+            return [R[r][0] * t[0] + R[r][1] * t[1] + R[r][2] * t[2] for r in range(3)]
+        Ia, Iw_ = rot_inertia(al), rot_inertia(w)
+        g = cross3(w, Iw_)
+        Fp = [ac[r] * ch["pmass"] for r in range(3)]
+        arm = [o[r] + rc[r] - x[r] for r in range(3)]
+        cf = cross3(arm, Fp)
+        tw = [Ia[r] + g[r] + cf[r] - W[3 + r] for r in range(3)]
+        S = self.S
+        tq = [bc(S[0][k] * tw[0] + S[1][k] * tw[1] + S[2][k] * tw[2], nj - 1) for k in range(3)]
+        xk = self.mat_times(self.Minv, qacc)
+        rhs = qacc - dt * joint_damp * xk
+        qd_new = qdl + dt * rhs
+        q_new = ql + dt * qd_new
+        vs2_t = self.jrow_times(qd_new)
+        vs2 = [bc(vs2_t, TASK_LANE[a]) for a in range(6)]
+        hx = [self.hand[r] - x[r] for r in range(3)]
+        cw = cross3(vs2[3:], hx)
+        hv = [vs2[r] + cw[r] for r in range(3)]
+        return {"qs": qs[:nj], "alpha": np.array([alpha[TASK_LANE[a]] for a in range(6)]), "qacc": qacc[:nj],
+                "tq": np.array([t[0] for t in tq]), "q": q_new[:nj], "qd": qd_new[:nj], "hv": np.array([h[0] for h in hv])}

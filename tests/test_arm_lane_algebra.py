@@ -1,0 +1,80 @@
+"""CPU check of the lane-distributed arm mathematics (scan kinematics, prefix/suffix-sum Newton-Euler, composite inertia by suffix sums,
+row-per-lane Gauss-Jordan, task-space rows in lanes 0-2 / 4-6) against the serial-chain formulation, in float64.  The HIP code in
+robotic-ultrasound-imaging_amd/csrc/usim_arm16.h is a transcription of tests/arm_lanes_model.py::Lanes."""
+import numpy as np
+import pytest
+
+import arm_lanes_model as alm
+
+
+def _case(ch, rng):
+    nj = ch["nj"]
+    q = ch["initq"] + rng.normal(0, 0.3, nj)
+    q = np.clip(q, ch["qmin"] + 0.05, ch["qmax"] - 0.05)
+    qd = rng.normal(0, 0.8, nj)
+    q0 = ch["initq"] + rng.normal(0, 0.05, nj)
+    a = rng.normal(0, 1, 4); a /= np.linalg.norm(a)
+    w, x, y, z = a
+    G = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                  [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    kp = rng.uniform(0, 500, 6)
+    return q, qd, q0, G, kp, 2 * np.sqrt(kp), rng.normal(0, 3, 6)
+
+
+@pytest.mark.parametrize("robot", ["panda"])
+def test_lane_formulation_equals_the_serial_chain(robot):
+    ch = {"panda": alm.panda_chain}[robot]()
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        q, qd, q0, G, kp, kd, W = _case(ch, rng)
+        K = alm.plain_fk(ch, q)
+        D = alm.plain_dynamics(ch, K, qd)
+        J = alm.plain_jacobian(K)
+        gpos = K["x"] + rng.normal(0, 0.02, 3)
+        override = None if trial % 4 else rng.uniform(-10, 10, 6)
+        C = alm.plain_controller(ch, K, D, J, q, qd, q0, gpos, G, kp, kd, override)
+        P = alm.plain_after_contact(ch, K, D, J, C, qd, q, W, 0.002)
+
+        L = alm.Lanes(ch).fk(q)
+        nj = ch["nj"]
+        for r in range(3):
+            assert np.allclose(L.o[r][:nj], K["o"][:, r], atol=1e-12) and np.allclose(L.c[r][:nj], K["c"][:, r], atol=1e-12)
+            assert np.allclose(L.x[r], K["x"][r], atol=1e-12) and np.allclose(L.hand[r], K["hand"][r], atol=1e-12)
+            for k in range(3):
+                assert np.allclose(L.S[r][k], K["S"][r, k], atol=1e-12) and np.allclose(L.R[r][k][:nj], K["R"][:, r, k], atol=1e-12)
+        L.dynamics(qd)
+        assert np.allclose(L.bias[:nj], D["bias"], atol=1e-10)
+        Ml = np.array([[L.M[j][i] for j in range(nj)] for i in range(nj)])
+        assert np.allclose(Ml, D["M"], atol=1e-11)
+        for r in range(3):
+            assert np.isclose(L.w[r][nj - 1], D["w7"][r]) and np.isclose(L.al[r][nj - 1], D["al7"][r]) and np.isclose(L.a[r][nj - 1], D["a7"][r])
+        L.inverse()
+        Mi = np.array([[L.Minv[j][i] for j in range(nj)] for i in range(nj)])
+        assert np.allclose(Mi, C["Minv"], rtol=1e-8, atol=1e-9)
+        L.task_space()
+        Li = np.array([[L.Li[b][alm.TASK_LANE[a]] for b in range(6)] for a in range(6)])
+        assert np.allclose(Li, C["Li"], rtol=1e-8, atol=1e-10)
+        L.controller(q, qd, q0, gpos, G, kp, kd, override)
+        assert np.allclose(L.tau[:nj], C["tau"], rtol=1e-7, atol=1e-8)
+        assert np.allclose([L.v6[alm.TASK_LANE[a]] for a in range(6)], C["v6"], atol=1e-12)
+        out = L.after_contact(q, qd, W, 0.002)
+        for k in ("qs", "alpha", "qacc", "tq", "q", "qd", "hv"):
+            assert np.allclose(out[k], P[k], rtol=1e-7, atol=1e-8), k
+
+
+def test_plain_panda_model_matches_the_oracle_forward_quantities():
+    """the serial-chain reference of this file is the same arm model the C oracle implements (uso_debug_forward)"""
+    from oracle_lib import Oracle
+    ch = alm.panda_chain()
+    orc = Oracle(1, torso="none")
+    orc.reset()
+    q = orc.get_state()["q"][0]
+    dbg = orc.debug_forward(0)
+    K = alm.plain_fk(ch, q)
+    D = alm.plain_dynamics(ch, K, np.zeros(7))
+    base = np.array([-0.56, 0.0, 0.913])
+    assert np.allclose(K["x"] + base, dbg["x"], atol=1e-9)
+    assert np.allclose(K["S"], dbg["R"], atol=1e-9)
+    assert np.allclose(D["M"], dbg["M"], atol=1e-9)
+    assert np.allclose(D["bias"], dbg["bias"], atol=1e-9)
+    assert np.allclose(alm.plain_jacobian(K), dbg["J"], atol=1e-9)
