@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--randomize", action="store_true", help="BASELINE configs[4]: per-env randomised stiffness/damping + probe friction")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--lanes-per-env", type=int, default=0, choices=[0, 8, 16], help="soft-torso kernel mapping (0 = automatic)")
+    ap.add_argument("--lanes-per-env", type=int, default=0, choices=[0, 1, 8, 16], help="kernel mapping: 16 lanes per environment (automatic), 8 (soft torso) or 1 (rigid torso)")
     args = ap.parse_args()
 
     import torch
@@ -96,11 +96,11 @@ def main():
     extra = {"friction_randomization": 1} if args.randomize else {}
     with_gather = use_dist and not args.no_gather
     if with_gather and args.workload == "soft" and args.lanes_per_env == 0:
-        # With 16 lanes per environment the step kernel fills every SIMD of the chip (1024 waves, whole register file each); the
-        # resident workgroups of the overlapped all-gather would then push part of every step into a second round (measured with a
-        # stand-in kernel: 29 -> 45-49 us/step, tools/gpu_interference.py).  8 lanes per environment leave half of the SIMDs to
-        # the collective: 31 us/step with or without it.
-        extra["lanes_per_env"] = 8
+        # At 4096 envs the step kernel holds one wave on every SIMD of the chip.  With the register budget of one wave per SIMD the
+        # resident workgroups of the overlapped all-gather push part of every step into a second round (measured with a stand-in
+        # kernel of RCCL's footprint, tools/gpu_interference.py: 21.8 -> 33-36 us/step); with the budget of two waves per SIMD the
+        # displaced workgroups double up on other CUs instead (22.7 us alone, 25.7-28.7 us next to the stand-in).
+        extra["waves_per_simd"] = 2
     elif args.lanes_per_env:
         extra["lanes_per_env"] = args.lanes_per_env
     env = usim.UltrasoundVecEnv(n, device=device, seed=3, env_offset=rank * n, torso=args.workload, **extra, **usim.default_robosuite_kwargs())
@@ -175,11 +175,11 @@ def main():
             "config": {"workload": WORKLOAD_NAME[args.workload], "envs_per_gpu": n, "global_envs": n * world,
                        "controller": "OSC_POSE impedance_mode=tracking", "rollout_block": T, "domain_randomisation": "stiffness+damping" + ("+friction" if args.randomize else ""),
                        "parallelism": f"env-shard x{world}" + (" + RCCL all-gather of transition blocks" if gather is not None else ""),
-                       "lanes_per_env": int(extra.get("lanes_per_env", 0)) or ("auto" if args.workload == "soft" else 1)},
+                       "lanes_per_env": int(extra.get("lanes_per_env", 0)) or 16, "waves_per_simd": int(extra.get("waves_per_simd", 0)) or "auto"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": "profiles/r01/traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch)" if traffic else None,
                          "algorithmic_bytes_per_launch": ALGO_BYTES[args.workload] * n, "algorithmic_bytes_per_env_step": ALGO_BYTES[args.workload],
-                         "avg_kernel_us": avg_kernel_s * 1e6, "kernel": "usim_step_kernel",
+                         "avg_kernel_us": avg_kernel_s * 1e6, "kernel": "usim_step16_kernel" if int(extra.get("lanes_per_env", 0)) in (0, 16) else "usim_step_kernel",
                          "valu_fp32_tflops": valu_tflops, "valu_frac": valu_tflops / FP32_VALU_PEAK_TFLOPS,
                          "note": "kernel is FP32-VALU/latency bound at 4096 envs (one wave per SIMD), not HBM bound; see DESIGN.md section 5"},
         }

@@ -48,6 +48,8 @@ typedef enum usim_status {
 enum { USIM_MODE_TRACKING = 0, USIM_MODE_FIXED = 1, USIM_MODE_VARIABLE_Z = 2, USIM_MODE_WRENCH = 3 };
 /* torso model: BASELINE.json configs[1] (rigid, contact solver off) / configs[2] (soft torso) */
 enum { USIM_TORSO_NONE = 0, USIM_TORSO_TOP = 1 };
+/* robots (ultrasound.py:137) */
+enum { USIM_ROBOT_PANDA = 0, USIM_ROBOT_UR5E = 1 };
 
 /* Mirrors the `robosuite:` block of src/rl_config.yaml:18-57 (the kwargs of Ultrasound.__init__,
  * ultrasound.py:99-136) plus the knobs the MJCF assets fix in the reference. */
@@ -61,11 +63,14 @@ typedef struct usim_config {
     int32_t initial_probe_pos_randomization;   /* rl_config.yaml:56 */
     int32_t friction_randomization;            /* BASELINE.json configs[4] */
     int32_t torso_drop;                        /* reproduce the 4.7 mm spawn drop (ultrasound.py:313) */
-    int32_t pgs_iters;                         /* contact PGS sweeps per forward pass */
+    int32_t pgs_iters;                         /* contact PGS sweeps per forward pass (default 6: converged to float32 resolution) */
     int32_t ik_iters;                          /* reset inverse-kinematics iterations */
     int32_t env_offset;                        /* global index of env 0 of this handle (multi-GPU shard) */
-    int32_t lanes_per_env;                     /* soft-torso kernel mapping: 0 auto, 8 or 16 lanes per environment */
+    int32_t lanes_per_env;                     /* kernel mapping: 0 auto (16), 16 lanes per environment (arm mathematics distributed over the group), 8 (soft torso;
+                                                * arm mathematics replicated per lane) or 1 (rigid torso: one environment per lane) */
     int32_t torso_shape;                       /* use_box_torso (rl_config.yaml:57): 0 box (soft_box.xml), 1 cylinder (soft_human_torso.xml) */
+    int32_t waves_per_simd;                    /* 16-lane step kernel: register budget for 1 or 2 waves per SIMD; 0 auto (1 up to 4096 envs, 2 beyond) */
+    int32_t robot;                             /* USIM_ROBOT_*: robots of ultrasound.py:137 */
     uint64_t seed;                             /* rl_config.yaml:1 */
     double control_dt;                         /* 1 / control_freq (rl_config.yaml:26) */
     double kp_fixed, damping_ratio;            /* rl_config.yaml:38-39 */

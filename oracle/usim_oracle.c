@@ -1089,7 +1089,7 @@ void uso_default_config(uso_config* c) {
     memset(c, 0, sizeof *c);
     c->mode = USO_MODE_TRACKING; c->torso = USO_TORSO_TOP; c->horizon = 1000; c->early_termination = 1;
     c->deterministic_trajectory = 0; c->torso_solref_randomization = 1; c->initial_probe_pos_randomization = 1;
-    c->friction_randomization = 0; c->torso_drop = 1; c->pgs_iters = 8; c->ik_iters = 5; c->env_offset = 0;
+    c->friction_randomization = 0; c->torso_drop = 1; c->pgs_iters = 6; c->ik_iters = 5; c->env_offset = 0;
     c->seed = 3; c->control_dt = 0.002; c->kp_fixed = 300; c->damping_ratio = 1; c->kp_min = 0; c->kp_max = 500;
     c->out_max_pos = 0.05; c->out_max_ori = 0.5; c->stiffness = 1324.17; c->damping = 17.59;
     c->elem_friction = 0.01; c->probe_friction = 1e-4;

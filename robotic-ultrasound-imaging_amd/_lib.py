@@ -25,7 +25,7 @@ class UsimConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "mode", "torso", "horizon", "early_termination", "deterministic_trajectory", "torso_solref_randomization",
         "initial_probe_pos_randomization", "friction_randomization", "torso_drop", "pgs_iters", "ik_iters", "env_offset",
-        "lanes_per_env", "torso_shape")] + \
+        "lanes_per_env", "torso_shape", "waves_per_simd", "robot")] + \
         [("seed", C.c_uint64)] + [(n, C.c_double) for n in (
             "control_dt", "kp_fixed", "damping_ratio", "kp_min", "kp_max", "out_max_pos", "out_max_ori", "stiffness", "damping",
             "elem_friction", "probe_friction", "probe_radius", "probe_halflen")]

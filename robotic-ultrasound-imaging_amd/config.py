@@ -12,7 +12,7 @@ _IGNORED = {
     "initialization_noise", "placement_initializer", "ignore_done", "hard_reset",
 }
 # extensions of this build (not kwargs of the reference env)
-_NATIVE = {"torso", "friction_randomization", "torso_drop", "pgs_iters", "ik_iters", "lanes_per_env", "stiffness", "damping",
+_NATIVE = {"torso", "friction_randomization", "torso_drop", "pgs_iters", "ik_iters", "lanes_per_env", "waves_per_simd", "stiffness", "damping",
            "elem_friction", "probe_friction", "probe_radius", "probe_halflen"}
 
 
@@ -90,7 +90,7 @@ def make_config(seed=3, env_offset=0, **kw):
     if torso not in _lib.TORSO:
         raise ValueError(f"torso must be one of {sorted(_lib.TORSO)}")
     c.torso = _lib.TORSO[torso]
-    for k in ("friction_randomization", "torso_drop", "pgs_iters", "ik_iters", "lanes_per_env"):
+    for k in ("friction_randomization", "torso_drop", "pgs_iters", "ik_iters", "lanes_per_env", "waves_per_simd", "waves_per_simd"):
         if k in kw:
             setattr(c, k, int(kw.pop(k)))
     for k in ("stiffness", "damping", "elem_friction", "probe_friction", "probe_radius", "probe_halflen"):

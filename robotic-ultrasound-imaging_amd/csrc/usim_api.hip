@@ -21,7 +21,7 @@ using namespace usim;
 
 struct usim_handle {
     usim_config cfg;
-    int n = 0, npad = 0, device = 0, adim = 6, n_el = 0, nfields = 0, lpe = 1;
+    int n = 0, npad = 0, device = 0, adim = 6, n_el = 0, nfields = 0, lpe = 1, occ = 1;
     DevModel M;
     DevCfg C;
     float* state = nullptr;
@@ -32,7 +32,7 @@ struct usim_handle {
     int* d_count = nullptr;           // [0] items, [1] finished workgroups of the running refill
     long long steps_since_refill = 0;
     int bank_row0 = 0;
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0, lds16_bytes = 0;
     std::string hip_err;
 };
 
@@ -112,6 +112,49 @@ std::vector<double> invert(std::vector<double> a, int n) {
 }
 }  // namespace
 
+// per-handle copy of the table block (synchronous: complete before usim_create returns, so no stream of the caller can race with it)
+static int upload_tables(usim_handle* h, const std::vector<float>& tb) {
+    HIPCHK(h, hipMalloc(&h->d_tables, tb.size() * sizeof(float)));
+    HIPCHK(h, hipMemcpy(h->d_tables, tb.data(), tb.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->M.tables = h->d_tables;
+    return USIM_OK;
+}
+
+// Arm table of the 16-lane step kernel (usim_device.h ArmTable): the Panda chain of usim_devmath.h as per-lane records.  Link i: fixed
+// translation, fixed rotation about x by ROTX[i] * 90 deg, joint about the local z axis; link 7 carries the composite of link7 + hand +
+// probe (DevModel m7 / c7 / I7); lane 7 is the end-effector site (site7, link-7 frame rotated by -45 deg about z).
+static void build_arm_table(const DevModel& M, float* tb) {
+    static const double lpos[NJ][3] = {{0, 0, 0.333}, {0, 0, 0}, {0, -0.316, 0}, {0.0825, 0, 0}, {-0.0825, 0.384, 0}, {0, 0, 0}, {0.088, 0, 0}};
+    static const int rotx[NJ] = {0, -1, 1, 1, -1, 1, 1};
+    static const double lcom[NJ][3] = {{0, 0, -0.07}, {0, -0.1, 0}, {0.04, 0, -0.05}, {-0.04, 0.05, 0}, {0, 0, -0.15}, {0.06, 0, 0}, {0, 0, 0}};
+    static const double lmass[NJ] = {3, 3, 2, 2, 2, 1.5, 0}, liso[NJ] = {0.3, 0.3, 0.2, 0.2, 0.2, 0.1, 0};
+    static const double qmin[NJ] = {-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973};
+    static const double qmax[NJ] = {2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973};
+    static const double taumax[NJ] = {80, 80, 80, 80, 12, 12, 12};
+    static const double initq[NJ] = {0.0, 0.19634954084936207, 0.0, -2.6179938779914944, 0.0, 2.941592653589793, 0.7853981633974483};
+    for (int l = 0; l < A16_LANES; ++l) {
+        float* r = tb + l * AT_STRIDE;
+        for (int k = 0; k < AT_STRIDE; ++k) r[k] = 0.f;
+        r[AT_RFIX + 0] = 1.f; r[AT_RFIX + 4] = 1.f; r[AT_RFIX + 8] = 1.f;      // identity columns
+        r[AT_QMIN] = -1.0e30f; r[AT_QMAX] = 1.0e30f; r[AT_TAUMAX] = 1.0f;
+        if (l < NJ) {
+            // rotation about x by rotx * 90 deg: columns x = (1,0,0), y = (0,c,s), z = (0,-s,c)
+            const double c = rotx[l] == 0 ? 1.0 : 0.0, sn = (double)rotx[l];
+            r[AT_RFIX + 3] = 0.f; r[AT_RFIX + 4] = (float)c; r[AT_RFIX + 5] = (float)sn;
+            r[AT_RFIX + 6] = 0.f; r[AT_RFIX + 7] = (float)-sn; r[AT_RFIX + 8] = (float)c;
+            for (int k = 0; k < 3; ++k) { r[AT_LPOS + k] = (float)lpos[l][k]; r[AT_LCOM + k] = (l < NJ - 1) ? (float)lcom[l][k] : M.c7[k]; }
+            r[AT_MASS] = (l < NJ - 1) ? (float)lmass[l] : M.m7;
+            if (l < NJ - 1) { r[AT_INERTIA + 0] = r[AT_INERTIA + 3] = r[AT_INERTIA + 5] = (float)liso[l]; }
+            else for (int k = 0; k < 6; ++k) r[AT_INERTIA + k] = M.I7[k];
+            r[AT_QMIN] = (float)qmin[l]; r[AT_QMAX] = (float)qmax[l]; r[AT_TAUMAX] = (float)taumax[l]; r[AT_INITQ] = (float)initq[l];
+        } else if (l == 7) {
+            const double h = 0.70710678118654752;                                 // Rz(-45 deg): columns (h,-h,0), (h,h,0), (0,0,1)
+            r[AT_RFIX + 0] = (float)h; r[AT_RFIX + 1] = (float)-h; r[AT_RFIX + 3] = (float)h; r[AT_RFIX + 4] = (float)h;
+            for (int k = 0; k < 3; ++k) r[AT_LPOS + k] = M.site7[k];
+        }
+    }
+}
+
 static int build_model(usim_handle* h) {
     DevModel& M = h->M;
     std::memset(&M, 0, sizeof M);
@@ -150,9 +193,12 @@ static int build_model(usim_handle* h) {
     M.wfix = (float)(dmax / (1 - dmax));
     M.wten = (float)(0.5 * dmax / (1 - dmax));
 
+    // one table block per handle: [lattice tables (soft torso) | arm table], laid out as the kernels read it
+    std::vector<float> tb(TB_TOTAL, 0.f);
+    build_arm_table(M, &tb[TB_ARM]);
     // ---- torso lattice: top face (iy = 3) of the 9 x 4 x 11 shell, shell ids in creation order ----
     h->n_el = (h->cfg.torso == USIM_TORSO_TOP) ? N_TOP : 0;
-    if (h->n_el == 0) return USIM_OK;
+    if (h->n_el == 0) return upload_tables(h, tb);
     std::vector<float> elpos(N_TOP * 3), elaxis(N_TOP * 3);
     std::vector<int> nbr(N_TOP * 4, -2), shell(N_TOP);
     int sid = 0, top_index[9][11];
@@ -186,16 +232,11 @@ static int build_model(usim_handle* h) {
         for (int d = 0; d < nn; ++d) if (nbr[e * 4 + d] >= 0) L[(size_t)e * N_TOP + nbr[e * 4 + d]] = -0.5 * dmax / (1 - dmax);
     }
     std::vector<double> Li = invert(L, N_TOP);
-    // one table block, laid out exactly as the kernels' workgroup-resident LDS copy
-    std::vector<float> tb(TB_WORDS, 0.f);
+    // lattice part: laid out exactly as the kernels' workgroup-resident LDS copy
     for (int i = 0; i < N_TOP; ++i) for (int j = 0; j < N_TOP; ++j) tb[TB_LINV + (size_t)i * LROW + j] = (float)Li[(size_t)i * N_TOP + j];
     for (int i = 0; i < N_TOP * 3; ++i) { tb[TB_POS + i] = elpos[i]; tb[TB_AXIS + i] = elaxis[i]; }
     std::memcpy(&tb[TB_SHELL], shell.data(), shell.size() * sizeof(int));
-    // per-handle copy (synchronous: complete before usim_create returns, so no stream of the caller can race with it)
-    HIPCHK(h, hipMalloc(&h->d_tables, tb.size() * sizeof(float)));
-    HIPCHK(h, hipMemcpy(h->d_tables, tb.data(), tb.size() * sizeof(float), hipMemcpyHostToDevice));
-    M.tables = h->d_tables;
-    return USIM_OK;
+    return upload_tables(h, tb);
 }
 
 template <int TORSO, int G, int MODE>
@@ -205,11 +246,24 @@ static hipError_t launch_step(usim_handle* h, const DevIO& io, int flags, long l
     return hipGetLastError();
 }
 
+template <int TORSO, int OCC>
+static hipError_t launch_step16(usim_handle* h, const DevIO& io, int flags, long long rstep, hipStream_t s) {
+    dim3 grid((h->n + 15) / 16), block(256);
+    hipLaunchKernelGGL((usim_step16_kernel<TORSO, OCC>), grid, block, h->lds16_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
+    return hipGetLastError();
+}
+
 template <int MODE>
 static int launch(usim_handle* h, DevIO io, int flags, long long rstep, hipStream_t s) {
     io.bank_row0 = h->bank_row0;
     hipError_t e;
-    if (!h->n_el) e = launch_step<0, 1, MODE>(h, io, flags, rstep, s);
+    // steps with 16 lanes per environment run the kernel with the distributed arm mathematics (usim_step16.h); reset computations and the
+    // 8-lane / one-lane mappings run the kernels of usim_kernels.hip
+    if (MODE == 0 && h->lpe == 16) {
+        if (!h->n_el) e = launch_step16<0, 2>(h, io, flags, rstep, s);
+        else e = (h->occ == 1) ? launch_step16<1, 1>(h, io, flags, rstep, s) : launch_step16<1, 2>(h, io, flags, rstep, s);
+    }
+    else if (!h->n_el) e = launch_step<0, 1, MODE>(h, io, flags, rstep, s);
     else if (h->lpe == 8) e = launch_step<1, 8, MODE>(h, io, flags, rstep, s);
     else e = launch_step<1, 16, MODE>(h, io, flags, rstep, s);
     if (e != hipSuccess) { h->hip_err = std::string("usim_step_kernel launch: ") + hipGetErrorString(e); return USIM_ERR_HIP; }
@@ -223,7 +277,7 @@ int usim_default_config(usim_config* c) {
     std::memset(c, 0, sizeof *c);
     c->mode = USIM_MODE_TRACKING; c->torso = USIM_TORSO_TOP; c->horizon = 1000; c->early_termination = 1;
     c->deterministic_trajectory = 0; c->torso_solref_randomization = 1; c->initial_probe_pos_randomization = 1;
-    c->friction_randomization = 0; c->torso_drop = 1; c->pgs_iters = 8; c->ik_iters = 5; c->env_offset = 0; c->lanes_per_env = 0; c->torso_shape = 0; c->seed = 3;
+    c->friction_randomization = 0; c->torso_drop = 1; c->pgs_iters = 6; c->ik_iters = 5; c->env_offset = 0; c->lanes_per_env = 0; c->torso_shape = 0; c->waves_per_simd = 0; c->robot = 0; c->seed = 3;
     c->control_dt = 0.002; c->kp_fixed = 300; c->damping_ratio = 1; c->kp_min = 0; c->kp_max = 500; c->out_max_pos = 0.05; c->out_max_ori = 0.5;
     c->stiffness = 1324.17; c->damping = 17.59; c->elem_friction = 0.01; c->probe_friction = 1e-4; c->probe_radius = 0.04; c->probe_halflen = 0.02;
     return USIM_OK;
@@ -233,7 +287,7 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
     if (!cfg || !out || n_envs <= 0) return USIM_ERR_INVALID;
     if (cfg->mode < 0 || cfg->mode > 3 || cfg->torso < 0 || cfg->torso > 1 || cfg->horizon <= 0 || cfg->control_dt <= 0 ||
         cfg->probe_halflen < 1e-4 || cfg->probe_radius <= 0 || cfg->pgs_iters < 0 || cfg->ik_iters < 0 || cfg->torso_shape < 0 ||
-        cfg->torso_shape > 1) return USIM_ERR_INVALID;
+        cfg->torso_shape > 1 || cfg->waves_per_simd < 0 || cfg->waves_per_simd > 2 || cfg->robot != 0) return USIM_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return USIM_ERR_NO_DEVICE;
     usim_handle* h = new (std::nothrow) usim_handle();
@@ -270,8 +324,16 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
     // kernel mapping: rigid torso -> one environment per lane; soft torso -> 8 or 16 lanes per
     // environment.  The step kernel needs the whole register file of a SIMD (one wave per SIMD), so the mapping that
     // yields about 1024 waves wins: 16 lanes up to 4096 envs/GPU (one 4-wave workgroup per CU), 8 lanes beyond.
-    h->lpe = h->n_el ? (cfg->lanes_per_env == 0 ? (n_envs <= 4096 ? 16 : 8) : cfg->lanes_per_env) : 1;
-    if (h->n_el && h->lpe != 8 && h->lpe != 16) return USIM_ERR_INVALID;
+    // (superseded for steps by the 16-lane kernel of usim_step16.h, which is the automatic choice at every batch size; 8 lanes on request)
+    // Rigid torso: 16 lanes per environment (arm mathematics distributed over the group) or, with lanes_per_env = 1, one lane each.
+    h->lpe = h->n_el ? (cfg->lanes_per_env == 0 ? 16 : cfg->lanes_per_env) : (cfg->lanes_per_env == 0 ? 16 : cfg->lanes_per_env);
+    if (h->n_el ? (h->lpe != 8 && h->lpe != 16) : (h->lpe != 1 && h->lpe != 16)) return USIM_ERR_INVALID;
+    h->occ = cfg->waves_per_simd ? cfg->waves_per_simd : (n_envs <= 4096 ? 1 : 2);
+    h->lds16_bytes = h->n_el ? (size_t)GroupGeom<16>::LDS_WORDS * sizeof(float) : (size_t)16 * X16_RIGID_STRIDE * sizeof(float);
+    if (h->n_el) {
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step16_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds16_bytes));
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step16_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds16_bytes));
+    }
     h->lds_bytes = 0;
     if (h->n_el) {
         h->lds_bytes = (size_t)(h->lpe == 8 ? GroupGeom<8>::LDS_WORDS : GroupGeom<16>::LDS_WORDS) * sizeof(float);

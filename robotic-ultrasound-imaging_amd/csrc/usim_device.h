@@ -37,6 +37,14 @@ __host__ __device__ inline size_t scalar_index(int f, size_t i) { return i * F_N
 constexpr int LAT_ENV_WORDS = 200, LAT_S = 0, LAT_SD = 100;
 static_assert(F_TOTAL_TOP == F_LAT + LAT_ENV_WORDS && LAT_SD + N_TOP <= LAT_ENV_WORDS, "lattice region");
 
+// arm table (16-lane step kernel, usim_step16.h): one record per lane of a group.  Lanes 0 .. nj-1 own the links of the chain (fixed transform
+// from the parent link frame, joint about the local z axis, inertial parameters in the link frame), lane 7 owns the end-effector site frame
+// (a fixed child of the last link), the other lanes carry identity transforms without mass.
+constexpr int A16_LANES = 16;
+enum ArmTable : int { AT_RFIX = 0 /* 9: columns x, y, z of the fixed rotation */, AT_LPOS = 9 /* 3 */, AT_LCOM = 12 /* 3 */, AT_MASS = 15,
+                      AT_INERTIA = 16 /* 6: xx xy xz yy yz zz about the COM, link frame */, AT_QMIN = 22, AT_QMAX = 23, AT_TAUMAX = 24,
+                      AT_INITQ = 25, AT_STRIDE = 28 };
+
 // model constants (host-built in fp64, narrowed once; passed to the kernels by value -> kernarg/SGPRs)
 struct DevModel {
     float m7, c7[3], I7[6];         // link-7 composite (link7 + hand + probe): mass, COM, inertia about COM (xx,xy,xz,yy,yz,zz), link-7 frame

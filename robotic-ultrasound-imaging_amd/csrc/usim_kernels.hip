@@ -39,6 +39,8 @@ constexpr int TB_POS = N_TOP * LROW;                  // float [99][3] nominal s
 constexpr int TB_AXIS = TB_POS + 300;                 // float [99][3] slide axis
 constexpr int TB_SHELL = TB_AXIS + 300;               // int   [99]    shell id (contact-pair index convention)
 constexpr int TB_WORDS = TB_SHELL + 100;              // 10600 words (the lattice topology itself is implicit: 9 x 11 grid stencil)
+constexpr int TB_ARM = TB_WORDS;                      // behind the lattice block (not copied to LDS): the arm table of the 16-lane step kernel
+constexpr int TB_TOTAL = TB_ARM + A16_LANES * AT_STRIDE;
 
 // per-environment LDS block (word offsets); GE_X must stay 16-byte aligned
 constexpr int GE_X = 0;                               // rhs[100] of the lattice solve
@@ -92,6 +94,15 @@ DI float group_bcast(float v, int k) {
     return __int_as_float(iv);
 }
 #undef USIM_BCAST_CASE
+
+// phase timeline probe (diagnostics only; profiling build): wave 0 of workgroup 0 stamps the shader clock when a buffer is given
+#if !defined(USIM_TSTAMP) && !defined(USIM_TSTAMP_NOWAIT)
+#define USIM_STAMP(dbg, k) do { } while (0)
+#elif defined(USIM_TSTAMP_NOWAIT)
+#define USIM_STAMP(dbg, k) do { if ((dbg) && blockIdx.x == 0 && threadIdx.x == 0) (dbg)[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define USIM_STAMP(dbg, k) do { if ((dbg) && blockIdx.x == 0 && threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); (dbg)[k] = __builtin_readcyclecounter(); } } while (0)
+#endif
 
 // prescribed torso base motion: free fall over the 4.7 mm spawn gap, then rest (ultrasound.py:313)
 DI void torso_motion(const DevCfg& C, int tsim, float& dz, float& vz, float& az) {
@@ -298,6 +309,148 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
     return nc;
 #undef EBF
 #undef LSTAMP
+}
+
+// Contact solve of one forward pass (called when some environment of the wave has a contact): contact k of an environment lives in the
+// registers of lane k of its group.  Inputs: contact records in LDS (lattice_front), element indices cel[], the site-space operator
+// Lambda^-1 (packed lower 6 x 6), the site acceleration / velocity of the unconstrained arm (alpha, vs).  Outputs: net contact wrench on the
+// site W[6] (accumulated) and the impulse gf[k] along each contact's element axis.
+template <int G>
+DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M, const DevCfg& C, const int nc, const int ncmax, const int* cel,
+                      const float* Li, const float* alpha, const float* vs, const float mu, const float vz, float* W, float* gf,
+                      unsigned long long* dbg) {
+#define EB(off) lds[TB_WORDS + eb * GE_STRIDE + (off)]
+    // ---- contact k lives in the registers of lane k of its group.  Set-up: row directions w, Lambda^-1 w, element
+    //      coupling g, reference acceleration, regulariser; Km[c] = Linv[e_own][e_c] / m ----
+    const bool own = gl < nc;
+    float w[3][6], Liw[3][6], g[3], invD[3], Rd[3], f[3] = {0.f, 0.f, 0.f}, cres[3] = {0.f, 0.f, 0.f}, Km[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) Km[c] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        g[d] = 0.f; invD[d] = 0.f; Rd[d] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { w[d][a] = 0.f; Liw[d][a] = 0.f; }
+    }
+    if (own) {
+        const int b = GE_CG + gl * CG_WORDS;
+        f3 nn = mk(EB(b + 0), EB(b + 1), EB(b + 2)), rr = mk(EB(b + 3), EB(b + 4), EB(b + 5));
+        const int e = __float_as_int(EB(b + 6));
+        const float dist = EB(b + 7);
+        f3 ref = (fabsf(nn.x) > 0.9f) ? mk(0, 1, 0) : mk(1, 0, 0);
+        f3 t1 = cross(nn, ref); t1 = t1 * rsq_(dot(t1, t1));
+        f3 t2 = cross(nn, t1);
+        f3 ax = mk(lds[TB_AXIS + 3 * e], lds[TB_AXIS + 3 * e + 1], lds[TB_AXIS + 3 * e + 2]);
+        const float sde = EB(GE_SD + e);
+        const float bcon = 2.0f / (SI_DMAX * SR_TC);
+        float xx = fminf(-dist * (1.0f / SI_WIDTH), 1.f);
+        float yy = (xx < 0.5f) ? 2.f * xx * xx : 1.f - 2.f * (1.f - xx) * (1.f - xx);
+        float dimp = SI_D0 + yy * (SI_DMAX - SI_D0);
+        float kk = dimp * (1.0f / (SI_DMAX * SI_DMAX * SR_TC * SR_TC));
+        float Rn = (1.f - dimp) * rcp_(dimp) * M.invw;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) if (c < nc) Km[c] = lds[TB_LINV + e * LROW + cel[c]] * (1.0f / ELEM_MASS);
+        const float ae0 = EB(GE_A + e);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            f3 dir = (d == 0) ? nn : (d == 1 ? t1 : t2);
+            f3 rx = cross(rr, dir);
+            w[d][0] = dir.x; w[d][1] = dir.y; w[d][2] = dir.z; w[d][3] = rx.x; w[d][4] = rx.y; w[d][5] = rx.z;
+            g[d] = -dot(dir, ax);
+            float vrel = g[d] * sde - dir.z * vz, wa = 0.f;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                float s = 0.f;
+#pragma unroll
+                for (int bb = 0; bb < 6; ++bb) s = fmaf((a >= bb) ? Li[PK(a, bb)] : Li[PK(bb, a)], w[d][bb], s);
+                Liw[d][a] = s;
+                vrel = fmaf(w[d][a], vs[a], vrel);
+                wa = fmaf(w[d][a], alpha[a], wa);
+            }
+            const float aref = -bcon * vrel - (d == 0 ? kk * dist : 0.f);
+            Rd[d] = (d == 0) ? Rn : Rn * (1.0f / IMPRATIO);
+            cres[d] = fmaf(g[d], ae0, wa) - aref;             // residual of row d at zero force
+        }
+    }
+    USIM_STAMP(dbg, 9);
+    // ---- Delassus blocks: B[k][d][d'] = d(residual of row d of this lane's contact) / d(force on row d' of contact k)
+    //      = w_d . Lambda^-1 w^k_d' + g_d Km[k] g^k_d' (+ the regulariser on the diagonal of the lane's own block).  Lane k
+    //      shares Lambda^-1 w^k and g^k through DPP once; the sweeps below then need three broadcasts per visit. ----
+    float B[MAXC][3][3];            // B[k] is written and read only under k < ncmax
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+        if (k < ncmax) {
+            float gk[3];
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) gk[dd] = group_bcast<G>(g[dd], k) * Km[k];
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) {
+                float Lk[6];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) Lk[a] = group_bcast<G>(Liw[dd][a], k);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    float r1 = fmaf(w[d][4], Lk[4], fmaf(w[d][2], Lk[2], w[d][0] * Lk[0]));
+                    float r2 = fmaf(w[d][5], Lk[5], fmaf(w[d][3], Lk[3], w[d][1] * Lk[1]));
+                    B[k][d][dd] = fmaf(g[d], gk[dd], r1 + r2);
+                }
+            }
+            if (gl == k && own) {            // lanes without a contact keep invD = 0: their solve below yields zeros
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { B[k][d][d] += Rd[d]; invD[d] = rcp_(B[k][d][d]); }
+            }
+        }
+    }
+    // ---- projected Gauss-Seidel on the dual over the contact rows (fixed sweeps, cold start).  Contacts are visited in
+    //      ascending order.  The owner relaxes its three rows in order (normal, t1, t2; the earlier rows' updates enter
+    //      through its own block), projects on the cone and shares the three force increments; every lane then moves its
+    //      residuals by its block for that contact. ----
+    for (int it = 0; it < C.pgs_iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) {
+            if (k < ncmax) {
+                // every lane runs the solve on its own rows (no divergence); only lane k's increments are shared and kept
+                const float f0n = fmaxf(fmaf(-cres[0], invD[0], f[0]), 0.f);
+                float d0 = f0n - f[0];
+                const float d1u = -fmaf(B[k][1][0], d0, cres[1]) * invD[1];
+                const float d2u = -fmaf(B[k][2][1], d1u, fmaf(B[k][2][0], d0, cres[2])) * invD[2];
+                float t1 = f[1] + d1u, t2 = f[2] + d2u;
+                // elliptic cone: |f_t| <= mu f_n
+                const float ft2 = fmaf(t1, t1, t2 * t2), lim = mu * f0n;
+                const float sc = (ft2 > lim * lim) ? lim * rsq_(ft2) : 1.0f;
+                t1 *= sc; t2 *= sc;
+                float d1 = t1 - f[1], d2 = t2 - f[2];
+                const bool mine = gl == k;
+                f[0] = mine ? f0n : f[0]; f[1] = mine ? t1 : f[1]; f[2] = mine ? t2 : f[2];
+                d0 = group_bcast<G>(d0, k); d1 = group_bcast<G>(d1, k); d2 = group_bcast<G>(d2, k);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) cres[d] = fmaf(B[k][d][2], d2, fmaf(B[k][d][1], d1, fmaf(B[k][d][0], d0, cres[d])));
+            }
+        }
+    }
+    USIM_STAMP(dbg, 10);
+    // ---- contact wrench on the site and impulse along each element axis: the first MAXC lanes publish (lanes without a
+    //      contact hold w = g = f = 0, i.e. publish zeros), everyone sums the slots the wave uses ----
+    if (gl < MAXC) {
+        f3 Fw = mk(w[0][0] * f[0] + w[1][0] * f[1] + w[2][0] * f[2], w[0][1] * f[0] + w[1][1] * f[1] + w[2][1] * f[2],
+                   w[0][2] * f[0] + w[1][2] * f[1] + w[2][2] * f[2]);
+        f3 Tw = mk(w[0][3] * f[0] + w[1][3] * f[1] + w[2][3] * f[2], w[0][4] * f[0] + w[1][4] * f[1] + w[2][4] * f[2],
+                   w[0][5] * f[0] + w[1][5] * f[1] + w[2][5] * f[2]);
+        const int b = GE_WS + gl * 8;
+        EB(b + 0) = Fw.x; EB(b + 1) = Fw.y; EB(b + 2) = Fw.z; EB(b + 3) = Tw.x; EB(b + 4) = Tw.y; EB(b + 5) = Tw.z;
+        EB(b + 6) = (g[0] * f[0] + g[1] * f[1] + g[2] * f[2]) * (1.0f / ELEM_MASS);
+    }
+    group_sync();
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+        if (k < ncmax) {
+            const int b = GE_WS + k * 8;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) W[a] += EB(b + a);
+            gf[k] = EB(b + 6);
+        }
+    }
+#undef EB
 }
 
 struct StepOut {               // results of one forward pass that the env logic needs
@@ -715,136 +868,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                         alpha[a] = s; vs[a] = u;
                     }
                     TSTAMP(8);
-                    // ---- contact k lives in the registers of lane k of its group.  Set-up: row directions w, Lambda^-1 w, element
-                    //      coupling g, reference acceleration, regulariser; Km[c] = Linv[e_own][e_c] / m ----
-                    const bool own = gl < nc;
-                    float w[3][6], Liw[3][6], g[3], invD[3], Rd[3], f[3] = {0.f, 0.f, 0.f}, cres[3] = {0.f, 0.f, 0.f}, Km[MAXC];
-#pragma unroll
-                    for (int c = 0; c < MAXC; ++c) Km[c] = 0.f;
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        g[d] = 0.f; invD[d] = 0.f; Rd[d] = 0.f;
-#pragma unroll
-                        for (int a = 0; a < 6; ++a) { w[d][a] = 0.f; Liw[d][a] = 0.f; }
-                    }
-                    if (own) {
-                        const int b = GE_CG + gl * CG_WORDS;
-                        f3 nn = mk(EB(b + 0), EB(b + 1), EB(b + 2)), rr = mk(EB(b + 3), EB(b + 4), EB(b + 5));
-                        const int e = __float_as_int(EB(b + 6));
-                        const float dist = EB(b + 7);
-                        f3 ref = (fabsf(nn.x) > 0.9f) ? mk(0, 1, 0) : mk(1, 0, 0);
-                        f3 t1 = cross(nn, ref); t1 = t1 * rsq_(dot(t1, t1));
-                        f3 t2 = cross(nn, t1);
-                        f3 ax = mk(lds[TB_AXIS + 3 * e], lds[TB_AXIS + 3 * e + 1], lds[TB_AXIS + 3 * e + 2]);
-                        const float sde = EB(GE_SD + e);
-                        const float bcon = 2.0f / (SI_DMAX * SR_TC);
-                        float xx = fminf(-dist * (1.0f / SI_WIDTH), 1.f);
-                        float yy = (xx < 0.5f) ? 2.f * xx * xx : 1.f - 2.f * (1.f - xx) * (1.f - xx);
-                        float dimp = SI_D0 + yy * (SI_DMAX - SI_D0);
-                        float kk = dimp * (1.0f / (SI_DMAX * SI_DMAX * SR_TC * SR_TC));
-                        float Rn = (1.f - dimp) * rcp_(dimp) * M.invw;
-#pragma unroll
-                        for (int c = 0; c < MAXC; ++c) if (c < nc) Km[c] = lds[TB_LINV + e * LROW + cel[c]] * (1.0f / ELEM_MASS);
-                        const float ae0 = EB(GE_A + e);
-#pragma unroll
-                        for (int d = 0; d < 3; ++d) {
-                            f3 dir = (d == 0) ? nn : (d == 1 ? t1 : t2);
-                            f3 rx = cross(rr, dir);
-                            w[d][0] = dir.x; w[d][1] = dir.y; w[d][2] = dir.z; w[d][3] = rx.x; w[d][4] = rx.y; w[d][5] = rx.z;
-                            g[d] = -dot(dir, ax);
-                            float vrel = g[d] * sde - dir.z * vz, wa = 0.f;
-#pragma unroll
-                            for (int a = 0; a < 6; ++a) {
-                                float s = 0.f;
-#pragma unroll
-                                for (int bb = 0; bb < 6; ++bb) s = fmaf((a >= bb) ? Li[PK(a, bb)] : Li[PK(bb, a)], w[d][bb], s);
-                                Liw[d][a] = s;
-                                vrel = fmaf(w[d][a], vs[a], vrel);
-                                wa = fmaf(w[d][a], alpha[a], wa);
-                            }
-                            const float aref = -bcon * vrel - (d == 0 ? kk * dist : 0.f);
-                            Rd[d] = (d == 0) ? Rn : Rn * (1.0f / IMPRATIO);
-                            cres[d] = fmaf(g[d], ae0, wa) - aref;             // residual of row d at zero force
-                        }
-                    }
-                    TSTAMP(9);
-                    // ---- Delassus blocks: B[k][d][d'] = d(residual of row d of this lane's contact) / d(force on row d' of contact k)
-                    //      = w_d . Lambda^-1 w^k_d' + g_d Km[k] g^k_d' (+ the regulariser on the diagonal of the lane's own block).  Lane k
-                    //      shares Lambda^-1 w^k and g^k through DPP once; the sweeps below then need three broadcasts per visit. ----
-                    float B[MAXC][3][3];            // B[k] is written and read only under k < ncmax
-#pragma unroll
-                    for (int k = 0; k < MAXC; ++k) {
-                        if (k < ncmax) {
-                            float gk[3];
-#pragma unroll
-                            for (int dd = 0; dd < 3; ++dd) gk[dd] = group_bcast<G>(g[dd], k) * Km[k];
-#pragma unroll
-                            for (int dd = 0; dd < 3; ++dd) {
-                                float Lk[6];
-#pragma unroll
-                                for (int a = 0; a < 6; ++a) Lk[a] = group_bcast<G>(Liw[dd][a], k);
-#pragma unroll
-                                for (int d = 0; d < 3; ++d) {
-                                    float r1 = fmaf(w[d][4], Lk[4], fmaf(w[d][2], Lk[2], w[d][0] * Lk[0]));
-                                    float r2 = fmaf(w[d][5], Lk[5], fmaf(w[d][3], Lk[3], w[d][1] * Lk[1]));
-                                    B[k][d][dd] = fmaf(g[d], gk[dd], r1 + r2);
-                                }
-                            }
-                            if (gl == k && own) {            // lanes without a contact keep invD = 0: their solve below yields zeros
-#pragma unroll
-                                for (int d = 0; d < 3; ++d) { B[k][d][d] += Rd[d]; invD[d] = rcp_(B[k][d][d]); }
-                            }
-                        }
-                    }
-                    // ---- projected Gauss-Seidel on the dual over the contact rows (fixed sweeps, cold start).  Contacts are visited in
-                    //      ascending order.  The owner relaxes its three rows in order (normal, t1, t2; the earlier rows' updates enter
-                    //      through its own block), projects on the cone and shares the three force increments; every lane then moves its
-                    //      residuals by its block for that contact. ----
-                    for (int it = 0; it < C.pgs_iters; ++it) {
-#pragma unroll
-                        for (int k = 0; k < MAXC; ++k) {
-                            if (k < ncmax) {
-                                // every lane runs the solve on its own rows (no divergence); only lane k's increments are shared and kept
-                                const float f0n = fmaxf(fmaf(-cres[0], invD[0], f[0]), 0.f);
-                                float d0 = f0n - f[0];
-                                const float d1u = -fmaf(B[k][1][0], d0, cres[1]) * invD[1];
-                                const float d2u = -fmaf(B[k][2][1], d1u, fmaf(B[k][2][0], d0, cres[2])) * invD[2];
-                                float t1 = f[1] + d1u, t2 = f[2] + d2u;
-                                // elliptic cone: |f_t| <= mu f_n
-                                const float ft2 = fmaf(t1, t1, t2 * t2), lim = mu * f0n;
-                                const float sc = (ft2 > lim * lim) ? lim * rsq_(ft2) : 1.0f;
-                                t1 *= sc; t2 *= sc;
-                                float d1 = t1 - f[1], d2 = t2 - f[2];
-                                const bool mine = gl == k;
-                                f[0] = mine ? f0n : f[0]; f[1] = mine ? t1 : f[1]; f[2] = mine ? t2 : f[2];
-                                d0 = group_bcast<G>(d0, k); d1 = group_bcast<G>(d1, k); d2 = group_bcast<G>(d2, k);
-#pragma unroll
-                                for (int d = 0; d < 3; ++d) cres[d] = fmaf(B[k][d][2], d2, fmaf(B[k][d][1], d1, fmaf(B[k][d][0], d0, cres[d])));
-                            }
-                        }
-                    }
-                    TSTAMP(10);
-                    // ---- contact wrench on the site and impulse along each element axis: the first MAXC lanes publish (lanes without a
-                    //      contact hold w = g = f = 0, i.e. publish zeros), everyone sums the slots the wave uses ----
-                    if (gl < MAXC) {
-                        f3 Fw = mk(w[0][0] * f[0] + w[1][0] * f[1] + w[2][0] * f[2], w[0][1] * f[0] + w[1][1] * f[1] + w[2][1] * f[2],
-                                   w[0][2] * f[0] + w[1][2] * f[1] + w[2][2] * f[2]);
-                        f3 Tw = mk(w[0][3] * f[0] + w[1][3] * f[1] + w[2][3] * f[2], w[0][4] * f[0] + w[1][4] * f[1] + w[2][4] * f[2],
-                                   w[0][5] * f[0] + w[1][5] * f[1] + w[2][5] * f[2]);
-                        const int b = GE_WS + gl * 8;
-                        EB(b + 0) = Fw.x; EB(b + 1) = Fw.y; EB(b + 2) = Fw.z; EB(b + 3) = Tw.x; EB(b + 4) = Tw.y; EB(b + 5) = Tw.z;
-                        EB(b + 6) = (g[0] * f[0] + g[1] * f[1] + g[2] * f[2]) * (1.0f / ELEM_MASS);
-                    }
-                    group_sync();
-#pragma unroll
-                    for (int k = 0; k < MAXC; ++k) {
-                        if (k < ncmax) {
-                            const int b = GE_WS + k * 8;
-#pragma unroll
-                            for (int a = 0; a < 6; ++a) W[a] += EB(b + a);
-                            gf[k] = EB(b + 6);
-                        }
-                    }
+                    contact_solve<G>(lds, eb, gl, M, C, nc, ncmax, cel, Li, alpha, vs, mu, vz, W, gf, io.dbg);
                 }
                 TSTAMP(11);
                 // ---- element accelerations a = a~ + Linv[:, e_c] gf_c, semi-implicit Euler, write back ----
@@ -1177,3 +1201,5 @@ __global__ void usim_invweight_kernel(const DevModel M, float* out) {
 }
 
 }  // namespace usim
+
+#include "usim_step16.h"

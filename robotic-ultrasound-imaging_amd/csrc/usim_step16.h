@@ -1,0 +1,661 @@
+// usim_step16.h -- step kernel with the arm mathematics of an environment DISTRIBUTED over the 16 lanes of its group (one DPP row).
+//
+// The first step kernel (usim_kernels.hip) replicates the 7-DoF arm mathematics in all lanes of a group: at 4096 envs/GPU every SIMD holds
+// one wave, the kernel is bound by VALU issue slots, and 4.1 k of its 7 k instructions per wave-step are that replicated stream.  Here a lane
+// owns one link (joint space, lanes 0 .. nj-1) and / or one task-space row (lanes 0-2 position, 4-6 orientation); lane 7 owns the
+// end-effector site frame.  Lanes exchange data with DPP row operations only (row_newbcast, row_shr / row_shl, quad_perm) plus two 8 x 8
+// transposes through LDS:
+//   * kinematics: the world frame of every link is a prefix SCAN over the composition of the local link transforms (three shifted steps);
+//   * Newton-Euler bias forces: angular velocity / acceleration and origin acceleration are prefix SUMS of per-link terms, the force and
+//     moment accumulation is a suffix sum;
+//   * mass matrix (composite rigid body): suffix sums of the link inertias about the base origin; lane i forms row i from the axes of
+//     lanes j <= i (row broadcasts), the upper triangle comes back through the LDS transpose;
+//   * M^-1 by an in-place Gauss-Jordan sweep with row i in lane i (no pivoting: M is symmetric positive definite);
+//   * operational space: lane j keeps column j of the site Jacobian, task lane a keeps row a (LDS transpose), Lambda^-1 = J M^-1 J^T row a
+//     in task lane a; the two 3 x 3 solves of the uncoupled controller run inside the quads, the 6 x 6 nullspace solve across the six task
+//     lanes (Gauss-Jordan on [A | b] again);
+//   * every M^-1 / J / J^T product afterwards is "own row times broadcast vector".
+// The algorithm is modelled lane by lane in tests/arm_lanes_model.py and checked there against the serial chain.  The robot is a table
+// (DevModel::tables + TB_ARM, usim_device.h ArmTable): per lane the fixed transform to the parent link frame, a joint about the local z axis,
+// inertial parameters in the link frame -- the kernel is the same for every chain of up to seven joints.
+//
+// Lattice / contact phases (soft torso) are the ones of usim_kernels.hip (lattice_front, contact_solve): the G = 16 mapping is unchanged there.
+#pragma once
+#include <type_traits>
+
+namespace usim {
+
+template <int N, class F>
+DI void static_for(F&& f) {
+    if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
+}
+
+// ---- DPP row primitives (a row = 16 lanes = the group of one environment) ----
+template <int CTRL>
+DI float dpp0(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
+template <int K> DI float rbc(float v) { return dpp0<0x150 + K>(v); }                 // value of lane K of the row, in every lane
+template <int D> DI float rshr0(float v) { return dpp0<0x110 + D>(v); }               // value of lane l - D (0 for l < D)
+template <int D> DI float rshl0(float v) { return dpp0<0x100 + D>(v); }               // value of lane l + D (0 beyond the row)
+template <int D> DI float rshr(float v, float fill) {                                  // value of lane l - D (`fill` for l < D)
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x110 + D, 0xf, 0xf, false));
+}
+template <int K> DI float qbc(float v) { return dpp0<K * 0x55>(v); }                  // value of lane K of the quad
+template <int K> DI f3 rbc3(f3 v) { return mk(rbc<K>(v.x), rbc<K>(v.y), rbc<K>(v.z)); }
+DI float prefix_sum(float v) { v += rshr0<1>(v); v += rshr0<2>(v); v += rshr0<4>(v); return v; }     // inclusive, over lanes l-7 .. l
+DI float suffix_sum(float v) { v += rshl0<1>(v); v += rshl0<2>(v); v += rshl0<4>(v); return v; }     // inclusive, over lanes l .. l+7
+DI f3 prefix_sum(f3 v) { return mk(prefix_sum(v.x), prefix_sum(v.y), prefix_sum(v.z)); }
+DI f3 suffix_sum(f3 v) { return mk(suffix_sum(v.x), suffix_sum(v.y), suffix_sum(v.z)); }
+DI f3 symmul6(const float* I, f3 v) { return symmul(I, v); }
+
+constexpr int TASK_LANE[6] = {0, 1, 2, 4, 5, 6};      // lane that owns task-space row a: position rows in quad 0, orientation rows in quad 1
+
+// ---- fused DPP arithmetic.  The compiler folds a row shift into v_add_f32_dpp by itself but keeps a broadcast feeding a multiply-add as
+// v_mov_b32_dpp + v_fmac_f32 (the accumulator of v_fmac is tied to the destination, which its DPP combiner does not model), so the
+// "own row times broadcast vector" products are written out: one v_fmac_f32_dpp per term.  A DPP source written by the VALU instruction
+// right before needs two wait states, and the hazard recogniser does not look inside inline assembly: every block opens with s_nop 1. ----
+#define USIM_DPP_BC(K) " row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
+// sum_j A[j] * (value of v in lane j), j = 0 .. 6: own row times a vector that lives one component per joint lane
+DI float row_times_joint7(const float* A, float v) {
+    float s;
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %1, %2" USIM_DPP_BC(0) "v_fmac_f32_dpp %0, %1, %3" USIM_DPP_BC(1) "v_fmac_f32_dpp %0, %1, %4" USIM_DPP_BC(2)
+        "v_fmac_f32_dpp %0, %1, %5" USIM_DPP_BC(3) "v_fmac_f32_dpp %0, %1, %6" USIM_DPP_BC(4) "v_fmac_f32_dpp %0, %1, %7" USIM_DPP_BC(5)
+        "v_fmac_f32_dpp %0, %1, %8" USIM_DPP_BC(6)
+        : "=&v"(s) : "v"(v), "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(A[5]), "v"(A[6]));
+    return s;
+}
+template <int NJ_>
+DI float row_times_joint(const float* A, float v) {
+    static_assert(NJ_ == 7, "seven joint lanes");
+    return row_times_joint7(A, v);
+}
+// sum_a A[a] * (value of t in task lane a), task lanes 0 1 2 4 5 6
+DI float col_times_task(const float* A, float t) {
+    float s;
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %1, %2" USIM_DPP_BC(0) "v_fmac_f32_dpp %0, %1, %3" USIM_DPP_BC(1) "v_fmac_f32_dpp %0, %1, %4" USIM_DPP_BC(2)
+        "v_fmac_f32_dpp %0, %1, %5" USIM_DPP_BC(4) "v_fmac_f32_dpp %0, %1, %6" USIM_DPP_BC(5) "v_fmac_f32_dpp %0, %1, %7" USIM_DPP_BC(6)
+        : "=&v"(s) : "v"(t), "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(A[5]));
+    return s;
+}
+// A[c] += (value of A[c] in lane K) * f  for the seven entries of a row (Gauss-Jordan row update: the pivot row is lane K's)
+template <int K>
+DI void row_axpy_bc7(float* A, float f) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %0, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %1, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %2, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %3, %3, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %4, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %5, %5, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %6, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf"
+        : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]) : "v"(f), "n"(K));
+}
+// z . n + vo . f with (z, vo) taken from lane K: entry K of this lane's row of the mass matrix
+template <int K>
+DI float spatial_dot_bc(f3 z, f3 vo, f3 n, f3 f) {
+    float s;
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %1, %7 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %8 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %3, %9 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %4, %10 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %5, %11 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %6, %12 row_newbcast:%13 row_mask:0xf bank_mask:0xf"
+        : "=&v"(s) : "v"(z.x), "v"(z.y), "v"(z.z), "v"(vo.x), "v"(vo.y), "v"(vo.z), "v"(n.x), "v"(n.y), "v"(n.z), "v"(f.x), "v"(f.y), "v"(f.z), "n"(K));
+    return s;
+}
+
+// per-environment LDS scratch of the two transposes: 8 x 8 words
+constexpr int X16_WORDS = 64;
+constexpr int X16_RIGID_STRIDE = 68;                  // rigid-torso launches: one block of 68 words per environment (68 mod 32 = 4)
+
+// OCC = waves per SIMD the register allocation aims at.  1: the whole register file for one wave (no spills; the choice up to 4096 envs/GPU,
+// where every SIMD holds one wave anyway).  2: 256 registers per lane (the soft-torso kernel then keeps ~27 values in scratch): beyond 4096
+// envs/GPU two waves share a SIMD and fill each other's stalls (8192 envs: 28.6 us/step against 37.4 us in two rounds of one wave).
+template <int TORSO, int OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void usim_step16_kernel(const DevModel M, const DevCfg C, float* __restrict__ st, int n, int npad, const DevIO io,
+                                                          int flags, long long rstep) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int G = 16, EPW = 4, EPB = 16, NT = 256;
+    constexpr int NE = TORSO ? (N_TOP + G - 1) / G : 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = lane & 15, ge = lane >> 4;
+    const int gbase = lane - gl;
+    const int eb = wave * EPW + ge;
+    const int env = blockIdx.x * EPB + eb;
+    const bool valid = env < n;
+    const bool store = valid && gl == 0;
+    const int ei = valid ? env : n - 1;
+    const bool auto_reset = (flags & LF_AUTO_RESET) != 0;
+    unsigned long long* const dbg = io.dbg;
+#define LAT(w) st[(size_t)F_LAT * npad + (size_t)ei * LAT_ENV_WORDS + (w)]
+#define EB(off) lds[TB_WORDS + eb * GE_STRIDE + (off)]
+#define BK(slot, f) st[(size_t)io.bank_row0 * npad + ((size_t)ei * BANK_DEPTH + (slot)) * BANK_STRIDE + (f)]
+#define BKI(slot, f) (reinterpret_cast<int*>(st))[(size_t)io.bank_row0 * npad + ((size_t)ei * BANK_DEPTH + (slot)) * BANK_STRIDE + (f)]
+    float* const xl = TORSO ? &lds[TB_WORDS + eb * GE_STRIDE + GE_WS] : &lds[eb * X16_RIGID_STRIDE];       // transpose scratch of this environment
+    static_assert(GE_WS + X16_WORDS <= GE_STRIDE, "transpose scratch overlays the wrench records");
+
+    if constexpr (TORSO != 0) {
+        // workgroup-resident copy of the lattice tables: 16-byte loads, all issued before the first LDS store
+        const float4* src = reinterpret_cast<const float4*>(M.tables);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        constexpr int NV = TB_WORDS / 4, PER = (NV + NT - 1) / NT;
+        float4 tmp[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { int idx = threadIdx.x + i * NT; tmp[i] = (idx < NV) ? src[idx] : make_float4(0, 0, 0, 0); }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { int idx = threadIdx.x + i * NT; if (idx < NV) dst[idx] = tmp[i]; }
+        __syncthreads();
+    }
+    USIM_STAMP(dbg, 0);
+
+    // ---------------- load: this lane's link record, its joint state, the environment's scalars ----------------
+    float at[AT_STRIDE];
+    {
+        const float4* ap = reinterpret_cast<const float4*>(M.tables + TB_ARM + gl * AT_STRIDE);
+#pragma unroll
+        for (int v = 0; v < AT_STRIDE / 4; ++v) { const float4 x = ap[v]; at[4 * v] = x.x; at[4 * v + 1] = x.y; at[4 * v + 2] = x.z; at[4 * v + 3] = x.w; }
+    }
+    const float* const sp = st + scalar_index(0, (size_t)ei);
+    const bool jlane = gl < NJ;                                   // lanes that own a joint
+    const int jl = jlane ? gl : NJ - 1;
+    float qj = sp[F_Q + jl], qdj = sp[F_QD + jl], q0j = sp[F_Q0 + jl];
+    if (!jlane) { qj = 0.f; qdj = 0.f; q0j = 0.f; }
+    float sv[20];                                                  // scalar words 20 .. 39
+    {
+        const float4* s4 = reinterpret_cast<const float4*>(sp + 20);
+#pragma unroll
+        for (int v = 0; v < 5; ++v) { const float4 x = s4[v]; sv[4 * v] = x.x; sv[4 * v + 1] = x.y; sv[4 * v + 2] = x.z; sv[4 * v + 3] = x.w; }
+    }
+#define SV(f) sv[(f) - 20]
+    f3 ts = mk(SV(F_TS), SV(F_TS + 1), SV(F_TS + 2)), te = mk(SV(F_TE), SV(F_TE + 1), SV(F_TE + 2));
+    float u0 = SV(F_U0), vbar = SV(F_VBAR), fzbar = SV(F_FZBAR), fzprev = SV(F_FZPREV), dfz = SV(F_DFZ);
+    float kst = SV(F_KST), kdmp = SV(F_KDMP), mu = SV(F_MU), epret = SV(F_EPRET);
+    int t = __float_as_int(SV(F_T)), touched = __float_as_int(SV(F_TOUCH)), episode = __float_as_int(SV(F_EPISODE)), status = __float_as_int(SV(F_STATUS));
+#undef SV
+    float s_pre[NE], sd_pre[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = gl + i * G;
+        s_pre[i] = 0.f; sd_pre[i] = 0.f;
+        if (TORSO && e < N_TOP) { s_pre[i] = LAT(LAT_S + e); sd_pre[i] = LAT(LAT_SD + e); }
+    }
+    USIM_STAMP(dbg, 1);
+
+    // ---------------- action (replicated: seven words) ----------------
+    float act[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (flags & LF_RANDOM_ACT) {
+        // the two counter blocks are evaluated side by side by the even and odd lanes of the group, then shared
+        const uint32_t gid = (uint32_t)(C.env_offset + ei);
+        const u4 r = philox(gid, (uint32_t)rstep, (uint32_t)((unsigned long long)rstep >> 32), 1u + (uint32_t)(gl & 1), C.key0, C.key1);
+        const float ra = __uint_as_float(r.a), rb = __uint_as_float(r.b), rc = __uint_as_float(r.c), rd = __uint_as_float(r.d);
+        uint32_t rr[7];
+        rr[0] = __float_as_uint(rbc<0>(ra)); rr[1] = __float_as_uint(rbc<0>(rb)); rr[2] = __float_as_uint(rbc<0>(rc)); rr[3] = __float_as_uint(rbc<0>(rd));
+        rr[4] = __float_as_uint(rbc<1>(ra)); rr[5] = __float_as_uint(rbc<1>(rb)); rr[6] = __float_as_uint(rbc<1>(rc));
+#pragma unroll
+        for (int a = 0; a < 7; ++a) {
+            const float u = u01(rr[a]);
+            const bool sgn = (C.mode == 1) || (C.mode == 3) || (C.mode == 2 && a == 6);
+            act[a] = sgn ? 2.f * u - 1.f : u;
+            if (C.mode == 3) act[a] *= WRENCH_MAX;
+            if (io.act_out && store && a < C.adim) io.act_out[(size_t)ei * C.adim + a] = act[a];
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < 7; ++a) if (a < C.adim) {
+            const float v = io.act[(size_t)ei * C.adim + a];
+            act[a] = (v == v && fabsf(v) <= 3.0e38f) ? v : 0.f;          // a non-finite action component is treated as 0
+        }
+    }
+    t += 1;                                                              // MujocoEnv.step: timestep += 1
+    const float dt = C.dt, inv_h = rcp_((float)C.horizon);
+
+    // =================================================================================================================
+    // kinematics: local transform of this lane's link, then the scan  T_l <- T_(l-d) o T_l  for d = 1, 2, 4
+    // =================================================================================================================
+    f3 X, Y, Z, P;                                                       // world rotation columns and origin of this lane's frame
+    {
+        float s, c;
+        sincos_(qj, s, c);                                               // lanes without a joint carry q = 0: s = 0, c = 1 exactly
+        const f3 f0 = mk(at[AT_RFIX], at[AT_RFIX + 1], at[AT_RFIX + 2]), f1 = mk(at[AT_RFIX + 3], at[AT_RFIX + 4], at[AT_RFIX + 5]);
+        X = f0 * c + f1 * s; Y = f1 * c - f0 * s; Z = mk(at[AT_RFIX + 6], at[AT_RFIX + 7], at[AT_RFIX + 8]);
+        P = mk(at[AT_LPOS], at[AT_LPOS + 1], at[AT_LPOS + 2]);
+    }
+    static_for<3>([&](auto Dc) {
+        constexpr int D = 1 << decltype(Dc)::value;
+        // lanes l < D read the identity (fill values of the shift): their frame is already complete
+        const f3 LX = mk(rshr<D>(X.x, 1.f), rshr<D>(X.y, 0.f), rshr<D>(X.z, 0.f));
+        const f3 LY = mk(rshr<D>(Y.x, 0.f), rshr<D>(Y.y, 1.f), rshr<D>(Y.z, 0.f));
+        const f3 LZ = mk(rshr<D>(Z.x, 0.f), rshr<D>(Z.y, 0.f), rshr<D>(Z.z, 1.f));
+        const f3 LP = mk(rshr0<D>(P.x), rshr0<D>(P.y), rshr0<D>(P.z));
+        const f3 nX = LX * X.x + LY * X.y + LZ * X.z, nY = LX * Y.x + LY * Y.y + LZ * Y.z, nZ = LX * Z.x + LY * Z.y + LZ * Z.z;
+        P = LP + LX * P.x + LY * P.y + LZ * P.z;
+        X = nX; Y = nY; Z = nZ;
+    });
+    const f3 rcm = X * at[AT_LCOM] + Y * at[AT_LCOM + 1] + Z * at[AT_LCOM + 2];      // link COM relative to the link origin
+    const f3 cm_ = P + rcm;
+    // site frame = lane 7's; hand origin = a fixed point of the last link
+    const f3 sx = rbc3<7>(X), sy = rbc3<7>(Y), sz = rbc3<7>(Z), xs = rbc3<7>(P);
+    const f3 hand = rbc3<NJ - 1>(P + X * M.hand7[0] + Y * M.hand7[1] + Z * M.hand7[2]);
+
+    // =================================================================================================================
+    // dynamics: bias forces (prefix / suffix sums over the joint lanes) and mass matrix (composite inertia by suffix sums)
+    // =================================================================================================================
+    float bias, Mr[NJ];                                                  // this lane's bias torque and its full row of M
+    f3 w, al, ao;                                                        // link angular velocity, bias angular acceleration, bias acceleration of the origin
+    {
+        const f3 zq = Z * qdj;
+        w = prefix_sum(zq);
+        const f3 wp = w - zq;                                            // parent link
+        const f3 dal = cross(wp, zq);
+        al = prefix_sum(dal);
+        const f3 alp = al - dal;
+        const f3 r = mk(P.x - rshr0<1>(P.x), P.y - rshr0<1>(P.y), P.z - rshr0<1>(P.z));
+        f3 da = cross(alp, r) + cross(wp, cross(wp, r));
+        da.z += (gl == 0) ? GRAV : 0.f;                                  // gravity enters as the base acceleration
+        ao = prefix_sum(da);
+        const f3 ac = ao + cross(al, rcm) + cross(w, cross(w, rcm));
+        const float mass = at[AT_MASS];
+        const f3 F = ac * mass;
+        // world inertia Iw = R I R^T (six entries)
+        const float* I = &at[AT_INERTIA];
+        const f3 RI0 = mk(X.x * I[0] + Y.x * I[1] + Z.x * I[2], X.x * I[1] + Y.x * I[3] + Z.x * I[4], X.x * I[2] + Y.x * I[4] + Z.x * I[5]);   // row x of R I
+        const f3 RI1 = mk(X.y * I[0] + Y.y * I[1] + Z.y * I[2], X.y * I[1] + Y.y * I[3] + Z.y * I[4], X.y * I[2] + Y.y * I[4] + Z.y * I[5]);
+        const f3 RI2 = mk(X.z * I[0] + Y.z * I[1] + Z.z * I[2], X.z * I[1] + Y.z * I[3] + Z.z * I[4], X.z * I[2] + Y.z * I[4] + Z.z * I[5]);
+        float Iw[6];
+        Iw[0] = RI0.x * X.x + RI0.y * Y.x + RI0.z * Z.x; Iw[1] = RI0.x * X.y + RI0.y * Y.y + RI0.z * Z.y; Iw[2] = RI0.x * X.z + RI0.y * Y.z + RI0.z * Z.z;
+        Iw[3] = RI1.x * X.y + RI1.y * Y.y + RI1.z * Z.y; Iw[4] = RI1.x * X.z + RI1.y * Y.z + RI1.z * Z.z; Iw[5] = RI2.x * X.z + RI2.y * Y.z + RI2.z * Z.z;
+        const f3 Nc = symmul(Iw, al) + cross(w, symmul(Iw, w)) + cross(cm_, F);      // moment about the base origin
+        const f3 fa = suffix_sum(F), na = suffix_sum(Nc);
+        bias = dot(Z, na - cross(P, fa));
+        // composite inertia about the base origin: mass, first moment, second moment
+        const float cc = dot(cm_, cm_);
+        float Io[6] = {fmaf(mass, cc - cm_.x * cm_.x, Iw[0]), fmaf(-mass, cm_.x * cm_.y, Iw[1]), fmaf(-mass, cm_.x * cm_.z, Iw[2]),
+                       fmaf(mass, cc - cm_.y * cm_.y, Iw[3]), fmaf(-mass, cm_.y * cm_.z, Iw[4]), fmaf(mass, cc - cm_.z * cm_.z, Iw[5])};
+        const float cmass = suffix_sum(mass);
+        const f3 ch = suffix_sum(cm_ * mass);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Io[k] = suffix_sum(Io[k]);
+        const f3 vo = cross(P, Z);
+        const f3 nn = symmul(Io, Z) + cross(ch, vo);
+        const f3 ff = vo * cmass + cross(Z, ch);
+        // lower triangle of row l: M[l][j] = z_j . n_l + vo_j . f_l  (j <= l)
+        float Ml[8];
+        static_for<NJ>([&](auto Jc) {
+            constexpr int j = decltype(Jc)::value;
+            Ml[j] = spatial_dot_bc<j>(Z, vo, nn, ff);
+        });
+        Ml[7] = 0.f;
+        // upper triangle through LDS: every lane parks its row, then reads its column
+        if (gl < 8) {
+            *reinterpret_cast<float4*>(&xl[gl * 8]) = make_float4(Ml[0], Ml[1], Ml[2], Ml[3]);
+            *reinterpret_cast<float4*>(&xl[gl * 8 + 4]) = make_float4(Ml[4], Ml[5], Ml[6], Ml[7]);
+        }
+        group_sync();
+        const int gc = gl & 7;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) Mr[j] = (j > gl) ? xl[j * 8 + gc] : Ml[j];
+        group_sync();                                                    // the scratch is reused for the Jacobian below
+    }
+    USIM_STAMP(dbg, 2);
+
+    // ---------------- M^-1: in-place Gauss-Jordan, row l in lane l ----------------
+    float Mi[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) Mi[j] = Mr[j];
+    static_for<NJ>([&](auto Kc) {
+        constexpr int k = decltype(Kc)::value;
+        const float mk_ = (gl == k) ? 1.f : 0.f;
+        const float g = (mk_ - Mi[k]) * rcp_(rbc<k>(Mi[k]));           // minus the elimination factor
+        Mi[k] = mk_;
+        row_axpy_bc7<k>(Mi, g);
+    });
+
+    // ---------------- operational space: Jacobian column per joint lane, row per task lane, Lambda^-1 row per task lane ----------------
+    float Jc[6], Jr[8], Li[6];
+    {
+        const f3 jv = cross(Z, xs - P);
+        Jc[0] = jv.x; Jc[1] = jv.y; Jc[2] = jv.z; Jc[3] = Z.x; Jc[4] = Z.y; Jc[5] = Z.z;
+        float Xm[6];                                                     // row l of M^-1 J^T
+#pragma unroll
+        for (int a = 0; a < 6; ++a) Xm[a] = row_times_joint<NJ>(Mi, Jc[a]);
+        if (gl < 8) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) xl[a * 8 + gl] = Jc[a];
+        }
+        group_sync();
+        int arow = (gl & 7) - ((gl & 4) ? 1 : 0);
+        arow = arow > 5 ? 5 : arow;
+        {
+            const float4 j0 = *reinterpret_cast<const float4*>(&xl[arow * 8]), j1 = *reinterpret_cast<const float4*>(&xl[arow * 8 + 4]);
+            Jr[0] = j0.x; Jr[1] = j0.y; Jr[2] = j0.z; Jr[3] = j0.w; Jr[4] = j1.x; Jr[5] = j1.y; Jr[6] = j1.z; Jr[7] = j1.w;
+        }
+#pragma unroll
+        for (int b = 0; b < 6; ++b) Li[b] = row_times_joint<NJ>(Jr, Xm[b]);
+    }
+    const int comp = gl & 3;
+    const bool blk = (gl & 4) != 0;
+    const bool is_task = (gl < 8) && comp != 3;
+    const float v6 = row_times_joint<NJ>(Jr, qdj);                       // site twist component of this task lane
+    USIM_STAMP(dbg, 3);
+
+    // ---------------- OSC_POSE torque (robosuite osc.py run_controller; rl_config.yaml:33-51) ----------------
+    float tau;
+    {
+        auto pick = [&](f3 v) { return comp == 0 ? v.x : (comp == 1 ? v.y : v.z); };
+        const int arow = blk ? 3 + (comp > 2 ? 2 : comp) : (comp > 2 ? 2 : comp);
+        float act_own = act[0];
+#pragma unroll
+        for (int a = 1; a < 6; ++a) act_own = (arow == a) ? act[a] : act_own;
+        f3 gpos, gx, gy, gz;
+        float kp, kd;
+        const float up = clampf((float)(t - 1) * inv_h + u0, 0.f, 1.f);     // controller.traj_pos from the previous _post_action
+        const f3 tpw = ts + (te - ts) * up;
+        if (C.mode == 1) {
+            float d[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) d[a] = clampf(act[a], -1.f, 1.f) * (a < 3 ? C.out_pos : C.out_ori);
+            gpos = xs + mk(d[0], d[1], d[2]);
+            const float ang = sqrt_(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+            if (ang < 1e-12f) { gx = sx; gy = sy; gz = sz; }
+            else {
+                const float hh = 0.5f * ang, sh = sinf(hh) * rcp_(ang), qw = cosf(hh), qx = d[3] * sh, qy = d[4] * sh, qz = d[5] * sh;
+                const f3 e0 = mk(1.f - 2.f * (qy * qy + qz * qz), 2.f * (qx * qy + qw * qz), 2.f * (qx * qz - qw * qy));
+                const f3 e1 = mk(2.f * (qx * qy - qw * qz), 1.f - 2.f * (qx * qx + qz * qz), 2.f * (qy * qz + qw * qx));
+                const f3 e2 = mk(2.f * (qx * qz + qw * qy), 2.f * (qy * qz - qw * qx), 1.f - 2.f * (qx * qx + qy * qy));
+                gx = e0 * sx.x + e1 * sx.y + e2 * sx.z; gy = e0 * sy.x + e1 * sy.y + e2 * sy.z; gz = e0 * sz.x + e1 * sz.y + e2 * sz.z;
+            }
+            kp = C.kp_fixed;
+        } else {
+            const float v = (C.mode == 3) ? 0.f : clampf(act_own, 0.f, 1.f);   // wrench mode: no impedance term
+            kp = C.kp_min + v * (C.kp_max - C.kp_min);
+            gpos = mk(tpw.x - M.base[0], tpw.y - M.base[1], tpw.z - M.base[2]);
+            if (C.mode == 2) gpos.z += clampf(act[6], -1.f, 1.f) * C.out_pos;
+            gx = mk(M.grot[0], M.grot[3], M.grot[6]); gy = mk(M.grot[1], M.grot[4], M.grot[7]); gz = mk(M.grot[2], M.grot[5], M.grot[8]);
+        }
+        kd = 2.f * sqrt_(kp) * C.damping_ratio;
+        const f3 eo = (cross(sx, gx) + cross(sy, gy) + cross(sz, gz)) * 0.5f;
+        const f3 ep = gpos - xs;
+        const float e = blk ? pick(eo) : pick(ep);
+        float F = e * kp - v6 * kd;
+        // fork-only "wrench" baseline (utils/plot.py:267-268): the action takes the place of desired_force / desired_torque in the OSC law
+        if (C.mode == 3) F = clampf(act_own, -WRENCH_MAX, WRENCH_MAX);
+        // lambda_pos F, lambda_ori T (uncouple_pos_ori, rl_config.yaml:48): Gauss-Jordan on [B | F] inside the quads; lanes that own no
+        // task row carry unit rows so that every quad has regular pivots
+        float B[3], rhs = is_task ? F : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) B[c] = is_task ? (blk ? Li[3 + c] : Li[c]) : (comp == c ? 1.f : 0.f);
+        static_for<3>([&](auto Kc) {
+            constexpr int k = decltype(Kc)::value;
+            const float g = (B[k] - (comp == k ? 1.f : 0.f)) * rcp_(qbc<k>(B[k]));
+#pragma unroll
+            for (int c = k + 1; c < 3; ++c) B[c] = fmaf(-g, qbc<k>(B[c]), B[c]);
+            rhs = fmaf(-g, qbc<k>(rhs), rhs);
+        });
+        const float wr = rhs;
+        // nullspace torque N^T M (10 (q0 - q) - 2 sqrt(10) qd) = M pt - J^T Lambda (J pt)
+        const float pt = 10.f * (q0j - qj) - 6.3245553203367586f * qdj;
+        float y = 0.f, jb = 0.f;
+        y = row_times_joint<NJ>(Mr, pt); jb = row_times_joint<NJ>(Jr, pt);
+        float A[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) A[c] = is_task ? Li[c] : 0.f;       // lanes without a task row: zero rows, never pivots
+        jb = is_task ? jb : 0.f;
+        static_for<6>([&](auto Kc) {
+            constexpr int k = decltype(Kc)::value;
+            constexpr int lk = TASK_LANE[k];
+            const float g = (A[k] - (gl == lk ? 1.f : 0.f)) * rcp_(rbc<lk>(A[k]));
+#pragma unroll
+            for (int c = k + 1; c < 6; ++c) A[c] = fmaf(-g, rbc<lk>(A[c]), A[c]);
+            jb = fmaf(-g, rbc<lk>(jb), jb);
+        });
+        const float tq_ = bias + y + col_times_task(Jc, wr - jb);
+        tau = clampf(tq_, -at[AT_TAUMAX], at[AT_TAUMAX]);
+    }
+    if (io.log && valid) {
+        float* L = io.log + (size_t)ei * LOG_WIDTH;
+        if (jlane) L[33 + gl] = tau;
+        if (gl == 0) {
+#pragma unroll
+            for (int a = 0; a < 7; ++a) L[46 + a] = act[a];
+        }
+    }
+    USIM_STAMP(dbg, 4);
+
+    // ---------------- smooth acceleration, site-space acceleration of the unconstrained arm ----------------
+    const float qs = row_times_joint<NJ>(Mi, tau - bias - JOINT_DAMP * qdj);
+    float W[6] = {0, 0, 0, 0, 0, 0};
+    int ncon = 0, overflow = 0, con_shell[MAXC];
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) con_shell[k] = -1;
+    if constexpr (TORSO != 0) {
+        const int* tb_shell = reinterpret_cast<const int*>(lds + TB_SHELL);
+        const int tsim = t - 1;
+        float dz, vz, az;
+        torso_motion(C, tsim, dz, vz, az);
+        int nc = lattice_front<G, NE, true>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, true, s_pre, sd_pre, xs, sy, sz, dbg);
+        USIM_STAMP(dbg, 7);
+        if (nc > MAXC) { overflow = 1; nc = MAXC; }
+        ncon = nc;
+        group_sync();
+        int ncmax = 0;
+#pragma unroll
+        for (int k = MAXC; k >= 1; --k) if (ncmax == 0 && __any(nc >= k)) ncmax = k;
+        float gf[MAXC];
+        int cel[MAXC];
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) { gf[k] = 0.f; cel[k] = (k < nc) ? __float_as_int(EB(GE_CG + k * CG_WORDS + 6)) : 0; }
+        if (ncmax > 0) {
+            // every contact lane needs Lambda^-1, alpha = J qs and vs = J qd in full: broadcasts from the task lanes
+            const float alpha_t = row_times_joint<NJ>(Jr, qs);
+            float alpha[6], vs[6], Lp[21];
+            static_for<6>([&](auto Ac) {
+                constexpr int a = decltype(Ac)::value;
+                alpha[a] = rbc<TASK_LANE[a]>(alpha_t); vs[a] = rbc<TASK_LANE[a]>(v6);
+#pragma unroll
+                for (int b = 0; b <= a; ++b) Lp[PK(a, b)] = rbc<TASK_LANE[a]>(Li[b]);
+            });
+            USIM_STAMP(dbg, 8);
+            contact_solve<G>(lds, eb, gl, M, C, nc, ncmax, cel, Lp, alpha, vs, mu, vz, W, gf, dbg);
+        }
+        USIM_STAMP(dbg, 11);
+        // ---- element accelerations a = a~ + Linv[:, e_c] gf_c, semi-implicit Euler, write back ----
+        {
+            float acc_e[NE];
+#pragma unroll
+            for (int i = 0; i < NE; ++i) { const int e = gl + i * G; acc_e[i] = (e < N_TOP) ? EB(GE_A + e) : 0.f; }
+#pragma unroll
+            for (int k = 0; k < MAXC; ++k) {
+                if (k < ncmax) {
+#pragma unroll
+                    for (int i = 0; i < NE; ++i) {
+                        const int e = (gl + i * G < N_TOP) ? gl + i * G : N_TOP - 1;
+                        acc_e[i] = fmaf(lds[TB_LINV + e * LROW + cel[k]], gf[k], acc_e[i]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const int e = gl + i * G;
+                if (e >= N_TOP) continue;
+                const float sdn = EB(GE_SD + e) + dt * acc_e[i];
+                const float sn = EB(GE_S + e) + dt * sdn;
+                if (valid) { LAT(LAT_SD + e) = sdn; LAT(LAT_S + e) = sn; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) con_shell[k] = (k < nc) ? tb_shell[cel[k]] : -1;
+    }
+    USIM_STAMP(dbg, 12);
+
+    // ---------------- constrained arm acceleration, probe torque sensor, Euler step, hand velocity ----------------
+    float tq[3];
+    f3 hv;
+    {
+        float z0 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) z0 = fmaf(Jc[a], W[a], z0);
+        const float qacc = qs + (TORSO ? row_times_joint<NJ>(Mi, z0) : 0.f);
+        // link accelerations from the site Jacobian: alpha = alpha_bias + Jw qacc, a(o) = a_bias + Jv qacc - (Jw qacc) x (x - o).  Every lane
+        // evaluates the sensor on its own link's registers; the last link's lane holds the probe's.
+        const float aq_t = row_times_joint<NJ>(Jr, qacc);
+        float aq[6];
+        static_for<6>([&](auto Ac) { constexpr int a = decltype(Ac)::value; aq[a] = rbc<TASK_LANE[a]>(aq_t); });
+        const f3 alq = mk(aq[3], aq[4], aq[5]);
+        const f3 alt = al + alq;
+        const f3 a7 = ao + mk(aq[0], aq[1], aq[2]) - cross(alq, xs - P);
+        const f3 rc = X * M.pcom7[0] + Y * M.pcom7[1] + Z * M.pcom7[2];
+        const f3 ac = a7 + cross(alt, rc) + cross(w, cross(w, rc));
+        auto rot_inertia = [&](f3 v) {
+            const f3 l = mk(dot(X, v), dot(Y, v), dot(Z, v));
+            const f3 tt = symmul(M.pI7, l);
+            return X * tt.x + Y * tt.y + Z * tt.z;
+        };
+        const f3 N = rot_inertia(alt) + cross(w, rot_inertia(w));
+        const f3 Fp = ac * PROBE_MASS;
+        const f3 tw = N + cross(P + rc - xs, Fp) - mk(W[3], W[4], W[5]);
+        tq[0] = rbc<NJ - 1>(dot(sx, tw)); tq[1] = rbc<NJ - 1>(dot(sy, tw)); tq[2] = rbc<NJ - 1>(dot(sz, tw));
+        USIM_STAMP(dbg, 13);
+        // mj_Euler with implicit joint damping: (M + h D) x = M qacc, one fixed-point step on M^-1
+        const float xk = row_times_joint<NJ>(Mi, qacc);
+        const float rhs = fmaf(-dt * JOINT_DAMP, xk, qacc);
+        qdj = fmaf(dt, rhs, qdj); qj = fmaf(dt, qdj, qj);
+        if (!jlane) { qdj = 0.f; qj = 0.f; }
+        // hand velocity: Jacobian from before the integration, qvel from after (mj_step data semantics)
+        const float v2_t = row_times_joint<NJ>(Jr, qdj);
+        float v2[6];
+        static_for<6>([&](auto Ac) { constexpr int a = decltype(Ac)::value; v2[a] = rbc<TASK_LANE[a]>(v2_t); });
+        hv = mk(v2[0], v2[1], v2[2]) + cross(mk(v2[3], v2[4], v2[5]), hand - xs);
+    }
+    USIM_STAMP(dbg, 14);
+
+    // ---------------- observation (ultrasound.py:363-401), reward (:230-269), bookkeeping (:528-546), termination (:635-670) ----------------
+    float obs[OBS_DIM];
+    bool done, need;
+    {
+        const float up = clampf((float)(t - 1) * inv_h + u0, 0.f, 1.f);
+        const f3 tpw = ts + (te - ts) * up;
+        obs[0] = W[0]; obs[1] = W[1]; obs[2] = W[2];
+        obs[3] = tq[0]; obs[4] = tq[1]; obs[5] = tq[2];
+        obs[6] = hv.x; obs[7] = hv.y; obs[8] = hv.z;
+        obs[9] = fzbar - 5.0f; obs[10] = dfz - 0.0f; obs[11] = vbar - 0.04f;
+        const f3 xw = mk(xs.x + M.base[0], xs.y + M.base[1], xs.z + M.base[2]);
+        obs[12] = xw.x - tpw.x; obs[13] = xw.y - tpw.y; obs[14] = xw.z - tpw.z;
+        float qe[4]; mat2quat_xyzw(sx, sy, sz, qe);
+        difference_quat(qe, M.gquat, obs + 15);                          // xyzw arrays through the wxyz routine (ultrasound.py:390)
+        const bool contact = ncon > 0;
+        if (contact) touched = 1;
+        float pe0 = 90.f * (xw.x - tpw.x), pe1 = 90.f * (xw.y - tpw.y);
+        pe0 *= pe0; pe1 *= pe1;
+        const float pos_err_norm = sqrt_(pe0 * pe0 + pe1 * pe1);
+        const float pos_rew = 5.f * exp_(-pos_err_norm);
+        const float qc[4] = {qe[3], qe[0], qe[1], qe[2]};
+        const float ori_err = 0.2f * distance_quat_goal(qc, M.ghat, M.geps);
+        const float ori_rew = exp_(-ori_err);
+        float ve = 45.f * (vbar - 0.04f); ve *= ve;
+        const float vel_rew = exp_(-ve);
+        float fe = 0.7f * (fzbar - 5.f); fe *= fe;
+        const float force_rew = contact ? 3.f * exp_(-fe) : 0.f;
+        float de = 0.01f * dfz; de *= de;
+        const float dforce_rew = contact ? 2.f * exp_(-de) : 0.f;
+        float reward = pos_rew + ori_rew + vel_rew + force_rew + dforce_rew;
+        done = t >= C.horizon;
+        const float hvn = sqrt_(dot(hv, hv));
+        vbar += (hvn - vbar) * rcp_((float)t);
+        const float fz = W[2];
+        dfz = (fz - fzprev) * rcp_(dt);
+        fzprev = fz;
+        fzbar = 0.1f * fz + 0.9f * fzbar;
+        // joint-limit margin and run-away guard are per-joint quantities: one ballot / one prefix sum over the group
+        const bool jviol = (qj < at[AT_QMIN] + 0.1f) || (qj > at[AT_QMAX] - 0.1f);
+        const unsigned jany = (unsigned)(__ballot(jviol) >> gbase) & 0xffffu;
+        if (C.early_term) {
+            const bool term = (jany != 0u) || (pos_err_norm > 1.0f) || (contact && ori_err > 0.10f) || (touched && !contact);
+            done = done || term;
+        }
+        epret += reward;
+        if (io.log && valid) {
+            float* L = io.log + (size_t)ei * LOG_WIDTH;
+            if (jlane) L[26 + gl] = qj;
+            if (gl == 0) {
+                const float upn = clampf((float)t * inv_h + u0, 0.f, 1.f);
+                const f3 tpn = ts + (te - ts) * upn;
+                L[0] = xw.x; L[1] = xw.y; L[2] = xw.z; L[3] = tpn.x; L[4] = tpn.y; L[5] = tpn.z;
+                L[6] = hv.x; L[7] = hv.y; L[8] = hv.z; L[9] = 0.04f; L[10] = vbar;
+                L[11] = qe[0]; L[12] = qe[1]; L[13] = qe[2]; L[14] = qe[3];
+                L[15] = M.gquat[0]; L[16] = M.gquat[1]; L[17] = M.gquat[2]; L[18] = M.gquat[3];
+                L[19] = ori_err * 5.0f;
+                L[20] = fz; L[21] = 5.0f; L[22] = fzbar; L[23] = dfz; L[24] = 0.f; L[25] = contact ? 1.f : 0.f;
+                L[40] = (float)(t - 1) * inv_h * 100.f;
+                L[41] = pos_rew; L[42] = ori_rew; L[43] = vel_rew; L[44] = force_rew; L[45] = dforce_rew;
+            }
+        }
+        if (overflow) status |= 1;
+        {
+            // numerical fault guard: a non-finite or run-away state ends the episode and is flagged
+            const float chk = rbc<7>(prefix_sum(fabsf(qj) + 1e-3f * fabsf(qdj)));
+            if (!(chk < 1.0e3f)) { status |= 4; done = true; epret -= reward; reward = 0.f; if (!(epret == epret)) epret = 0.f; }
+        }
+        if (store) {
+            io.rew[ei] = reward;
+            if (io.status_out) io.status_out[ei] = status;
+            io.done[ei] = done ? 1 : 0;
+            if (io.contacts) {
+                io.contacts[(size_t)ei * (1 + MAXC)] = ncon;
+#pragma unroll
+                for (int k = 0; k < MAXC; ++k) io.contacts[(size_t)ei * (1 + MAXC) + 1 + k] = con_shell[k];
+            }
+            if (done) {
+                if (io.term_obs) {
+#pragma unroll
+                    for (int a = 0; a < OBS_DIM; ++a) io.term_obs[(size_t)ei * OBS_DIM + a] = obs[a];
+                }
+                if (io.ep_ret) io.ep_ret[ei] = epret;
+                if (io.ep_len) io.ep_len[ei] = t;
+            }
+        }
+        need = done && auto_reset;
+        if (store && io.obs && !need) {
+#pragma unroll
+            for (int a = 0; a < OBS_DIM; ++a) io.obs[(size_t)ei * OBS_DIM + a] = obs[a];
+        }
+    }
+
+    if (need) {
+        // ================= auto-reset: adopt the initial state prepared in the reset bank and queue the slot for refill =================
+        episode += 1;
+        const int sl = episode & (BANK_DEPTH - 1);
+        qj = jlane ? BK(sl, BQ0 + jl) : 0.f; q0j = qj; qdj = 0.f;
+        ts = mk(BK(sl, BTS), BK(sl, BTS + 1), BK(sl, BTS + 2)); te = mk(BK(sl, BTE), BK(sl, BTE + 1), BK(sl, BTE + 2));
+        u0 = BK(sl, BU0); kst = BK(sl, BKST); kdmp = BK(sl, BKDMP); mu = BK(sl, BMU); fzbar = BK(sl, BFZ);
+        t = 0; touched = 0; fzprev = 0.f; dfz = 0.f; vbar = 0.f; epret = 0.f; status = BKI(sl, BSTATUS);
+        if (store && io.obs) {
+#pragma unroll
+            for (int a = 0; a < OBS_DIM; ++a) io.obs[(size_t)ei * OBS_DIM + a] = BK(sl, BOBS + a);
+        }
+        if (TORSO && valid) for (int e = gl; e < N_TOP; e += G) { LAT(LAT_S + e) = 0.f; LAT(LAT_SD + e) = 0.f; }
+        if (store) { const int idx = atomicAdd(io.count, 1); io.items[idx] = make_int2(env, episode + BANK_DEPTH); }
+    }
+    USIM_STAMP(dbg, 15);
+
+    // ---------------- store state: joint words by their lanes, the scalar quads by the group's first lane ----------------
+    if (valid) {
+        float* const so = st + scalar_index(0, (size_t)ei);
+        if (jlane) {
+            so[F_Q + gl] = qj; so[F_QD + gl] = qdj;
+            if (need) so[F_Q0 + gl] = q0j;
+        }
+        if (gl == 0) {
+            float4* s4 = reinterpret_cast<float4*>(so);
+            if (need) {
+                so[F_TS] = ts.x; so[F_TS + 1] = ts.y; so[F_TS + 2] = ts.z;
+                s4[6] = make_float4(te.x, te.y, te.z, u0);
+            }
+            s4[7] = make_float4(vbar, fzbar, fzprev, dfz);
+            s4[8] = make_float4(kst, kdmp, mu, __int_as_float(t));
+            s4[9] = make_float4(__int_as_float(touched), __int_as_float(episode), epret, __int_as_float(status));
+        }
+    }
+    USIM_STAMP(dbg, 16);
+#undef LAT
+#undef EB
+#undef BK
+#undef BKI
+}
+
+}  // namespace usim

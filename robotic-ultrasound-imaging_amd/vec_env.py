@@ -171,8 +171,9 @@ class UltrasoundVecEnv:
         return float(ms.value)
 
     # label of the interval that ENDS at stamp k
-    PHASES = ["_", "load state", "action+fk+dynamics+chol", "osc", "smooth acc", "lattice stage+rhs", "lattice solve (MFMA)", "collision",
-              "site accel + Lambda^-1", "contact rows", "pgs", "wrench", "lattice integrate", "arm acc+sensor", "arm integrate",
+    # (16-lane kernel: stamps 2 / 3 / 4 close kinematics + dynamics, M^-1 + operational space, controller torque)
+    PHASES = ["_", "load state", "action+fk+dynamics", "factor/inverse + op. space", "controller torque", "lattice stage+rhs", "lattice solve (MFMA)",
+              "collision", "site accel + Lambda^-1", "contact rows", "pgs", "wrench", "lattice integrate", "arm acc+sensor", "arm integrate",
               "obs+reward+done", "store"]
 
     def profile_step(self, step):

@@ -259,7 +259,19 @@ def test_f32_oracle_tracks_f64_oracle():
 
 
 def test_pgs_is_converged_at_default_sweeps():
+    """six cold sweeps of the block Gauss-Seidel leave the contact forces within float32 resolution of the converged solution of the
+    convex problem (forces reach ~80 N here: one float32 ulp is 8e-6 N); ten sweeps reproduce it to 1e-7 N"""
     n = 128
+    d, ref = Oracle(n), Oracle(n, pgs_iters=300)
+    assert d.cfg.pgs_iters == 6
+    d.reset(); ref.reset()
+    for k in range(30):
+        act = ref.random_actions(k)
+        ref.step(act)
+    d.set_state(ref.get_state())
+    act = ref.random_actions(30)
+    od, orf = d.step(act, auto_reset=False)[0], ref.step(act, auto_reset=False)[0]
+    assert np.abs(orf[:, :3]).max() > 20.0 and np.abs(od[:, :3] - orf[:, :3]).max() < 2e-5
     a, b = Oracle(n, pgs_iters=10), Oracle(n, pgs_iters=300)
     a.reset(); b.reset()
     for k in range(30):

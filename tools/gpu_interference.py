@@ -12,8 +12,8 @@ spin.spin_launch.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 sink = torch.zeros(1, dtype=torch.int32, device="cuda")
 side = torch.cuda.Stream()
 K = 256
-for lpe in (16, 8):
-    env = usim.UltrasoundVecEnv(4096, torso="soft", lanes_per_env=lpe, **usim.default_robosuite_kwargs())
+for lpe, occ in ((16, 1), (16, 2), (8, 0)):
+    env = usim.UltrasoundVecEnv(4096, torso="soft", lanes_per_env=lpe, waves_per_simd=occ, **usim.default_robosuite_kwargs())
     env.reset_tensor(); env.rollout_random(0, 128); torch.cuda.synchronize()
     for blocks in (0, 4, 16, 32, 64):
         torch.cuda.synchronize()
@@ -24,5 +24,5 @@ for lpe in (16, 8):
         env.rollout_random(1000, K); torch.cuda.current_stream().synchronize()
         dt = time.perf_counter() - t0
         torch.cuda.synchronize()
-        print(f"lanes {lpe:2d}  spinner workgroups {blocks:3d}: {dt / K * 1e6:6.1f} us/step", flush=True)
+        print(f"lanes {lpe:2d} waves/SIMD {occ}  spinner workgroups {blocks:3d}: {dt / K * 1e6:6.1f} us/step", flush=True)
     env.close()
