@@ -156,7 +156,7 @@ def main():
     valu_tflops = ALGO_FLOPS[args.workload] * n / avg_kernel_s / 1e12
 
     traffic = None
-    tfile = ROOT / "profiles" / "r01" / "traffic.json"
+    tfile = next((f for f in (ROOT / "profiles" / r / "traffic.json" for r in ("r02", "r01")) if f.exists()), ROOT / "profiles" / "r02" / "traffic.json")
     if tfile.exists() and n == 4096:
         try:
             tj = json.loads(tfile.read_text()).get(args.workload)
@@ -177,7 +177,7 @@ def main():
                        "parallelism": f"env-shard x{world}" + (" + RCCL all-gather of transition blocks" if gather is not None else ""),
                        "lanes_per_env": int(extra.get("lanes_per_env", 0)) or 16, "waves_per_simd": int(extra.get("waves_per_simd", 0)) or "auto"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": "profiles/r01/traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch)" if traffic else None,
+                         "traffic": traffic, "traffic_source": f"{tfile.relative_to(ROOT)} (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch)" if traffic else None,
                          "algorithmic_bytes_per_launch": ALGO_BYTES[args.workload] * n, "algorithmic_bytes_per_env_step": ALGO_BYTES[args.workload],
                          "avg_kernel_us": avg_kernel_s * 1e6, "kernel": "usim_step16_kernel" if int(extra.get("lanes_per_env", 0)) in (0, 16) else "usim_step_kernel",
                          "valu_fp32_tflops": valu_tflops, "valu_frac": valu_tflops / FP32_VALU_PEAK_TFLOPS,

@@ -246,10 +246,10 @@ static hipError_t launch_step(usim_handle* h, const DevIO& io, int flags, long l
     return hipGetLastError();
 }
 
-template <int TORSO, int OCC>
+template <int TORSO, int OCC, int MODE>
 static hipError_t launch_step16(usim_handle* h, const DevIO& io, int flags, long long rstep, hipStream_t s) {
     dim3 grid((h->n + 15) / 16), block(256);
-    hipLaunchKernelGGL((usim_step16_kernel<TORSO, OCC>), grid, block, h->lds16_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
+    hipLaunchKernelGGL((usim_step16_kernel<TORSO, OCC, MODE>), grid, block, h->lds16_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
     return hipGetLastError();
 }
 
@@ -257,15 +257,16 @@ template <int MODE>
 static int launch(usim_handle* h, DevIO io, int flags, long long rstep, hipStream_t s) {
     io.bank_row0 = h->bank_row0;
     hipError_t e;
-    // steps with 16 lanes per environment run the kernel with the distributed arm mathematics (usim_step16.h); reset computations and the
-    // 8-lane / one-lane mappings run the kernels of usim_kernels.hip
-    if (MODE == 0 && h->lpe == 16) {
-        if (!h->n_el) e = launch_step16<0, 2>(h, io, flags, rstep, s);
-        else e = (h->occ == 1) ? launch_step16<1, 1>(h, io, flags, rstep, s) : launch_step16<1, 2>(h, io, flags, rstep, s);
+    // 16 lanes per environment: the kernels with the distributed arm mathematics (usim_step16.h); the 8-lane / one-lane mappings run the
+    // kernels of usim_kernels.hip
+    if (h->lpe == 16) {
+        // (reset computations are not register-critical: always the two-waves-per-SIMD build)
+        if (!h->n_el) e = launch_step16<0, 2, MODE>(h, io, flags, rstep, s);
+        else if constexpr (MODE == 0) e = (h->occ == 1) ? launch_step16<1, 1, 0>(h, io, flags, rstep, s) : launch_step16<1, 2, 0>(h, io, flags, rstep, s);
+        else e = launch_step16<1, 2, MODE>(h, io, flags, rstep, s);
     }
     else if (!h->n_el) e = launch_step<0, 1, MODE>(h, io, flags, rstep, s);
-    else if (h->lpe == 8) e = launch_step<1, 8, MODE>(h, io, flags, rstep, s);
-    else e = launch_step<1, 16, MODE>(h, io, flags, rstep, s);
+    else e = launch_step<1, 8, MODE>(h, io, flags, rstep, s);
     if (e != hipSuccess) { h->hip_err = std::string("usim_step_kernel launch: ") + hipGetErrorString(e); return USIM_ERR_HIP; }
     return USIM_OK;
 }
@@ -331,16 +332,15 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
     h->occ = cfg->waves_per_simd ? cfg->waves_per_simd : (n_envs <= 4096 ? 1 : 2);
     h->lds16_bytes = h->n_el ? (size_t)GroupGeom<16>::LDS_WORDS * sizeof(float) : (size_t)16 * X16_RIGID_STRIDE * sizeof(float);
     if (h->n_el) {
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step16_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds16_bytes));
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step16_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds16_bytes));
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step16_kernel<1, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds16_bytes));
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step16_kernel<1, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds16_bytes));
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step16_kernel<1, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds16_bytes));
     }
     h->lds_bytes = 0;
-    if (h->n_el) {
-        h->lds_bytes = (size_t)(h->lpe == 8 ? GroupGeom<8>::LDS_WORDS : GroupGeom<16>::LDS_WORDS) * sizeof(float);
-        const void* fn0 = h->lpe == 8 ? reinterpret_cast<const void*>(&usim_step_kernel<1, 8, 0>) : reinterpret_cast<const void*>(&usim_step_kernel<1, 16, 0>);
-        const void* fn1 = h->lpe == 8 ? reinterpret_cast<const void*>(&usim_step_kernel<1, 8, 1>) : reinterpret_cast<const void*>(&usim_step_kernel<1, 16, 1>);
-        HIPCHK(h, hipFuncSetAttribute(fn0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-        HIPCHK(h, hipFuncSetAttribute(fn1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    if (h->n_el && h->lpe == 8) {
+        h->lds_bytes = (size_t)GroupGeom<8>::LDS_WORDS * sizeof(float);
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step_kernel<1, 8, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step_kernel<1, 8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     }
     // contact regulariser scale: translational inverse weight of the probe at init_qpos (device, one lane) + element
     {

@@ -100,6 +100,54 @@ DI float spatial_dot_bc(f3 z, f3 vo, f3 n, f3 f) {
     return s;
 }
 
+// world frame of every link: local transform of this lane's link (fixed rotation, joint about the local z axis), then the scan
+// T_l <- T_(l-d) o T_l for d = 1, 2, 4.  X, Y, Z: rotation columns, P: origin.  Lanes without a joint carry q = 0 (sin 0 = 0, cos 0 = 1 exactly).
+DI void fk16(const float* at, const float q, f3& X, f3& Y, f3& Z, f3& P) {
+    float s, c;
+    sincos_(q, s, c);
+    const f3 f0 = mk(at[AT_RFIX], at[AT_RFIX + 1], at[AT_RFIX + 2]), f1 = mk(at[AT_RFIX + 3], at[AT_RFIX + 4], at[AT_RFIX + 5]);
+    X = f0 * c + f1 * s; Y = f1 * c - f0 * s; Z = mk(at[AT_RFIX + 6], at[AT_RFIX + 7], at[AT_RFIX + 8]);
+    P = mk(at[AT_LPOS], at[AT_LPOS + 1], at[AT_LPOS + 2]);
+    static_for<3>([&](auto Dc) {
+        constexpr int D = 1 << decltype(Dc)::value;
+        // lanes l < D read the identity (fill values of the shift): their frame is already complete
+        const f3 LX = mk(rshr<D>(X.x, 1.f), rshr<D>(X.y, 0.f), rshr<D>(X.z, 0.f));
+        const f3 LY = mk(rshr<D>(Y.x, 0.f), rshr<D>(Y.y, 1.f), rshr<D>(Y.z, 0.f));
+        const f3 LZ = mk(rshr<D>(Z.x, 0.f), rshr<D>(Z.y, 0.f), rshr<D>(Z.z, 1.f));
+        const f3 LP = mk(rshr0<D>(P.x), rshr0<D>(P.y), rshr0<D>(P.z));
+        const f3 nX = LX * X.x + LY * X.y + LZ * X.z, nY = LX * Y.x + LY * Y.y + LZ * Y.z, nZ = LX * Z.x + LY * Z.y + LZ * Z.z;
+        P = LP + LX * P.x + LY * P.y + LZ * P.z;
+        X = nX; Y = nY; Z = nZ;
+    });
+}
+
+// column l of the site Jacobian in joint lane l -> row a in task lane a, through the 8 x 8 LDS scratch of the environment
+DI void jacobian_rows(float* xl, const int gl, const float* Jc, float* Jr) {
+    if (gl < 8) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) xl[a * 8 + gl] = Jc[a];
+    }
+    group_sync();
+    int arow = (gl & 7) - ((gl & 4) ? 1 : 0);
+    arow = arow > 5 ? 5 : arow;
+    const float4 j0 = *reinterpret_cast<const float4*>(&xl[arow * 8]), j1 = *reinterpret_cast<const float4*>(&xl[arow * 8 + 4]);
+    Jr[0] = j0.x; Jr[1] = j0.y; Jr[2] = j0.z; Jr[3] = j0.w; Jr[4] = j1.x; Jr[5] = j1.y; Jr[6] = j1.z; Jr[7] = j1.w;
+}
+
+// solution of the 6 x 6 system whose row a (A[0..5] | b) lives in task lane a: Gauss-Jordan across the six task lanes, no pivoting (the
+// matrices are symmetric positive definite).  Lanes without a task row must pass zero rows: they are never pivots.
+DI float solve6_task(float* A, float b, const int gl) {
+    static_for<6>([&](auto Kc) {
+        constexpr int k = decltype(Kc)::value;
+        constexpr int lk = TASK_LANE[k];
+        const float g = (A[k] - (gl == lk ? 1.f : 0.f)) * rcp_(rbc<lk>(A[k]));
+#pragma unroll
+        for (int c = k + 1; c < 6; ++c) A[c] = fmaf(-g, rbc<lk>(A[c]), A[c]);
+        b = fmaf(-g, rbc<lk>(b), b);
+    });
+    return b;
+}
+
 // per-environment LDS scratch of the two transposes: 8 x 8 words
 constexpr int X16_WORDS = 64;
 constexpr int X16_RIGID_STRIDE = 68;                  // rigid-torso launches: one block of 68 words per environment (68 mod 32 = 4)
@@ -107,7 +155,10 @@ constexpr int X16_RIGID_STRIDE = 68;                  // rigid-torso launches: o
 // OCC = waves per SIMD the register allocation aims at.  1: the whole register file for one wave (no spills; the choice up to 4096 envs/GPU,
 // where every SIMD holds one wave anyway).  2: 256 registers per lane (the soft-torso kernel then keeps ~27 values in scratch): beyond 4096
 // envs/GPU two waves share a SIMD and fill each other's stalls (8192 envs: 28.6 us/step against 37.4 us in two rounds of one wave).
-template <int TORSO, int OCC>
+// MODE 0: one env.step() per environment; a finished environment takes its next initial state from the reset bank.
+// MODE 1: reset computation (draws, initial-pose IK, zero-torque forward pass) for the environments selected by the mask (written to the
+//         live state) or for the (env, episode) items of the refill work list (written to the reset bank).
+template <int TORSO, int OCC, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void usim_step16_kernel(const DevModel M, const DevCfg C, float* __restrict__ st, int n, int npad, const DevIO io,
                                                           int flags, long long rstep) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -117,12 +168,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     const int gl = lane & 15, ge = lane >> 4;
     const int gbase = lane - gl;
     const int eb = wave * EPW + ge;
-    const int env = blockIdx.x * EPB + eb;
-    const bool valid = env < n;
-    const bool store = valid && gl == 0;
-    const int ei = valid ? env : n - 1;
     const bool auto_reset = (flags & LF_AUTO_RESET) != 0;
     unsigned long long* const dbg = io.dbg;
+    // refill launches walk the work list with a grid-stride loop; every other launch runs the body once
+    const bool refill = (MODE == 1) && io.refill != 0;
+    const int item_cnt = refill ? io.count[0] : 1;
+    const int item_first = refill ? (int)blockIdx.x * EPB : 0;
+    for (int item0 = item_first; item0 < item_cnt; item0 += refill ? (int)gridDim.x * EPB : 1) {
+    int env = blockIdx.x * EPB + eb;
+    bool valid = env < n;
+    int item_ep = 0;
+    if (refill) {
+        valid = item0 + eb < item_cnt;
+        const int2 it = valid ? io.items[item0 + eb] : make_int2(0, 0);
+        env = it.x; item_ep = it.y;
+    }
+    const bool store = valid && gl == 0;
+    const int ei = valid ? env : (refill ? 0 : n - 1);              // clamp so that every lane has something to read; stores are guarded
 #define LAT(w) st[(size_t)F_LAT * npad + (size_t)ei * LAT_ENV_WORDS + (w)]
 #define EB(off) lds[TB_WORDS + eb * GE_STRIDE + (off)]
 #define BK(slot, f) st[(size_t)io.bank_row0 * npad + ((size_t)ei * BANK_DEPTH + (slot)) * BANK_STRIDE + (f)]
@@ -130,18 +192,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     float* const xl = TORSO ? &lds[TB_WORDS + eb * GE_STRIDE + GE_WS] : &lds[eb * X16_RIGID_STRIDE];       // transpose scratch of this environment
     static_assert(GE_WS + X16_WORDS <= GE_STRIDE, "transpose scratch overlays the wrench records");
 
-    if constexpr (TORSO != 0) {
-        // workgroup-resident copy of the lattice tables: 16-byte loads, all issued before the first LDS store
-        const float4* src = reinterpret_cast<const float4*>(M.tables);
-        float4* dst = reinterpret_cast<float4*>(lds);
-        constexpr int NV = TB_WORDS / 4, PER = (NV + NT - 1) / NT;
-        float4 tmp[PER];
-#pragma unroll
-        for (int i = 0; i < PER; ++i) { int idx = threadIdx.x + i * NT; tmp[i] = (idx < NV) ? src[idx] : make_float4(0, 0, 0, 0); }
-#pragma unroll
-        for (int i = 0; i < PER; ++i) { int idx = threadIdx.x + i * NT; if (idx < NV) dst[idx] = tmp[i]; }
-        __syncthreads();
-    }
     USIM_STAMP(dbg, 0);
 
     // ---------------- load: this lane's link record, its joint state, the environment's scalars ----------------
@@ -173,12 +223,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     for (int i = 0; i < NE; ++i) {
         const int e = gl + i * G;
         s_pre[i] = 0.f; sd_pre[i] = 0.f;
-        if (TORSO && e < N_TOP) { s_pre[i] = LAT(LAT_S + e); sd_pre[i] = LAT(LAT_SD + e); }
+        if (TORSO && MODE == 0 && e < N_TOP) { s_pre[i] = LAT(LAT_S + e); sd_pre[i] = LAT(LAT_SD + e); }
+    }
+    if (TORSO != 0 && item0 == item_first) {
+        // workgroup-resident copy of the lattice tables: 16-byte loads, all issued before the first LDS store (and behind the state loads
+        // above, whose HBM latency the copy then covers)
+        const float4* src = reinterpret_cast<const float4*>(M.tables);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        constexpr int NV = TB_WORDS / 4, PER = (NV + NT - 1) / NT;
+        float4 tmp[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { int idx = threadIdx.x + i * NT; tmp[i] = (idx < NV) ? src[idx] : make_float4(0, 0, 0, 0); }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { int idx = threadIdx.x + i * NT; if (idx < NV) dst[idx] = tmp[i]; }
+        __syncthreads();
     }
     USIM_STAMP(dbg, 1);
 
     // ---------------- action (replicated: seven words) ----------------
     float act[7] = {0, 0, 0, 0, 0, 0, 0};
+    if constexpr (MODE == 0) {
     if (flags & LF_RANDOM_ACT) {
         // the two counter blocks are evaluated side by side by the even and odd lanes of the group, then shared
         const uint32_t gid = (uint32_t)(C.env_offset + ei);
@@ -203,30 +267,95 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         }
     }
     t += 1;                                                              // MujocoEnv.step: timestep += 1
+    }
     const float dt = C.dt, inv_h = rcp_((float)C.horizon);
+    const int comp = gl & 3;                                             // task lanes: component of the position (quad 0) / orientation (quad 1) block
+    const bool blk = (gl & 4) != 0;
+    const bool is_task = (gl < 8) && comp != 3;
+    auto pick = [&](f3 v) { return comp == 0 ? v.x : (comp == 1 ? v.y : v.z); };
+
+    bool need = false;                                                   // MODE 1: environments that (re)initialise
+    int ep_t = episode;                                                  // episode index the reset draws are keyed on
+    if constexpr (MODE == 1) {
+        need = refill ? valid : (io.mask ? io.mask[ei] != 0 : true);
+        if (!__any(need)) continue;
+        // ================= reset draws (ultrasound.py:416-478): the three counter blocks side by side in lanes 0, 1, 2 =================
+        ep_t = refill ? item_ep : episode + 1;                           // listed bank episode, or the live reset
+        if (!refill) episode = ep_t;
+        const uint32_t gid = (uint32_t)(C.env_offset + ei);
+        const u4 r = philox(gid, (uint32_t)ep_t, (uint32_t)(gl < 3 ? gl : 2), 0u, C.key0, C.key1);
+        const float ra = __uint_as_float(r.a), rb = __uint_as_float(r.b), rc = __uint_as_float(r.c), rd = __uint_as_float(r.d);
+        u4 A, B, Cc;
+        A.a = __float_as_uint(rbc<0>(ra)); A.b = __float_as_uint(rbc<0>(rb)); A.c = __float_as_uint(rbc<0>(rc)); A.d = __float_as_uint(rbc<0>(rd));
+        B.a = __float_as_uint(rbc<1>(ra)); B.b = __float_as_uint(rbc<1>(rb)); B.c = __float_as_uint(rbc<1>(rc)); B.d = __float_as_uint(rbc<1>(rd));
+        Cc.a = __float_as_uint(rbc<2>(ra)); Cc.b = __float_as_uint(rbc<2>(rb)); Cc.c = __float_as_uint(rbc<2>(rc)); Cc.d = __float_as_uint(rbc<2>(rd));
+        const float tz = M.torso[2] + M.base[2] + C.top_off;             // ultrasound.py:184,807
+        f3 noise = mk(0, 0, 0);
+        kst = C.stiffness; kdmp = C.damping;
+        if (io.reset_params) {
+            const float* p = io.reset_params + (size_t)ei * 13;
+            ts = mk(p[0], p[1], p[2]); te = mk(p[3], p[4], p[5]); u0 = p[6]; noise = mk(p[7], p[8], p[9]);
+            kst = p[10]; kdmp = p[11]; mu = p[12];
+        } else {
+            if (C.det_traj) { ts = mk(0.062f, -0.020f, 0.896f); te = mk(-0.032f, -0.075f, 0.896f); }   // ultrasound.py:763-764
+            else {
+                // ultrasound.py:787-788: np.linspace grids over the torso top, 50 points each
+                const float tx = M.torso[0] + M.base[0], ty = M.torso[1] + M.base[1];
+                const float xs0 = -0.15f + tx + 0.03f, xstep = (0.15f + tx - xs0) / 49.f;
+                const float ys0 = -C.y_range + ty, ystep = 2.f * C.y_range / 49.f;
+                ts = mk(xs0 + (float)urange(A.a, 50u) * xstep, ys0 + (float)urange(A.b, 50u) * ystep, tz);
+                te = mk(xs0 + (float)urange(A.c, 50u) * xstep, ys0 + (float)urange(A.d, 50u) * ystep, tz);
+            }
+            u0 = u01(B.a);                                               // ultrasound.py:443
+            if (C.rand_pos) {                                            // ultrasound.py:880-881
+                const float r1 = sqrtf(-2.f * logf(u01_open(B.b))), th1 = 2.f * PI_F * u01(B.c);
+                const float r2 = sqrtf(-2.f * logf(u01_open(B.d))), th2 = 2.f * PI_F * u01(Cc.a);
+                noise = mk(r1 * cosf(th1) * 0.0025f, r1 * sinf(th1) * 0.0025f, r2 * cosf(th2) * 0.010f);
+            }
+            if (C.rand_solref) { kst = 1300.f + (float)urange(Cc.b, 300u); kdmp = 17.f + (float)urange(Cc.c, 24u); }   // ultrasound.py:293-294
+            float pf = C.probe_fric;
+            if (C.rand_fric) pf *= 0.5f + 1.5f * u01(Cc.d);
+            mu = fmaxf(pf, C.elem_fric);
+        }
+        // ================= initial pose: damped-least-squares IK from init_qpos (ultrasound.py:812-844) =================
+        const float uu = clampf(u0, 0.f, 1.f);
+        const f3 tp0 = ts + (te - ts) * uu;
+        const f3 target = mk(tp0.x + noise.x + 0.0028f - M.base[0], tp0.y + noise.y + 0.0008f - M.base[1], tp0.z + noise.z + 0.0066f - M.base[2]);
+        const f3 gx = mk(M.grot[0], M.grot[3], M.grot[6]), gy = mk(M.grot[1], M.grot[4], M.grot[7]), gz = mk(M.grot[2], M.grot[5], M.grot[8]);
+        qj = jlane ? at[AT_INITQ] : 0.f;
+        for (int it = 0; it < C.ik_iters; ++it) {
+            f3 X, Y, Z, P;
+            fk16(at, qj, X, Y, Z, P);
+            const f3 sx = rbc3<7>(X), sy = rbc3<7>(Y), sz = rbc3<7>(Z), xs = rbc3<7>(P);
+            const f3 eo = (cross(sx, gx) + cross(sy, gy) + cross(sz, gz)) * 0.5f;
+            const f3 ep = target - xs;
+            const float e = is_task ? (blk ? pick(eo) : pick(ep)) : 0.f;
+            const f3 jv = cross(Z, xs - P);
+            const float Jc[6] = {jv.x, jv.y, jv.z, Z.x, Z.y, Z.z};
+            float Jr[8];
+            jacobian_rows(xl, gl, Jc, Jr);
+            // (J J^T + 1e-6 I) y = e, row a in task lane a
+            float A6[6];
+            static_for<6>([&](auto Bc) {
+                constexpr int b = decltype(Bc)::value;
+                float sacc = 0.f;
+                static_for<NJ>([&](auto Jn) { constexpr int j = decltype(Jn)::value; sacc = fmaf(Jr[j], rbc<TASK_LANE[b]>(Jr[j]), sacc); });
+                A6[b] = is_task ? sacc + ((gl == TASK_LANE[b]) ? 1e-6f : 0.f) : 0.f;
+            });
+            const float y = solve6_task(A6, e, gl);
+            const float dq = col_times_task(Jc, y);
+            qj = jlane ? qj + dq : 0.f;
+            group_sync();                                                // the scratch is rewritten by the next iteration / the forward pass
+        }
+        q0j = qj; qdj = 0.f;
+        t = 0; touched = 0; fzprev = 0.f; dfz = 0.f; vbar = 0.f; epret = 0.f; status = 0;
+    }
 
     // =================================================================================================================
     // kinematics: local transform of this lane's link, then the scan  T_l <- T_(l-d) o T_l  for d = 1, 2, 4
     // =================================================================================================================
     f3 X, Y, Z, P;                                                       // world rotation columns and origin of this lane's frame
-    {
-        float s, c;
-        sincos_(qj, s, c);                                               // lanes without a joint carry q = 0: s = 0, c = 1 exactly
-        const f3 f0 = mk(at[AT_RFIX], at[AT_RFIX + 1], at[AT_RFIX + 2]), f1 = mk(at[AT_RFIX + 3], at[AT_RFIX + 4], at[AT_RFIX + 5]);
-        X = f0 * c + f1 * s; Y = f1 * c - f0 * s; Z = mk(at[AT_RFIX + 6], at[AT_RFIX + 7], at[AT_RFIX + 8]);
-        P = mk(at[AT_LPOS], at[AT_LPOS + 1], at[AT_LPOS + 2]);
-    }
-    static_for<3>([&](auto Dc) {
-        constexpr int D = 1 << decltype(Dc)::value;
-        // lanes l < D read the identity (fill values of the shift): their frame is already complete
-        const f3 LX = mk(rshr<D>(X.x, 1.f), rshr<D>(X.y, 0.f), rshr<D>(X.z, 0.f));
-        const f3 LY = mk(rshr<D>(Y.x, 0.f), rshr<D>(Y.y, 1.f), rshr<D>(Y.z, 0.f));
-        const f3 LZ = mk(rshr<D>(Z.x, 0.f), rshr<D>(Z.y, 0.f), rshr<D>(Z.z, 1.f));
-        const f3 LP = mk(rshr0<D>(P.x), rshr0<D>(P.y), rshr0<D>(P.z));
-        const f3 nX = LX * X.x + LY * X.y + LZ * X.z, nY = LX * Y.x + LY * Y.y + LZ * Y.z, nZ = LX * Z.x + LY * Z.y + LZ * Z.z;
-        P = LP + LX * P.x + LY * P.y + LZ * P.z;
-        X = nX; Y = nY; Z = nZ;
-    });
+    fk16(at, qj, X, Y, Z, P);
     const f3 rcm = X * at[AT_LCOM] + Y * at[AT_LCOM + 1] + Z * at[AT_LCOM + 2];      // link COM relative to the link origin
     const f3 cm_ = P + rcm;
     // site frame = lane 7's; hand origin = a fixed point of the last link
@@ -314,30 +443,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         float Xm[6];                                                     // row l of M^-1 J^T
 #pragma unroll
         for (int a = 0; a < 6; ++a) Xm[a] = row_times_joint<NJ>(Mi, Jc[a]);
-        if (gl < 8) {
-#pragma unroll
-            for (int a = 0; a < 6; ++a) xl[a * 8 + gl] = Jc[a];
-        }
-        group_sync();
-        int arow = (gl & 7) - ((gl & 4) ? 1 : 0);
-        arow = arow > 5 ? 5 : arow;
-        {
-            const float4 j0 = *reinterpret_cast<const float4*>(&xl[arow * 8]), j1 = *reinterpret_cast<const float4*>(&xl[arow * 8 + 4]);
-            Jr[0] = j0.x; Jr[1] = j0.y; Jr[2] = j0.z; Jr[3] = j0.w; Jr[4] = j1.x; Jr[5] = j1.y; Jr[6] = j1.z; Jr[7] = j1.w;
-        }
+        jacobian_rows(xl, gl, Jc, Jr);
 #pragma unroll
         for (int b = 0; b < 6; ++b) Li[b] = row_times_joint<NJ>(Jr, Xm[b]);
     }
-    const int comp = gl & 3;
-    const bool blk = (gl & 4) != 0;
-    const bool is_task = (gl < 8) && comp != 3;
     const float v6 = row_times_joint<NJ>(Jr, qdj);                       // site twist component of this task lane
     USIM_STAMP(dbg, 3);
 
     // ---------------- OSC_POSE torque (robosuite osc.py run_controller; rl_config.yaml:33-51) ----------------
-    float tau;
-    {
-        auto pick = [&](f3 v) { return comp == 0 ? v.x : (comp == 1 ? v.y : v.z); };
+    float tau = 0.f;                                                     // reset: sim.forward() with zero ctrl
+    if constexpr (MODE == 0) {
         const int arow = blk ? 3 + (comp > 2 ? 2 : comp) : (comp > 2 ? 2 : comp);
         float act_own = act[0];
 #pragma unroll
@@ -395,19 +510,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         float A[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) A[c] = is_task ? Li[c] : 0.f;       // lanes without a task row: zero rows, never pivots
-        jb = is_task ? jb : 0.f;
-        static_for<6>([&](auto Kc) {
-            constexpr int k = decltype(Kc)::value;
-            constexpr int lk = TASK_LANE[k];
-            const float g = (A[k] - (gl == lk ? 1.f : 0.f)) * rcp_(rbc<lk>(A[k]));
-#pragma unroll
-            for (int c = k + 1; c < 6; ++c) A[c] = fmaf(-g, rbc<lk>(A[c]), A[c]);
-            jb = fmaf(-g, rbc<lk>(jb), jb);
-        });
+        jb = solve6_task(A, is_task ? jb : 0.f, gl);
         const float tq_ = bias + y + col_times_task(Jc, wr - jb);
         tau = clampf(tq_, -at[AT_TAUMAX], at[AT_TAUMAX]);
     }
-    if (io.log && valid) {
+    if (MODE == 0 && io.log && valid) {
         float* L = io.log + (size_t)ei * LOG_WIDTH;
         if (jlane) L[33 + gl] = tau;
         if (gl == 0) {
@@ -425,10 +532,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     for (int k = 0; k < MAXC; ++k) con_shell[k] = -1;
     if constexpr (TORSO != 0) {
         const int* tb_shell = reinterpret_cast<const int*>(lds + TB_SHELL);
-        const int tsim = t - 1;
+        const int tsim = (t > 0) ? t - 1 : 0;
         float dz, vz, az;
         torso_motion(C, tsim, dz, vz, az);
-        int nc = lattice_front<G, NE, true>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, true, s_pre, sd_pre, xs, sy, sz, dbg);
+        int nc = lattice_front<G, NE, true>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, MODE == 0, s_pre, sd_pre, xs, sy, sz, dbg);
         USIM_STAMP(dbg, 7);
         if (nc > MAXC) { overflow = 1; nc = MAXC; }
         ncon = nc;
@@ -454,8 +561,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             contact_solve<G>(lds, eb, gl, M, C, nc, ncmax, cel, Lp, alpha, vs, mu, vz, W, gf, dbg);
         }
         USIM_STAMP(dbg, 11);
-        // ---- element accelerations a = a~ + Linv[:, e_c] gf_c, semi-implicit Euler, write back ----
-        {
+        // ---- element accelerations a = a~ + Linv[:, e_c] gf_c, semi-implicit Euler, write back (a reset leaves the lattice at rest) ----
+        if constexpr (MODE == 1) {
+            if (valid && need && !refill) for (int e = gl; e < N_TOP; e += G) { LAT(LAT_S + e) = 0.f; LAT(LAT_SD + e) = 0.f; }
+        } else {
             float acc_e[NE];
 #pragma unroll
             for (int i = 0; i < NE; ++i) { const int e = gl + i * G; acc_e[i] = (e < N_TOP) ? EB(GE_A + e) : 0.f; }
@@ -511,25 +620,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         const f3 tw = N + cross(P + rc - xs, Fp) - mk(W[3], W[4], W[5]);
         tq[0] = rbc<NJ - 1>(dot(sx, tw)); tq[1] = rbc<NJ - 1>(dot(sy, tw)); tq[2] = rbc<NJ - 1>(dot(sz, tw));
         USIM_STAMP(dbg, 13);
-        // mj_Euler with implicit joint damping: (M + h D) x = M qacc, one fixed-point step on M^-1
-        const float xk = row_times_joint<NJ>(Mi, qacc);
-        const float rhs = fmaf(-dt * JOINT_DAMP, xk, qacc);
-        qdj = fmaf(dt, rhs, qdj); qj = fmaf(dt, qdj, qj);
-        if (!jlane) { qdj = 0.f; qj = 0.f; }
-        // hand velocity: Jacobian from before the integration, qvel from after (mj_step data semantics)
-        const float v2_t = row_times_joint<NJ>(Jr, qdj);
-        float v2[6];
-        static_for<6>([&](auto Ac) { constexpr int a = decltype(Ac)::value; v2[a] = rbc<TASK_LANE[a]>(v2_t); });
-        hv = mk(v2[0], v2[1], v2[2]) + cross(mk(v2[3], v2[4], v2[5]), hand - xs);
+        hv = mk(0, 0, 0);
+        if constexpr (MODE == 0) {
+            // mj_Euler with implicit joint damping: (M + h D) x = M qacc, one fixed-point step on M^-1
+            const float xk = row_times_joint<NJ>(Mi, qacc);
+            const float rhs = fmaf(-dt * JOINT_DAMP, xk, qacc);
+            qdj = fmaf(dt, rhs, qdj); qj = fmaf(dt, qdj, qj);
+            if (!jlane) { qdj = 0.f; qj = 0.f; }
+            // hand velocity: Jacobian from before the integration, qvel from after (mj_step data semantics)
+            const float v2_t = row_times_joint<NJ>(Jr, qdj);
+            float v2[6];
+            static_for<6>([&](auto Ac) { constexpr int a = decltype(Ac)::value; v2[a] = rbc<TASK_LANE[a]>(v2_t); });
+            hv = mk(v2[0], v2[1], v2[2]) + cross(mk(v2[3], v2[4], v2[5]), hand - xs);
+        }
     }
     USIM_STAMP(dbg, 14);
 
     // ---------------- observation (ultrasound.py:363-401), reward (:230-269), bookkeeping (:528-546), termination (:635-670) ----------------
     float obs[OBS_DIM];
-    bool done, need;
+    bool done = false;
     {
-        const float up = clampf((float)(t - 1) * inv_h + u0, 0.f, 1.f);
+        const int tprev = (MODE == 0) ? t - 1 : 0;
+        const float up = clampf((float)tprev * inv_h + u0, 0.f, 1.f);
         const f3 tpw = ts + (te - ts) * up;
+        if (MODE == 1) fzbar = W[2];                                     // ultrasound.py:477
         obs[0] = W[0]; obs[1] = W[1]; obs[2] = W[2];
         obs[3] = tq[0]; obs[4] = tq[1]; obs[5] = tq[2];
         obs[6] = hv.x; obs[7] = hv.y; obs[8] = hv.z;
@@ -538,6 +652,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         obs[12] = xw.x - tpw.x; obs[13] = xw.y - tpw.y; obs[14] = xw.z - tpw.z;
         float qe[4]; mat2quat_xyzw(sx, sy, sz, qe);
         difference_quat(qe, M.gquat, obs + 15);                          // xyzw arrays through the wxyz routine (ultrasound.py:390)
+        if constexpr (MODE == 1) {
+            if (overflow) status |= 1;
+            if (refill) {
+                // reset computed ahead of time: park it in the bank slot of episode ep_t
+                if (valid && need) {
+                    const int sl = ep_t & (BANK_DEPTH - 1);
+                    if (jlane) BK(sl, BQ0 + gl) = qj;
+                    if (gl == 0) {
+                        BK(sl, BTS) = ts.x; BK(sl, BTS + 1) = ts.y; BK(sl, BTS + 2) = ts.z; BK(sl, BTE) = te.x; BK(sl, BTE + 1) = te.y; BK(sl, BTE + 2) = te.z;
+                        BK(sl, BU0) = u0; BK(sl, BKST) = kst; BK(sl, BKDMP) = kdmp; BK(sl, BMU) = mu; BK(sl, BFZ) = fzbar;
+#pragma unroll
+                        for (int a = 0; a < OBS_DIM; ++a) BK(sl, BOBS + a) = obs[a];
+                        BKI(sl, BSTATUS) = overflow ? 1 : 0;
+                    }
+                }
+            } else if (store && io.obs && need) {
+#pragma unroll
+                for (int a = 0; a < OBS_DIM; ++a) io.obs[(size_t)ei * OBS_DIM + a] = obs[a];
+            }
+        } else {
         const bool contact = ncon > 0;
         if (contact) touched = 1;
         float pe0 = 90.f * (xw.x - tpw.x), pe1 = 90.f * (xw.y - tpw.y);
@@ -614,9 +748,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 #pragma unroll
             for (int a = 0; a < OBS_DIM; ++a) io.obs[(size_t)ei * OBS_DIM + a] = obs[a];
         }
+        }
     }
 
-    if (need) {
+    if (MODE == 0 && need) {
         // ================= auto-reset: adopt the initial state prepared in the reset bank and queue the slot for refill =================
         episode += 1;
         const int sl = episode & (BANK_DEPTH - 1);
@@ -634,7 +769,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     USIM_STAMP(dbg, 15);
 
     // ---------------- store state: joint words by their lanes, the scalar quads by the group's first lane ----------------
-    if (valid) {
+    if (valid && (MODE == 0 || (need && !refill))) {
         float* const so = st + scalar_index(0, (size_t)ei);
         if (jlane) {
             so[F_Q + gl] = qj; so[F_QD + gl] = qdj;
@@ -649,6 +784,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             s4[7] = make_float4(vbar, fzbar, fzprev, dfz);
             s4[8] = make_float4(kst, kdmp, mu, __int_as_float(t));
             s4[9] = make_float4(__int_as_float(touched), __int_as_float(episode), epret, __int_as_float(status));
+        }
+    }
+    if (refill) group_sync();                                            // the next item reuses the per-environment LDS block
+    }   // item loop
+    if (MODE == 1 && refill) {
+        // the last workgroup to finish empties the work list for the step kernels that follow on the stream
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(io.count + 1, 1) == (int)gridDim.x - 1) { io.count[0] = 0; io.count[1] = 0; }
         }
     }
     USIM_STAMP(dbg, 16);

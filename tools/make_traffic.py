@@ -1,5 +1,5 @@
 """profiles/<round>/traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/profile.sh.
-usage: python tools/make_traffic.py gpurun_out/prof_<soft tag> gpurun_out/prof_<rigid tag> > profiles/r01/traffic.json"""
+usage: python tools/make_traffic.py gpurun_out/prof_<soft tag> gpurun_out/prof_<rigid tag> > profiles/<round>/traffic.json"""
 import csv, glob, json, os, sys
 
 def mean_kb(root, sub, counter):
@@ -8,7 +8,8 @@ def mean_kb(root, sub, counter):
         with open(f) as fh:
             for r in csv.DictReader(fh):
                 name = r["Kernel_Name"].replace(" ", "")
-                if "usim_step_kernel" in name and name.split(">(")[0].endswith(",0") and r["Counter_Name"] == counter:
+                is_step = "usim_step16_kernel" in name or ("usim_step_kernel" in name and name.split(">(")[0].endswith(",0"))
+                if is_step and r["Counter_Name"] == counter:
                     vals.append(float(r["Counter_Value"]))
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
