@@ -80,25 +80,55 @@ static const double BASE_WORLD[3] = {-0.56, 0.0, 0.913};   /* ultrasound.py:279-
 #define TORSO_HALF_HEIGHT 0.0525
 #define GRAV 9.81
 
-/* Panda (robosuite asset, un-vendored) -- the build's own model definition */
-static const double LINK_POS[NJ][3] = {
-    {0, 0, 0.333}, {0, 0, 0}, {0, -0.316, 0}, {0.0825, 0, 0}, {-0.0825, 0.384, 0}, {0, 0, 0}, {0.088, 0, 0}};
-static const double LINK_QUAT_WXYZ[NJ][4] = {
-    {1, 0, 0, 0}, {0.7071067811865476, -0.7071067811865476, 0, 0}, {0.7071067811865476, 0.7071067811865476, 0, 0},
-    {0.7071067811865476, 0.7071067811865476, 0, 0}, {0.7071067811865476, -0.7071067811865476, 0, 0},
-    {0.7071067811865476, 0.7071067811865476, 0, 0}, {0.7071067811865476, 0.7071067811865476, 0, 0}};
-static const double LINK_MASS[NJ] = {3, 3, 2, 2, 2, 1.5, 0.5};
-static const double LINK_COM[NJ][3] = {
-    {0, 0, -0.07}, {0, -0.1, 0}, {0.04, 0, -0.05}, {-0.04, 0.05, 0}, {0, 0, -0.15}, {0.06, 0, 0}, {0, 0, 0.08}};
-static const double LINK_INERTIA[NJ] = {0.3, 0.3, 0.2, 0.2, 0.2, 0.1, 0.05};  /* isotropic diaginertia */
-static const double Q_MIN[NJ] = {-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973};
-static const double Q_MAX[NJ] = {2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973};
-static const double TAU_MAX[NJ] = {80, 80, 80, 80, 12, 12, 12};
+/* Robot descriptions in the form of the robosuite MJCF assets (un-vendored; SURVEY.md Appendix B.4 -- the build's own model definition,
+ * RECALLED from robosuite v1.2 robots/{panda,ur5e}/robot.xml): per body the position and orientation in the parent body frame, the joint
+ * axis in the body frame ('y' or 'z'), inertial frame (COM, principal-axes quaternion, diagonal inertia), joint range, torque limit and
+ * init_qpos; then the right_hand body on the last link.  build_model() turns this into the z-aligned chain the kinematics use: a fixed
+ * rotation Rc (z -> joint axis) is folded into every link frame.  A chain shorter than NJ is padded with locked unit-inertia joints
+ * (identity transform, no mass): the state layout stays at NJ joints, the padded entries stay zero. */
+typedef struct {
+    int nj;
+    double pos[NJ][3], quat[NJ][4];
+    char axis[NJ];
+    double mass[NJ], com[NJ][3], iquat[NJ][4], diag[NJ][3];
+    double qmin[NJ], qmax[NJ], taumax[NJ], initq[NJ];
+    double hand_pos[3], hand_quat[4];
+    double ik_bias[3];        /* systematic offset of the reference's DH-model IK seen in the decoded reset observations (Panda only) */
+} RobotDesc;
+#define Q90 0.7071067811865476
+static const RobotDesc ROBOT_PANDA = {
+    7,
+    {{0, 0, 0.333}, {0, 0, 0}, {0, -0.316, 0}, {0.0825, 0, 0}, {-0.0825, 0.384, 0}, {0, 0, 0}, {0.088, 0, 0}},
+    {{1, 0, 0, 0}, {Q90, -Q90, 0, 0}, {Q90, Q90, 0, 0}, {Q90, Q90, 0, 0}, {Q90, -Q90, 0, 0}, {Q90, Q90, 0, 0}, {Q90, Q90, 0, 0}},
+    {'z', 'z', 'z', 'z', 'z', 'z', 'z'},
+    {3, 3, 2, 2, 2, 1.5, 0.5},
+    {{0, 0, -0.07}, {0, -0.1, 0}, {0.04, 0, -0.05}, {-0.04, 0.05, 0}, {0, 0, -0.15}, {0.06, 0, 0}, {0, 0, 0.08}},
+    {{1, 0, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}},
+    {{0.3, 0.3, 0.3}, {0.3, 0.3, 0.3}, {0.2, 0.2, 0.2}, {0.2, 0.2, 0.2}, {0.2, 0.2, 0.2}, {0.1, 0.1, 0.1}, {0.05, 0.05, 0.05}},
+    {-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973},
+    {2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973},
+    {80, 80, 80, 80, 12, 12, 12},
+    {0.0, PI / 16.0, 0.0, -PI / 2.0 - PI / 3.0, 0.0, PI - 0.2, PI / 4.0},
+    {0, 0, 0.107}, {0.9238795325112867, 0, 0, -0.3826834323650898},       /* right_hand: yaw -45 deg */
+    {0.0028, 0.0008, 0.0066}};
+static const RobotDesc ROBOT_UR5E = {
+    6,
+    {{0, 0, 0.163}, {0, 0.138, 0}, {0, -0.131, 0.425}, {0, 0, 0.392}, {0, 0.127, 0}, {0, 0, 0.1}, {0, 0, 0}},
+    {{1, 0, 0, 0}, {Q90, 0, Q90, 0}, {1, 0, 0, 0}, {Q90, 0, Q90, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}},
+    {'z', 'y', 'y', 'y', 'z', 'y', 'z'},
+    {3.7, 8.393, 2.275, 1.219, 1.219, 0.1889, 0},
+    {{0, 0, 0}, {0, 0, 0.2125}, {0, 0, 0.196}, {0, 0.127, 0}, {0, 0, 0.1}, {0, 0.0771683, 0}, {0, 0, 0}},
+    {{1, 0, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}, {Q90, 0, 0, Q90}, {1, 0, 0, 0}},
+    {{0.0102675, 0.0102675, 0.00666}, {0.133886, 0.133886, 0.0151074}, {0.0311796, 0.0311796, 0.004095}, {0.0025599, 0.0025599, 0.0021942},
+     {0.0025599, 0.0025599, 0.0021942}, {0.000132134, 9.90863e-05, 9.90863e-05}, {0, 0, 0}},
+    {-6.28319, -6.28319, -3.14159, -6.28319, -6.28319, -6.28319, 0},
+    {6.28319, 6.28319, 3.14159, 6.28319, 6.28319, 6.28319, 0},
+    {150, 150, 150, 28, 28, 28, 1},
+    {-0.470, -1.735, 2.480, -2.275, -1.590, -1.991, 0},
+    {0, 0.098, 0}, {Q90, -Q90, 0, 0},                                       /* right_hand on wrist_3_link */
+    {0, 0, 0}};
 #define JOINT_DAMPING 0.1
-static const double INIT_QPOS[NJ] = {0.0, PI / 16.0, 0.0, -PI / 2.0 - PI / 3.0, 0.0, PI - 0.2, PI / 4.0};
-/* hand body on link7, then the probe body (ultrasound_probe_gripper.xml:6) */
-static const double HAND_POS[3] = {0, 0, 0.107};
-#define HAND_YAW (-PI / 4.0)
+/* right_hand body on the last link (0.5 kg, isotropic), then the probe body (ultrasound_probe_gripper.xml:6) */
 #define HAND_MASS 0.5
 #define HAND_INERTIA 0.05
 static const double PROBE_POS[3] = {-0.004, -0.063, 0.128};   /* ultrasound_probe_gripper.xml:6 */
@@ -131,8 +161,6 @@ static const double PROBE_INERTIA[3] = {1.6e-3, 1.6e-3, 2.0e-4};
 #define SOLIMP_DMAX 0.95
 #define SOLIMP_WIDTH 0.001
 #define IMPRATIO 20.0                 /* robosuite base.xml option impratio=20 cone=elliptic [RESTATED] */
-/* systematic offset of the reference's DH-Panda IK seen in the decoded reset observations */
-static const double INIT_POS_BIAS[3] = {0.0028, 0.0008, 0.0066};
 
 /* ------------------------------------------------------------------------------------------------
  * small helpers
@@ -213,6 +241,8 @@ typedef struct {
     /* robot tree in base-centred world axes */
     real link_pos[NJ][3], link_rot[NJ][9];
     real mass[NJ], com[NJ][3], inertia[NJ][9];      /* link-frame COM and inertia about COM (link 7 = composite with hand+probe) */
+    int active[NJ];                                 /* 0: padding joint of a shorter chain (locked, unit inertia, no Jacobian column) */
+    double qmin[NJ], qmax[NJ], taumax[NJ], initq[NJ], ik_bias[3];
     real site_pos7[3], site_rot7[9];                /* eef site (grip_site == ft_frame) in link-7 frame */
     real hand_pos7[3];                              /* right_hand body origin in link-7 frame */
     real probe_com7[3], probe_inertia7[9];          /* probe body alone (torque sensor), link-7 frame */
@@ -291,21 +321,58 @@ static void rne(const Model* m, const real* q, const real* qd, const real* qdd, 
 static void build_model(Sim* S) {
     Model* m = &S->m;
     memset(m, 0, sizeof *m);
+    const RobotDesc* rd = (S->cfg.robot == USO_ROBOT_UR5E) ? &ROBOT_UR5E : &ROBOT_PANDA;
+    /* z-aligned chain: link frame F'_i = F_i Rc_i with Rc_i z = joint axis, so that F'_i = F'_(i-1) [Rc_(i-1)^T T_i Rc_i] Rz(q_i) */
+    static const double RC_Y[9] = {1, 0, 0, 0, 0, 1, 0, -1, 0};            /* Rx(-90 deg): z -> y */
+    static const double RC_Z[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    const double* Rcp = RC_Z;
     for (int i = 0; i < NJ; i++) {
-        for (int k = 0; k < 3; k++) { m->link_pos[i][k] = (real)LINK_POS[i][k]; m->com[i][k] = (real)LINK_COM[i][k]; }
-        quat_wxyz_to_mat(m->link_rot[i], LINK_QUAT_WXYZ[i]);
-        m->mass[i] = (real)LINK_MASS[i];
-        for (int k = 0; k < 9; k++) m->inertia[i][k] = 0;
-        m->inertia[i][0] = m->inertia[i][4] = m->inertia[i][8] = (real)LINK_INERTIA[i];
+        const int real_joint = i < rd->nj;
+        const double* Rc = real_joint ? (rd->axis[i] == 'y' ? RC_Y : RC_Z) : Rcp;   /* padding keeps the alignment: identity transform */
+        m->active[i] = real_joint;
+        m->qmin[i] = real_joint ? rd->qmin[i] : -1e30; m->qmax[i] = real_joint ? rd->qmax[i] : 1e30;
+        m->taumax[i] = real_joint ? rd->taumax[i] : 1.0; m->initq[i] = real_joint ? rd->initq[i] : 0.0;
+        double Rq[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pos[3] = {0, 0, 0}, com[3] = {0, 0, 0}, Il[9] = {0};
+        if (real_joint) {
+            real Rq_r[9], Ri_r[9];
+            quat_wxyz_to_mat(Rq_r, rd->quat[i]); quat_wxyz_to_mat(Ri_r, rd->iquat[i]);
+            for (int k = 0; k < 9; k++) Rq[k] = (double)Rq_r[k];
+            for (int k = 0; k < 3; k++) { pos[k] = rd->pos[i][k]; com[k] = rd->com[i][k]; }
+            for (int a2 = 0; a2 < 3; a2++) for (int b2 = 0; b2 < 3; b2++) { double sacc = 0; for (int k = 0; k < 3; k++) sacc += (double)Ri_r[3 * a2 + k] * rd->diag[i][k] * (double)Ri_r[3 * b2 + k]; Il[3 * a2 + b2] = sacc; }
+        }
+        /* fixed transform in the parent's z-aligned frame, inertial parameters in this link's z-aligned frame */
+        double T1[9], Rf[9], I1[9], I2[9];
+        for (int a2 = 0; a2 < 3; a2++) for (int b2 = 0; b2 < 3; b2++) { double sacc = 0; for (int k = 0; k < 3; k++) sacc += Rcp[3 * k + a2] * Rq[3 * k + b2]; T1[3 * a2 + b2] = sacc; }     /* Rcp^T Rq */
+        for (int a2 = 0; a2 < 3; a2++) for (int b2 = 0; b2 < 3; b2++) { double sacc = 0; for (int k = 0; k < 3; k++) sacc += T1[3 * a2 + k] * Rc[3 * k + b2]; Rf[3 * a2 + b2] = sacc; }
+        for (int a2 = 0; a2 < 3; a2++) for (int b2 = 0; b2 < 3; b2++) { double sacc = 0; for (int k = 0; k < 3; k++) sacc += Rc[3 * k + a2] * Il[3 * k + b2]; I1[3 * a2 + b2] = sacc; }       /* Rc^T I */
+        for (int a2 = 0; a2 < 3; a2++) for (int b2 = 0; b2 < 3; b2++) { double sacc = 0; for (int k = 0; k < 3; k++) sacc += I1[3 * a2 + k] * Rc[3 * k + b2]; I2[3 * a2 + b2] = sacc; }
+        for (int a2 = 0; a2 < 3; a2++) {
+            double sp = 0, sc = 0;
+            for (int k = 0; k < 3; k++) { sp += Rcp[3 * k + a2] * pos[k]; sc += Rc[3 * k + a2] * com[k]; }
+            m->link_pos[i][a2] = (real)sp; m->com[i][a2] = (real)sc;
+        }
+        for (int k = 0; k < 9; k++) { m->link_rot[i][k] = (real)Rf[k]; m->inertia[i][k] = (real)I2[k]; }
+        m->mass[i] = real_joint ? (real)rd->mass[i] : 0;
+        Rcp = Rc;
     }
-    /* hand rotation about z by HAND_YAW (robosuite right_hand quat 0.924 0 0 -0.383) */
-    double ch = cos(HAND_YAW), sh = sin(HAND_YAW);
-    double Rh[9] = {ch, -sh, 0, sh, ch, 0, 0, 0, 1};
+    for (int k = 0; k < 3; k++) m->ik_bias[k] = rd->ik_bias[k];
+    const int last = rd->nj - 1;                    /* the link that carries hand and probe; links behind it are padding with identity transforms */
+    /* right_hand frame in the last link's z-aligned frame */
+    double Rh[9], HAND_POS[3];
+    {
+        real Rq_r[9]; quat_wxyz_to_mat(Rq_r, rd->hand_quat);
+        for (int a2 = 0; a2 < 3; a2++) {
+            double sp = 0;
+            for (int k = 0; k < 3; k++) sp += Rcp[3 * k + a2] * rd->hand_pos[k];
+            HAND_POS[a2] = sp;
+            for (int b2 = 0; b2 < 3; b2++) { double sacc = 0; for (int k = 0; k < 3; k++) sacc += Rcp[3 * k + a2] * (double)Rq_r[3 * k + b2]; Rh[3 * a2 + b2] = sacc; }
+        }
+    }
     double site7[3];
     for (int i = 0; i < 3; i++) site7[i] = HAND_POS[i] + Rh[3 * i] * PROBE_POS[0] + Rh[3 * i + 1] * PROBE_POS[1] + Rh[3 * i + 2] * PROBE_POS[2];
     for (int i = 0; i < 3; i++) { m->site_pos7[i] = (real)site7[i]; m->hand_pos7[i] = (real)HAND_POS[i]; }
     for (int i = 0; i < 9; i++) m->site_rot7[i] = (real)Rh[i];
-    /* probe COM and inertia in link-7 frame */
+    /* probe COM and inertia in the last link's frame */
     double pc7[3], Ip7[9];
     for (int i = 0; i < 3; i++) pc7[i] = site7[i] + Rh[3 * i] * PROBE_COM[0] + Rh[3 * i + 1] * PROBE_COM[1] + Rh[3 * i + 2] * PROBE_COM[2];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
@@ -314,15 +381,15 @@ static void build_model(Sim* S) {
     }
     for (int i = 0; i < 3; i++) m->probe_com7[i] = (real)pc7[i];
     for (int i = 0; i < 9; i++) m->probe_inertia7[i] = (real)Ip7[i];
-    /* link 7 composite = link7 + hand + probe (no joints between them) */
-    double mc = LINK_MASS[6], cc[3] = {LINK_COM[6][0], LINK_COM[6][1], LINK_COM[6][2]};
-    double Ic[9] = {LINK_INERTIA[6], 0, 0, 0, LINK_INERTIA[6], 0, 0, 0, LINK_INERTIA[6]};
+    /* last link composite = link + hand + probe (no joints between them) */
+    double mc = (double)m->mass[last], cc[3] = {(double)m->com[last][0], (double)m->com[last][1], (double)m->com[last][2]};
+    double Ic[9]; for (int k = 0; k < 9; k++) Ic[k] = (double)m->inertia[last][k];
     double Ih[9] = {HAND_INERTIA, 0, 0, 0, HAND_INERTIA, 0, 0, 0, HAND_INERTIA};
     merge_inertia(&mc, cc, Ic, HAND_MASS, HAND_POS, Ih);
     merge_inertia(&mc, cc, Ic, PROBE_MASS, pc7, Ip7);
-    m->mass[6] = (real)mc;
-    for (int i = 0; i < 3; i++) m->com[6][i] = (real)cc[i];
-    for (int i = 0; i < 9; i++) m->inertia[6][i] = (real)Ic[i];
+    m->mass[last] = (real)mc;
+    for (int i = 0; i < 3; i++) m->com[last][i] = (real)cc[i];
+    for (int i = 0; i < 9; i++) m->inertia[last][i] = (real)Ic[i];
     /* probe collision capsule in the site frame */
     v3set(m->cap_c_site, 0, 0, (real)(-S->cfg.probe_radius));
     v3set(m->cap_axis_site, 0, 1, 0);
@@ -404,19 +471,20 @@ static void build_model(Sim* S) {
      * body_invweight0], probe at init_qpos, element = (1/m + 2/M_torso)/3 */
     {
         real q[NJ], z[NJ] = {0}, o[NJ][3], R[NJ][9], Mm[NJ * NJ], col[NJ], t0[NJ];
-        for (int i = 0; i < NJ; i++) q[i] = (real)INIT_QPOS[i];
+        for (int i = 0; i < NJ; i++) q[i] = (real)m->initq[i];
         rne(m, q, z, z, 0, t0, 0, 0, 0, o, R);
         for (int j = 0; j < NJ; j++) {
             real e[NJ] = {0}; e[j] = 1;
             rne(m, q, z, e, 0, col, 0, 0, 0, o, R);
             for (int i = 0; i < NJ; i++) Mm[i * NJ + j] = col[i];
         }
+        for (int j = 0; j < NJ; j++) if (!m->active[j]) Mm[j * NJ + j] = 1;
         chol(Mm, NJ);
         real x[3], tmp[3]; m3mulv(tmp, R[6], m->site_pos7); v3add(x, o[6], tmp);
         double tr = 0;
         for (int ax = 0; ax < 3; ax++) {
             real jt[NJ];
-            for (int i = 0; i < NJ; i++) { real zi[3] = {R[i][2], R[i][5], R[i][8]}, r[3], c[3]; v3sub(r, x, o[i]); v3cross(c, zi, r); jt[i] = c[ax]; }
+            for (int i = 0; i < NJ; i++) { real zi[3] = {R[i][2], R[i][5], R[i][8]}, r[3], c[3]; v3sub(r, x, o[i]); v3cross(c, zi, r); jt[i] = m->active[i] ? c[ax] : 0; }
             real y[NJ]; memcpy(y, jt, sizeof y); chol_solve(Mm, NJ, y);
             for (int i = 0; i < NJ; i++) tr += (double)(jt[i] * y[i]);
         }
@@ -506,6 +574,7 @@ static void kin_dyn(const Model* m, const real* q, const real* qd, KinDyn* k) {
         for (int i = 0; i < NJ; i++) k->M[i * NJ + j] = col[i];
     }
     for (int i = 0; i < NJ; i++) for (int j = 0; j < i; j++) { real s = (real)0.5 * (k->M[i * NJ + j] + k->M[j * NJ + i]); k->M[i * NJ + j] = k->M[j * NJ + i] = s; }
+    for (int j = 0; j < NJ; j++) if (!m->active[j]) k->M[j * NJ + j] = 1;       /* padding joint: locked, decoupled */
     memcpy(k->Lm, k->M, sizeof k->M);
     chol(k->Lm, NJ);
     real t[3];
@@ -515,7 +584,7 @@ static void kin_dyn(const Model* m, const real* q, const real* qd, KinDyn* k) {
     for (int i = 0; i < NJ; i++) {
         real z[3] = {k->R[i][2], k->R[i][5], k->R[i][8]}, r[3], c[3];
         v3sub(r, k->x, k->o[i]); v3cross(c, z, r);
-        for (int a = 0; a < 3; a++) { k->J[a][i] = c[a]; k->J[3 + a][i] = z[a]; }
+        for (int a = 0; a < 3; a++) { k->J[a][i] = m->active[i] ? c[a] : 0; k->J[3 + a][i] = m->active[i] ? z[a] : 0; }
     }
 }
 
@@ -568,7 +637,7 @@ static void osc_torque(const Sim* S, const KinDyn* k, const real* q, const real*
     for (int a = 0; a < 6; a++) { real s = 0; for (int i = 0; i < NJ; i++) s += MiJt[i][a] * ptm[i]; jb[a] = s; }   /* (M^-1 J^T)^T y */
     for (int a = 0; a < 6; a++) { real s = 0; for (int b = 0; b < 6; b++) s += lam_full[b * 6 + a] * jb[b]; lj[a] = s; } /* lam^T (..) */
     for (int i = 0; i < NJ; i++) { real s = ptm[i]; for (int a = 0; a < 6; a++) s -= k->J[a][i] * lj[a]; tau[i] += s; }
-    for (int i = 0; i < NJ; i++) { real lim = (real)TAU_MAX[i]; if (tau[i] > lim) tau[i] = lim; if (tau[i] < -lim) tau[i] = -lim; }
+    for (int i = 0; i < NJ; i++) { real lim = (real)S->m.taumax[i]; if (tau[i] > lim) tau[i] = lim; if (tau[i] < -lim) tau[i] = -lim; }
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -967,13 +1036,13 @@ static void reset_env(Sim* S, int i, const double* ex /* explicit draws or NULL 
      * the decoded fixtures is eef = target + INIT_POS_BIAS.  Restated as fixed-count damped least squares. */
     real tp[3], target[3];
     traj_eval(S, E, 0, tp);
-    for (int a = 0; a < 3; a++) target[a] = tp[a] + (real)(noise[a] + INIT_POS_BIAS[a] - BASE_WORLD[a]);
-    real q[NJ]; for (int j = 0; j < NJ; j++) q[j] = (real)INIT_QPOS[j];
+    for (int a = 0; a < 3; a++) target[a] = tp[a] + (real)(noise[a] + m->ik_bias[a] - BASE_WORLD[a]);
+    real q[NJ]; for (int j = 0; j < NJ; j++) q[j] = (real)m->initq[j];
     for (int it = 0; it < c->ik_iters; it++) {
         real o[NJ][3], R[NJ][9], x[3], Rs[9], t[3], J[6][NJ], e[6];
         fk_all(m, q, o, R);
         m3mulv(t, R[6], m->site_pos7); v3add(x, o[6], t); m3mul(Rs, R[6], m->site_rot7);
-        for (int j = 0; j < NJ; j++) { real z[3] = {R[j][2], R[j][5], R[j][8]}, r[3], cx[3]; v3sub(r, x, o[j]); v3cross(cx, z, r); for (int a = 0; a < 3; a++) { J[a][j] = cx[a]; J[3 + a][j] = z[a]; } }
+        for (int j = 0; j < NJ; j++) { real z[3] = {R[j][2], R[j][5], R[j][8]}, r[3], cx[3]; v3sub(r, x, o[j]); v3cross(cx, z, r); for (int a = 0; a < 3; a++) { J[a][j] = m->active[j] ? cx[a] : 0; J[3 + a][j] = m->active[j] ? z[a] : 0; } }
         for (int a = 0; a < 3; a++) e[a] = target[a] - x[a];
         e[3] = e[4] = e[5] = 0;
         for (int cc = 0; cc < 3; cc++) { real rc[3] = {Rs[cc], Rs[3 + cc], Rs[6 + cc]}, rd[3] = {m->goal_rot[cc], m->goal_rot[3 + cc], m->goal_rot[6 + cc]}, xx[3]; v3cross(xx, rc, rd); for (int a = 0; a < 3; a++) e[3 + a] += (real)0.5 * xx[a]; }
@@ -1054,10 +1123,10 @@ static void step_env(Sim* S, int i, const double* act_d, double* obs, double* re
     E->fzbar = (real)FORCE_EMA_ALPHA * fz + (1 - (real)FORCE_EMA_ALPHA) * E->fzbar;   /* :546 */
     int cause = done ? 1 : 0;
     double jmargin = 1e9;
-    for (int j = 0; j < NJ; j++) { double a = (double)E->q[j] - (Q_MIN[j] + QLIM_TOL), b = (Q_MAX[j] - QLIM_TOL) - (double)E->q[j]; if (a < jmargin) jmargin = a; if (b < jmargin) jmargin = b; }
+    for (int j = 0; j < NJ; j++) { double a = (double)E->q[j] - (m->qmin[j] + QLIM_TOL), b = (m->qmax[j] - QLIM_TOL) - (double)E->q[j]; if (a < jmargin) jmargin = a; if (b < jmargin) jmargin = b; }
     if (c->early_termination) {                            /* :549-550 -> :635-670 */
         int term = 0;
-        for (int j = 0; j < NJ; j++) if (E->q[j] < (real)(Q_MIN[j] + QLIM_TOL) || E->q[j] > (real)(Q_MAX[j] - QLIM_TOL)) { term = 1; cause |= 2; }   /* :651 */
+        for (int j = 0; j < NJ; j++) if (E->q[j] < (real)(m->qmin[j] + QLIM_TOL) || E->q[j] > (real)(m->qmax[j] - QLIM_TOL)) { term = 1; cause |= 2; }   /* :651 */
         if (pos_err_norm > (real)POS_ERR_THRESH) { term = 1; cause |= 4; }           /* :656 */
         if (contact && ori_err > (real)ORI_ERR_THRESH) { term = 1; cause |= 8; }     /* :661 */
         if (E->has_touched && !contact) { term = 1; cause |= 16; }                   /* :666 */
@@ -1089,7 +1158,7 @@ void uso_default_config(uso_config* c) {
     memset(c, 0, sizeof *c);
     c->mode = USO_MODE_TRACKING; c->torso = USO_TORSO_TOP; c->horizon = 1000; c->early_termination = 1;
     c->deterministic_trajectory = 0; c->torso_solref_randomization = 1; c->initial_probe_pos_randomization = 1;
-    c->friction_randomization = 0; c->torso_drop = 1; c->pgs_iters = 6; c->ik_iters = 5; c->env_offset = 0;
+    c->friction_randomization = 0; c->torso_drop = 1; c->pgs_iters = 6; c->ik_iters = 5; c->env_offset = 0; c->robot = 0;
     c->seed = 3; c->control_dt = 0.002; c->kp_fixed = 300; c->damping_ratio = 1; c->kp_min = 0; c->kp_max = 500;
     c->out_max_pos = 0.05; c->out_max_ori = 0.5; c->stiffness = 1324.17; c->damping = 17.59;
     c->elem_friction = 0.01; c->probe_friction = 1e-4;

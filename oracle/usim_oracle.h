@@ -34,6 +34,7 @@ extern "C" {
 enum { USO_MODE_TRACKING = 0, USO_MODE_FIXED = 1, USO_MODE_VARIABLE_Z = 2, USO_MODE_WRENCH = 3 };
 /* torso model: 0 = rigid/absent (BASELINE config #2), 1 = 99 top-face elements dynamic (config #3) */
 enum { USO_TORSO_NONE = 0, USO_TORSO_TOP = 1 };
+enum { USO_ROBOT_PANDA = 0, USO_ROBOT_UR5E = 1 };
 
 typedef struct uso_config {
     int32_t mode;                 /* USO_MODE_* */
@@ -49,6 +50,7 @@ typedef struct uso_config {
     int32_t ik_iters;             /* fixed reset-IK iteration count */
     int32_t env_offset;           /* global index of env 0 (multi-GPU shards) */
     int32_t torso_shape;          /* 0 box (soft_box.xml, use_box_torso True), 1 cylinder (soft_human_torso.xml) */
+    int32_t robot;                /* USO_ROBOT_*: the two robots ultrasound.py:137 admits */
     uint64_t seed;                /* rl_config.yaml:1 */
     double control_dt;            /* 1/control_freq = 0.002 (rl_config.yaml:26) */
     double kp_fixed;              /* rl_config.yaml:38 / main.py:31 */

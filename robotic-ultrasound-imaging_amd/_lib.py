@@ -18,6 +18,7 @@ LOG_WIDTH = 53
 
 MODE = {"tracking": 0, "fixed": 1, "variable_z": 2, "wrench": 3}
 TORSO = {"none": 0, "rigid": 0, "top": 1, "soft": 1}
+ROBOT = {"Panda": 0, "UR5e": 1}             # ultrasound.py:137
 
 
 class UsimConfig(C.Structure):

@@ -52,8 +52,9 @@ def make_config(seed=3, env_offset=0, **kw):
         if len(robots) != 1:
             raise ValueError("Ultrasound is a single-arm environment")
         robots = robots[0]
-    if robots != "Panda":
-        raise ValueError("only the Panda robot of rl_config.yaml:20 is implemented (UR5e: SURVEY.md 8f)")
+    if robots not in _lib.ROBOT:
+        raise ValueError("Robot must be UR5e or Panda!")                   # ultrasound.py:137-138
+    c.robot = _lib.ROBOT[robots]
     if kw.pop("gripper_types", "UltrasoundProbeGripper") != "UltrasoundProbeGripper":
         raise ValueError("Tried to specify gripper other than UltrasoundProbeGripper in Ultrasound environment!")
     use_box = bool(kw.pop("use_box_torso", True))

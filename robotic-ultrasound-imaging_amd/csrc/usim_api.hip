@@ -14,6 +14,7 @@
 
 #include "../../include/usim.h"
 #include "usim_device.h"
+#include "usim_robot.h"
 #include "usim_kernels.hip"      // single translation unit: kernels + host launcher (no relocatable device code)
 
 
@@ -63,26 +64,9 @@ const double kBase[3] = {-0.56, 0.0, 0.913};                                    
 // -0.05 (soft_human_torso.xml:14); trajectory height / waypoint grid width per shape (ultrasound.py:184,186)
 const double kTorsoZ[2] = {0.8 + 0.005 + 0.0522, 0.8 + 0.005 + 0.05};
 const double kTopOff[2] = {0.039, 0.041}, kYRange[2] = {0.09, 0.05};
-const double kHandPos[3] = {0, 0, 0.107};
 const double kProbePos[3] = {-0.004, -0.063, 0.128};                                 // ultrasound_probe_gripper.xml:6
 const double kProbeCom[3] = {0.0013, 0.021, -0.043};                                 // stand-in (mesh missing from the snapshot)
 const double kProbeI[3] = {1.6e-3, 1.6e-3, 2.0e-4};
-
-struct Inertial { double m; double c[3]; double I[3][3]; };
-
-void add_body(Inertial& a, double mb, const double cb[3], const double Ib[3][3]) {
-    double m = a.m + mb, c[3];
-    for (int i = 0; i < 3; ++i) c[i] = (a.m * a.c[i] + mb * cb[i]) / m;
-    double I[3][3];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) I[i][j] = a.I[i][j] + Ib[i][j];
-    auto shift = [&](double mm, const double* cc) {
-        double d[3] = {cc[0] - c[0], cc[1] - c[1], cc[2] - c[2]}, dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) I[i][j] += mm * ((i == j ? dd : 0.0) - d[i] * d[j]);
-    };
-    shift(a.m, a.c); shift(mb, cb);
-    a.m = m;
-    for (int i = 0; i < 3; ++i) { a.c[i] = c[i]; for (int j = 0; j < 3; ++j) a.I[i][j] = I[i][j]; }
-}
 
 void pack_sym(const double I[3][3], float* o) { o[0] = (float)I[0][0]; o[1] = (float)I[0][1]; o[2] = (float)I[0][2]; o[3] = (float)I[1][1]; o[4] = (float)I[1][2]; o[5] = (float)I[2][2]; }
 
@@ -120,37 +104,28 @@ static int upload_tables(usim_handle* h, const std::vector<float>& tb) {
     return USIM_OK;
 }
 
-// Arm table of the 16-lane step kernel (usim_device.h ArmTable): the Panda chain of usim_devmath.h as per-lane records.  Link i: fixed
-// translation, fixed rotation about x by ROTX[i] * 90 deg, joint about the local z axis; link 7 carries the composite of link7 + hand +
-// probe (DevModel m7 / c7 / I7); lane 7 is the end-effector site (site7, link-7 frame rotated by -45 deg about z).
-static void build_arm_table(const DevModel& M, float* tb) {
-    static const double lpos[NJ][3] = {{0, 0, 0.333}, {0, 0, 0}, {0, -0.316, 0}, {0.0825, 0, 0}, {-0.0825, 0.384, 0}, {0, 0, 0}, {0.088, 0, 0}};
-    static const int rotx[NJ] = {0, -1, 1, 1, -1, 1, 1};
-    static const double lcom[NJ][3] = {{0, 0, -0.07}, {0, -0.1, 0}, {0.04, 0, -0.05}, {-0.04, 0.05, 0}, {0, 0, -0.15}, {0.06, 0, 0}, {0, 0, 0}};
-    static const double lmass[NJ] = {3, 3, 2, 2, 2, 1.5, 0}, liso[NJ] = {0.3, 0.3, 0.2, 0.2, 0.2, 0.1, 0};
-    static const double qmin[NJ] = {-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973};
-    static const double qmax[NJ] = {2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973};
-    static const double taumax[NJ] = {80, 80, 80, 80, 12, 12, 12};
-    static const double initq[NJ] = {0.0, 0.19634954084936207, 0.0, -2.6179938779914944, 0.0, 2.941592653589793, 0.7853981633974483};
+// Arm table of the 16-lane kernels (usim_device.h ArmTable) from the z-aligned chain: lanes 0 .. 6 the links (padding links of a shorter
+// chain: identity transform, no mass, no joint), lane 7 the end-effector site as a fixed child of the last link.
+static void build_arm_table(const usim_host::Chain& c, float* tb) {
     for (int l = 0; l < A16_LANES; ++l) {
         float* r = tb + l * AT_STRIDE;
         for (int k = 0; k < AT_STRIDE; ++k) r[k] = 0.f;
         r[AT_RFIX + 0] = 1.f; r[AT_RFIX + 4] = 1.f; r[AT_RFIX + 8] = 1.f;      // identity columns
         r[AT_QMIN] = -1.0e30f; r[AT_QMAX] = 1.0e30f; r[AT_TAUMAX] = 1.0f;
+        const usim_host::M3* rot = nullptr; usim_host::V3 pos;
         if (l < NJ) {
-            // rotation about x by rotx * 90 deg: columns x = (1,0,0), y = (0,c,s), z = (0,-s,c)
-            const double c = rotx[l] == 0 ? 1.0 : 0.0, sn = (double)rotx[l];
-            r[AT_RFIX + 3] = 0.f; r[AT_RFIX + 4] = (float)c; r[AT_RFIX + 5] = (float)sn;
-            r[AT_RFIX + 6] = 0.f; r[AT_RFIX + 7] = (float)-sn; r[AT_RFIX + 8] = (float)c;
-            for (int k = 0; k < 3; ++k) { r[AT_LPOS + k] = (float)lpos[l][k]; r[AT_LCOM + k] = (l < NJ - 1) ? (float)lcom[l][k] : M.c7[k]; }
-            r[AT_MASS] = (l < NJ - 1) ? (float)lmass[l] : M.m7;
-            if (l < NJ - 1) { r[AT_INERTIA + 0] = r[AT_INERTIA + 3] = r[AT_INERTIA + 5] = (float)liso[l]; }
-            else for (int k = 0; k < 6; ++k) r[AT_INERTIA + k] = M.I7[k];
-            r[AT_QMIN] = (float)qmin[l]; r[AT_QMAX] = (float)qmax[l]; r[AT_TAUMAX] = (float)taumax[l]; r[AT_INITQ] = (float)initq[l];
-        } else if (l == 7) {
-            const double h = 0.70710678118654752;                                 // Rz(-45 deg): columns (h,-h,0), (h,h,0), (0,0,1)
-            r[AT_RFIX + 0] = (float)h; r[AT_RFIX + 1] = (float)-h; r[AT_RFIX + 3] = (float)h; r[AT_RFIX + 4] = (float)h;
-            for (int k = 0; k < 3; ++k) r[AT_LPOS + k] = M.site7[k];
+            const usim_host::Link& k = c.link[l];
+            rot = &k.rfix; pos = k.lpos;
+            r[AT_LCOM] = (float)k.lcom.x; r[AT_LCOM + 1] = (float)k.lcom.y; r[AT_LCOM + 2] = (float)k.lcom.z;
+            r[AT_MASS] = (float)k.mass;
+            r[AT_INERTIA + 0] = (float)k.inertia.m[0][0]; r[AT_INERTIA + 1] = (float)k.inertia.m[0][1]; r[AT_INERTIA + 2] = (float)k.inertia.m[0][2];
+            r[AT_INERTIA + 3] = (float)k.inertia.m[1][1]; r[AT_INERTIA + 4] = (float)k.inertia.m[1][2]; r[AT_INERTIA + 5] = (float)k.inertia.m[2][2];
+            r[AT_QMIN] = (float)k.qmin; r[AT_QMAX] = (float)k.qmax; r[AT_TAUMAX] = (float)k.taumax; r[AT_INITQ] = (float)k.initq;
+            r[AT_JOINT] = k.joint ? 1.f : 0.f;
+        } else if (l == 7) { rot = &c.site_rot; pos = c.site; }
+        if (rot) {
+            for (int col = 0; col < 3; ++col) for (int row = 0; row < 3; ++row) r[AT_RFIX + 3 * col + row] = (float)rot->m[row][col];   // stored by columns
+            r[AT_LPOS] = (float)pos.x; r[AT_LPOS + 1] = (float)pos.y; r[AT_LPOS + 2] = (float)pos.z;
         }
     }
 }
@@ -158,24 +133,18 @@ static void build_arm_table(const DevModel& M, float* tb) {
 static int build_model(usim_handle* h) {
     DevModel& M = h->M;
     std::memset(&M, 0, sizeof M);
-    // site / hand / probe in the link-7 frame; hand frame is link 7 rotated by -45 deg about z
-    const double ch = std::cos(-kPi / 4), sh = std::sin(-kPi / 4);
-    const double Rh[3][3] = {{ch, -sh, 0}, {sh, ch, 0}, {0, 0, 1}};
-    double site7[3], pcom7[3], Ip7[3][3];
-    for (int i = 0; i < 3; ++i) {
-        site7[i] = kHandPos[i]; pcom7[i] = 0;
-        for (int k = 0; k < 3; ++k) site7[i] += Rh[i][k] * kProbePos[k];
+    // robot chain (z-aligned, end effector folded into the last link): arm table + the end-effector constants of the kernels
+    const usim_host::RobotDesc desc = (h->cfg.robot == USIM_ROBOT_UR5E) ? usim_host::ur5e_desc() : usim_host::panda_desc();
+    const usim_host::Chain chain = usim_host::z_aligned_chain(desc, {kProbePos[0], kProbePos[1], kProbePos[2]}, {kProbeCom[0], kProbeCom[1], kProbeCom[2]},
+                                                              {kProbeI[0], kProbeI[1], kProbeI[2]}, 1.0, 0.5, 0.05);
+    {
+        const usim_host::Link& last = chain.link[chain.nj - 1];
+        M.m7 = (float)last.mass;
+        const double c7[3] = {last.lcom.x, last.lcom.y, last.lcom.z}, s7[3] = {chain.site.x, chain.site.y, chain.site.z}, h7[3] = {chain.hand.x, chain.hand.y, chain.hand.z},
+                     p7[3] = {chain.pcom.x, chain.pcom.y, chain.pcom.z}, ib[3] = {chain.ik_bias.x, chain.ik_bias.y, chain.ik_bias.z};
+        for (int i = 0; i < 3; ++i) { M.c7[i] = (float)c7[i]; M.site7[i] = (float)s7[i]; M.hand7[i] = (float)h7[i]; M.pcom7[i] = (float)p7[i]; M.ikb[i] = (float)ib[i]; }
+        pack_sym(last.inertia.m, M.I7); pack_sym(chain.pI.m, M.pI7);
     }
-    for (int i = 0; i < 3; ++i) { pcom7[i] = site7[i]; for (int k = 0; k < 3; ++k) pcom7[i] += Rh[i][k] * kProbeCom[k]; }
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { Ip7[i][j] = 0; for (int k = 0; k < 3; ++k) Ip7[i][j] += Rh[i][k] * kProbeI[k] * Rh[j][k]; }
-    // link-7 composite: link7 (0.5 kg, com z 0.08, I 0.05) + hand (0.5 kg at the hand origin, I 0.05) + probe (1 kg)
-    Inertial c7{0.5, {0, 0, 0.08}, {{0.05, 0, 0}, {0, 0.05, 0}, {0, 0, 0.05}}};
-    const double Ih[3][3] = {{0.05, 0, 0}, {0, 0.05, 0}, {0, 0, 0.05}};
-    add_body(c7, 0.5, kHandPos, Ih);
-    add_body(c7, 1.0, pcom7, Ip7);
-    M.m7 = (float)c7.m;
-    for (int i = 0; i < 3; ++i) { M.c7[i] = (float)c7.c[i]; M.site7[i] = (float)site7[i]; M.hand7[i] = (float)kHandPos[i]; M.pcom7[i] = (float)pcom7[i]; }
-    pack_sym(c7.I, M.I7); pack_sym(Ip7, M.pI7);
     const int shape = h->cfg.torso_shape ? 1 : 0;
     const double kTorso[3] = {0.0, 0.0, kTorsoZ[shape]};
     for (int i = 0; i < 3; ++i) { M.torso[i] = (float)(kTorso[i] - kBase[i]); M.base[i] = (float)kBase[i]; }
@@ -195,7 +164,9 @@ static int build_model(usim_handle* h) {
 
     // one table block per handle: [lattice tables (soft torso) | arm table], laid out as the kernels read it
     std::vector<float> tb(TB_TOTAL, 0.f);
-    build_arm_table(M, &tb[TB_ARM]);
+    build_arm_table(chain, &tb[TB_ARM]);
+    // contact regulariser scale: translational inverse weight of the probe at init_qpos + element (MuJoCo body_invweight0 analogue)
+    M.invw = (float)(usim_host::site_inverse_weight(chain) + (1.0 / 0.01 + 2.0 / (270 * 0.01)) / 3.0);
     // ---- torso lattice: top face (iy = 3) of the 9 x 4 x 11 shell, shell ids in creation order ----
     h->n_el = (h->cfg.torso == USIM_TORSO_TOP) ? N_TOP : 0;
     if (h->n_el == 0) return upload_tables(h, tb);
@@ -288,7 +259,7 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
     if (!cfg || !out || n_envs <= 0) return USIM_ERR_INVALID;
     if (cfg->mode < 0 || cfg->mode > 3 || cfg->torso < 0 || cfg->torso > 1 || cfg->horizon <= 0 || cfg->control_dt <= 0 ||
         cfg->probe_halflen < 1e-4 || cfg->probe_radius <= 0 || cfg->pgs_iters < 0 || cfg->ik_iters < 0 || cfg->torso_shape < 0 ||
-        cfg->torso_shape > 1 || cfg->waves_per_simd < 0 || cfg->waves_per_simd > 2 || cfg->robot != 0) return USIM_ERR_INVALID;
+        cfg->torso_shape > 1 || cfg->waves_per_simd < 0 || cfg->waves_per_simd > 2 || cfg->robot < 0 || cfg->robot > 1) return USIM_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return USIM_ERR_NO_DEVICE;
     usim_handle* h = new (std::nothrow) usim_handle();
@@ -329,6 +300,10 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
     // Rigid torso: 16 lanes per environment (arm mathematics distributed over the group) or, with lanes_per_env = 1, one lane each.
     h->lpe = h->n_el ? (cfg->lanes_per_env == 0 ? 16 : cfg->lanes_per_env) : (cfg->lanes_per_env == 0 ? 16 : cfg->lanes_per_env);
     if (h->n_el ? (h->lpe != 8 && h->lpe != 16) : (h->lpe != 1 && h->lpe != 16)) return USIM_ERR_INVALID;
+    if (cfg->robot != USIM_ROBOT_PANDA && h->lpe != 16) {
+        h->hip_err = "the UR5e runs on the table-driven 16-lane kernels only (lanes_per_env 0 or 16)";
+        return USIM_ERR_UNSUPPORTED;
+    }
     h->occ = cfg->waves_per_simd ? cfg->waves_per_simd : (n_envs <= 4096 ? 1 : 2);
     h->lds16_bytes = h->n_el ? (size_t)GroupGeom<16>::LDS_WORDS * sizeof(float) : (size_t)16 * X16_RIGID_STRIDE * sizeof(float);
     if (h->n_el) {
@@ -341,17 +316,6 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
         h->lds_bytes = (size_t)GroupGeom<8>::LDS_WORDS * sizeof(float);
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step_kernel<1, 8, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step_kernel<1, 8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-    }
-    // contact regulariser scale: translational inverse weight of the probe at init_qpos (device, one lane) + element
-    {
-        float* d_w = nullptr; float w = 0.f;
-        HIPCHK(h, hipMalloc(&d_w, sizeof(float)));
-        hipLaunchKernelGGL(usim_invweight_kernel, dim3(1), dim3(WG), 0, 0, h->M, d_w);
-        HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipMemcpy(&w, d_w, sizeof(float), hipMemcpyDeviceToHost));
-        HIPCHK(h, hipFree(d_w));
-        const double invw_elem = (1.0 / 0.01 + 2.0 / (270 * 0.01)) / 3.0;
-        h->M.invw = (float)((double)w + invw_elem);
     }
     return USIM_OK;
 }

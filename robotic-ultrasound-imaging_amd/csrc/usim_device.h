@@ -43,7 +43,7 @@ static_assert(F_TOTAL_TOP == F_LAT + LAT_ENV_WORDS && LAT_SD + N_TOP <= LAT_ENV_
 constexpr int A16_LANES = 16;
 enum ArmTable : int { AT_RFIX = 0 /* 9: columns x, y, z of the fixed rotation */, AT_LPOS = 9 /* 3 */, AT_LCOM = 12 /* 3 */, AT_MASS = 15,
                       AT_INERTIA = 16 /* 6: xx xy xz yy yz zz about the COM, link frame */, AT_QMIN = 22, AT_QMAX = 23, AT_TAUMAX = 24,
-                      AT_INITQ = 25, AT_STRIDE = 28 };
+                      AT_INITQ = 25, AT_JOINT = 26 /* 1: the lane owns a joint, 0: padding / site / idle lane */, AT_STRIDE = 28 };
 
 // model constants (host-built in fp64, narrowed once; passed to the kernels by value -> kernarg/SGPRs)
 struct DevModel {
@@ -55,6 +55,7 @@ struct DevModel {
     float gquat[4];                 // goal_quat (x,y,z,w) exactly as written at ultrasound.py:174
     float ghat[4], geps;            // unit goal quaternion (w,x,y,z) and 1 - |goal_quat|
     float base[3];                  // robot base in world coordinates
+    float ikb[3];                   // systematic offset of the reference's initial-pose IK
     float invw, wfix, wten;         // contact regulariser scale, lattice soft-equality weights
     const float* tables;            // this handle's lattice table block in HBM (TB_WORDS words, 16-byte aligned; soft torso only)
 };

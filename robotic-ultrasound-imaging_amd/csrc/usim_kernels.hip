@@ -1177,29 +1177,6 @@ __global__ void usim_random_actions_kernel(const DevCfg C, int n, long long rste
     }
 }
 
-// translational inverse weight of the probe at init_qpos: tr(Jv M^-1 Jv^T) / 3 (MuJoCo body_invweight0 analogue)
-__global__ void usim_invweight_kernel(const DevModel M, float* out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float q[NJ], qd[NJ];
-#pragma unroll
-    for (int i = 0; i < NJ; ++i) { q[i] = INITQ[i]; qd[i] = 0.f; }
-    Kin K; fk<false>(M, q, K);
-    Dyn D; dynamics(M, K, qd, D);
-    float idm[NJ];
-    chol_packed<NJ>(D.M, idm);
-    float tr = 0.f;
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-        float jt[NJ], y[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) { f3 jv = cross(K.z[j], K.x - K.o[j]); jt[j] = (ax == 0) ? jv.x : (ax == 1 ? jv.y : jv.z); y[j] = jt[j]; }
-        chol_solve<NJ>(D.M, idm, y);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) tr = fmaf(jt[j], y[j], tr);
-    }
-    out[0] = tr * (1.0f / 3.0f);
-}
-
 }  // namespace usim
 
 #include "usim_step16.h"

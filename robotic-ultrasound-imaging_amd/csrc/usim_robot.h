@@ -1,0 +1,196 @@
+// usim_robot.h -- host-side robot models (double precision) for the arm table of the 16-lane kernels.
+//
+// The two robots the reference admits (ultrasound.py:137) in the form of their robosuite MJCF assets (un-vendored; SURVEY.md Appendix B.4 --
+// the build's own model definition, recalled from robosuite v1.2 robots/{panda,ur5e}/robot.xml): per body the pose in the parent body, the
+// joint axis, the inertial frame.  z_aligned_chain() turns a description into the chain the kernels integrate: every link frame is
+// post-multiplied by a constant rotation that takes z to the joint axis, so that all joints turn about their local z; the end effector
+// (right_hand body + ultrasound probe, ultrasound_probe_gripper.xml:6-17) is folded into the last link.  A chain shorter than seven joints is
+// padded with locked joints (identity transform, no mass; the kernels give them a unit diagonal in M and no Jacobian column).
+#pragma once
+#include <array>
+#include <cmath>
+
+namespace usim_host {
+
+struct V3 { double x = 0, y = 0, z = 0; };
+struct M3 {                       // row-major 3 x 3
+    double m[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    static M3 zero() { M3 r; for (auto& row : r.m) for (double& v : row) v = 0; return r; }
+    static M3 diag(double a, double b, double c) { M3 r = zero(); r.m[0][0] = a; r.m[1][1] = b; r.m[2][2] = c; return r; }
+    static M3 quat(double w, double x, double y, double z) {
+        const double n = std::sqrt(w * w + x * x + y * y + z * z); w /= n; x /= n; y /= n; z /= n;
+        M3 r;
+        r.m[0][0] = 1 - 2 * (y * y + z * z); r.m[0][1] = 2 * (x * y - w * z); r.m[0][2] = 2 * (x * z + w * y);
+        r.m[1][0] = 2 * (x * y + w * z); r.m[1][1] = 1 - 2 * (x * x + z * z); r.m[1][2] = 2 * (y * z - w * x);
+        r.m[2][0] = 2 * (x * z - w * y); r.m[2][1] = 2 * (y * z + w * x); r.m[2][2] = 1 - 2 * (x * x + y * y);
+        return r;
+    }
+    M3 T() const { M3 r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = m[j][i]; return r; }
+};
+inline M3 operator*(const M3& a, const M3& b) {
+    M3 r = M3::zero();
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) r.m[i][j] += a.m[i][k] * b.m[k][j];
+    return r;
+}
+inline V3 operator*(const M3& a, const V3& v) {
+    return {a.m[0][0] * v.x + a.m[0][1] * v.y + a.m[0][2] * v.z, a.m[1][0] * v.x + a.m[1][1] * v.y + a.m[1][2] * v.z, a.m[2][0] * v.x + a.m[2][1] * v.y + a.m[2][2] * v.z};
+}
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+// m (|c|^2 E - c c^T)
+inline M3 point_inertia(double mass, V3 c) {
+    const double cc = dot(c, c);
+    M3 r;
+    const double v[3] = {c.x, c.y, c.z};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = mass * ((i == j ? cc : 0.0) - v[i] * v[j]);
+    return r;
+}
+inline M3 add(const M3& a, const M3& b) { M3 r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = a.m[i][j] + b.m[i][j]; return r; }
+
+struct BodyDesc {
+    V3 pos; double quat[4]; char axis;                    // pose in the parent body, joint axis in the body frame ('y' or 'z')
+    double mass; V3 com; double iquat[4]; V3 diag;        // inertial frame
+    double qmin, qmax, taumax, initq;
+};
+struct RobotDesc {
+    int nj;
+    BodyDesc body[7];
+    V3 hand_pos; double hand_quat[4];                     // right_hand body on the last link
+    V3 ik_bias;                                           // systematic offset of the reference's DH-model IK (measured for the Panda only)
+};
+
+inline RobotDesc panda_desc() {
+    const double h = 0.7071067811865476;
+    RobotDesc r{};
+    r.nj = 7;
+    const double pos[7][3] = {{0, 0, 0.333}, {0, 0, 0}, {0, -0.316, 0}, {0.0825, 0, 0}, {-0.0825, 0.384, 0}, {0, 0, 0}, {0.088, 0, 0}};
+    const double qx[7] = {0, -h, h, h, -h, h, h};         // body quats (w, x, 0, 0): rotations about x by 0 / -90 / +90 degrees
+    const double mass[7] = {3, 3, 2, 2, 2, 1.5, 0.5}, iso[7] = {0.3, 0.3, 0.2, 0.2, 0.2, 0.1, 0.05};
+    const double com[7][3] = {{0, 0, -0.07}, {0, -0.1, 0}, {0.04, 0, -0.05}, {-0.04, 0.05, 0}, {0, 0, -0.15}, {0.06, 0, 0}, {0, 0, 0.08}};
+    const double qmin[7] = {-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973}, qmax[7] = {2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973};
+    const double tmax[7] = {80, 80, 80, 80, 12, 12, 12};
+    const double pi = 3.14159265358979323846;
+    const double initq[7] = {0.0, pi / 16.0, 0.0, -pi / 2.0 - pi / 3.0, 0.0, pi - 0.2, pi / 4.0};
+    for (int i = 0; i < 7; ++i)
+        r.body[i] = BodyDesc{{pos[i][0], pos[i][1], pos[i][2]}, {qx[i] == 0 ? 1.0 : h, qx[i], 0, 0}, 'z', mass[i], {com[i][0], com[i][1], com[i][2]}, {1, 0, 0, 0},
+                             {iso[i], iso[i], iso[i]}, qmin[i], qmax[i], tmax[i], initq[i]};
+    r.hand_pos = {0, 0, 0.107};
+    r.hand_quat[0] = std::cos(-pi / 8); r.hand_quat[1] = 0; r.hand_quat[2] = 0; r.hand_quat[3] = std::sin(-pi / 8);      // yaw -45 deg
+    r.ik_bias = {0.0028, 0.0008, 0.0066};
+    return r;
+}
+
+inline RobotDesc ur5e_desc() {
+    const double h = 0.7071067811865476;
+    RobotDesc r{};
+    r.nj = 6;
+    r.body[0] = BodyDesc{{0, 0, 0.163}, {1, 0, 0, 0}, 'z', 3.7, {0, 0, 0}, {1, 0, 0, 0}, {0.0102675, 0.0102675, 0.00666}, -6.28319, 6.28319, 150, -0.470};
+    r.body[1] = BodyDesc{{0, 0.138, 0}, {h, 0, h, 0}, 'y', 8.393, {0, 0, 0.2125}, {1, 0, 0, 0}, {0.133886, 0.133886, 0.0151074}, -6.28319, 6.28319, 150, -1.735};
+    r.body[2] = BodyDesc{{0, -0.131, 0.425}, {1, 0, 0, 0}, 'y', 2.275, {0, 0, 0.196}, {1, 0, 0, 0}, {0.0311796, 0.0311796, 0.004095}, -3.14159, 3.14159, 150, 2.480};
+    r.body[3] = BodyDesc{{0, 0, 0.392}, {h, 0, h, 0}, 'y', 1.219, {0, 0.127, 0}, {1, 0, 0, 0}, {0.0025599, 0.0025599, 0.0021942}, -6.28319, 6.28319, 28, -2.275};
+    r.body[4] = BodyDesc{{0, 0.127, 0}, {1, 0, 0, 0}, 'z', 1.219, {0, 0, 0.1}, {1, 0, 0, 0}, {0.0025599, 0.0025599, 0.0021942}, -6.28319, 6.28319, 28, -1.590};
+    r.body[5] = BodyDesc{{0, 0, 0.1}, {1, 0, 0, 0}, 'y', 0.1889, {0, 0.0771683, 0}, {h, 0, 0, h}, {0.000132134, 9.90863e-05, 9.90863e-05}, -6.28319, 6.28319, 28, -1.991};
+    r.hand_pos = {0, 0.098, 0};
+    r.hand_quat[0] = h; r.hand_quat[1] = -h; r.hand_quat[2] = 0; r.hand_quat[3] = 0;
+    r.ik_bias = {0, 0, 0};
+    return r;
+}
+
+// the chain as the kernels integrate it
+struct Link { M3 rfix; V3 lpos, lcom; double mass = 0; M3 inertia = M3::zero(); double qmin = -1e30, qmax = 1e30, taumax = 1, initq = 0; bool joint = false; };
+struct Chain {
+    int nj = 0;
+    std::array<Link, 7> link;
+    V3 hand, site, pcom;        // right_hand origin, eef site (grip_site == ft_frame), probe COM: last link's frame
+    M3 site_rot;                // site frame in the last link's frame
+    M3 pI = M3::zero();         // probe inertia about its COM, last link's frame
+    V3 ik_bias;
+};
+
+inline Chain z_aligned_chain(const RobotDesc& d, V3 probe_pos, V3 probe_com, V3 probe_diag, double probe_mass, double hand_mass, double hand_iso) {
+    const M3 rcy = M3::quat(std::cos(-3.14159265358979323846 / 4), std::sin(-3.14159265358979323846 / 4), 0, 0);     // Rx(-90 deg): z -> y
+    Chain c;
+    c.nj = d.nj;
+    M3 rcp;                                                           // z-alignment of the parent link
+    for (int i = 0; i < d.nj; ++i) {
+        const BodyDesc& b = d.body[i];
+        const M3 rc = (b.axis == 'y') ? rcy : M3();
+        Link& l = c.link[i];
+        l.rfix = rcp.T() * M3::quat(b.quat[0], b.quat[1], b.quat[2], b.quat[3]) * rc;
+        l.lpos = rcp.T() * b.pos;
+        l.lcom = rc.T() * b.com;
+        const M3 ri = M3::quat(b.iquat[0], b.iquat[1], b.iquat[2], b.iquat[3]);
+        l.inertia = rc.T() * (ri * M3::diag(b.diag.x, b.diag.y, b.diag.z) * ri.T()) * rc;
+        l.mass = b.mass; l.qmin = b.qmin; l.qmax = b.qmax; l.taumax = b.taumax; l.initq = b.initq; l.joint = true;
+        rcp = rc;
+    }
+    // end effector in the last link's z-aligned frame
+    const M3 rh = rcp.T() * M3::quat(d.hand_quat[0], d.hand_quat[1], d.hand_quat[2], d.hand_quat[3]);
+    c.hand = rcp.T() * d.hand_pos;
+    c.site_rot = rh;
+    c.site = c.hand + rh * probe_pos;
+    c.pcom = c.site + rh * probe_com;
+    c.pI = rh * M3::diag(probe_diag.x, probe_diag.y, probe_diag.z) * rh.T();
+    c.ik_bias = d.ik_bias;
+    // composite of the last link: link + hand (point-like frame at the hand origin with isotropic inertia) + probe
+    Link& last = c.link[d.nj - 1];
+    const double mt = last.mass + hand_mass + probe_mass;
+    const V3 ct = (last.lcom * last.mass + c.hand * hand_mass + c.pcom * probe_mass) * (1.0 / mt);
+    M3 it = add(add(last.inertia, point_inertia(last.mass, last.lcom - ct)), add(M3::diag(hand_iso, hand_iso, hand_iso), point_inertia(hand_mass, c.hand - ct)));
+    it = add(it, add(c.pI, point_inertia(probe_mass, c.pcom - ct)));
+    last.mass = mt; last.lcom = ct; last.inertia = it;
+    return c;
+}
+
+// Translational inverse weight of the eef site at init_qpos, tr(Jv M^-1 Jv^T) / 3 (the MuJoCo body_invweight0 analogue that scales the
+// contact regulariser): forward kinematics, mass matrix by the composite-rigid-body recursion about the base origin, Gaussian elimination.
+inline double site_inverse_weight(const Chain& c) {
+    M3 R[7]; V3 o[7], z[7], com[7];
+    M3 Rp; V3 op;
+    for (int i = 0; i < 7; ++i) {
+        const Link& l = c.link[i];
+        const double cs = std::cos(l.initq), sn = std::sin(l.initq);
+        M3 rz; rz.m[0][0] = cs; rz.m[0][1] = -sn; rz.m[1][0] = sn; rz.m[1][1] = cs;
+        o[i] = op + Rp * l.lpos;
+        R[i] = Rp * l.rfix * rz;
+        z[i] = {R[i].m[0][2], R[i].m[1][2], R[i].m[2][2]};
+        com[i] = o[i] + R[i] * l.lcom;
+        Rp = R[i]; op = o[i];
+    }
+    const V3 x = o[6] + R[6] * c.site;
+    double Mm[7][7] = {};
+    double cm = 0; V3 ch; M3 Io = M3::zero();
+    for (int i = 6; i >= 0; --i) {
+        const Link& l = c.link[i];
+        cm += l.mass; ch = ch + com[i] * l.mass;
+        Io = add(Io, add(R[i] * l.inertia * R[i].T(), point_inertia(l.mass, com[i])));
+        const V3 vo = cross(o[i], z[i]);
+        const V3 n = Io * z[i] + cross(ch, vo), f = vo * cm + cross(z[i], ch);
+        for (int j = 0; j <= i; ++j) Mm[i][j] = Mm[j][i] = dot(z[j], n) + dot(cross(o[j], z[j]), f);
+    }
+    for (int i = 0; i < 7; ++i) if (!c.link[i].joint) Mm[i][i] = 1.0;
+    double tr = 0;
+    for (int ax = 0; ax < 3; ++ax) {
+        double a[7][8];
+        double jt[7];
+        for (int i = 0; i < 7; ++i) {
+            const V3 jv = cross(z[i], x - o[i]);
+            jt[i] = c.link[i].joint ? (ax == 0 ? jv.x : (ax == 1 ? jv.y : jv.z)) : 0.0;
+            for (int j = 0; j < 7; ++j) a[i][j] = Mm[i][j];
+            a[i][7] = jt[i];
+        }
+        for (int k = 0; k < 7; ++k)                                        // Gauss-Jordan without pivoting (symmetric positive definite)
+            for (int i = 0; i < 7; ++i) {
+                if (i == k) continue;
+                const double f = a[i][k] / a[k][k];
+                for (int j = k; j < 8; ++j) a[i][j] -= f * a[k][j];
+            }
+        for (int i = 0; i < 7; ++i) tr += jt[i] * a[i][7] / a[i][i];
+    }
+    return tr / 3.0;
+}
+
+}  // namespace usim_host

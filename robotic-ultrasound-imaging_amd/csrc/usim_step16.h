@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         for (int v = 0; v < AT_STRIDE / 4; ++v) { const float4 x = ap[v]; at[4 * v] = x.x; at[4 * v + 1] = x.y; at[4 * v + 2] = x.z; at[4 * v + 3] = x.w; }
     }
     const float* const sp = st + scalar_index(0, (size_t)ei);
-    const bool jlane = gl < NJ;                                   // lanes that own a joint
+    const bool jlane = at[AT_JOINT] != 0.f;                       // lanes that own a joint (a chain of fewer than seven joints pads with locked ones)
     const int jl = jlane ? gl : NJ - 1;
     float qj = sp[F_Q + jl], qdj = sp[F_QD + jl], q0j = sp[F_Q0 + jl];
     if (!jlane) { qj = 0.f; qdj = 0.f; q0j = 0.f; }
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         // ================= initial pose: damped-least-squares IK from init_qpos (ultrasound.py:812-844) =================
         const float uu = clampf(u0, 0.f, 1.f);
         const f3 tp0 = ts + (te - ts) * uu;
-        const f3 target = mk(tp0.x + noise.x + 0.0028f - M.base[0], tp0.y + noise.y + 0.0008f - M.base[1], tp0.z + noise.z + 0.0066f - M.base[2]);
+        const f3 target = mk(tp0.x + noise.x + M.ikb[0] - M.base[0], tp0.y + noise.y + M.ikb[1] - M.base[1], tp0.z + noise.z + M.ikb[2] - M.base[2]);
         const f3 gx = mk(M.grot[0], M.grot[3], M.grot[6]), gy = mk(M.grot[1], M.grot[4], M.grot[7]), gz = mk(M.grot[2], M.grot[5], M.grot[8]);
         qj = jlane ? at[AT_INITQ] : 0.f;
         for (int it = 0; it < C.ik_iters; ++it) {
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             const f3 ep = target - xs;
             const float e = is_task ? (blk ? pick(eo) : pick(ep)) : 0.f;
             const f3 jv = cross(Z, xs - P);
-            const float Jc[6] = {jv.x, jv.y, jv.z, Z.x, Z.y, Z.z};
+            const float Jc[6] = {jlane ? jv.x : 0.f, jlane ? jv.y : 0.f, jlane ? jv.z : 0.f, jlane ? Z.x : 0.f, jlane ? Z.y : 0.f, jlane ? Z.z : 0.f};
             float Jr[8];
             jacobian_rows(xl, gl, Jc, Jr);
             // (J J^T + 1e-6 I) y = e, row a in task lane a
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         group_sync();
         const int gc = gl & 7;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) Mr[j] = (j > gl) ? xl[j * 8 + gc] : Ml[j];
+        for (int j = 0; j < NJ; ++j) Mr[j] = ((j > gl) ? xl[j * 8 + gc] : Ml[j]) + ((j == gl && !jlane) ? 1.f : 0.f);    // padding joint: unit diagonal
         group_sync();                                                    // the scratch is reused for the Jacobian below
     }
     USIM_STAMP(dbg, 2);
@@ -440,6 +440,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     {
         const f3 jv = cross(Z, xs - P);
         Jc[0] = jv.x; Jc[1] = jv.y; Jc[2] = jv.z; Jc[3] = Z.x; Jc[4] = Z.y; Jc[5] = Z.z;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) Jc[a] = jlane ? Jc[a] : 0.f;         // no column for padding / site / idle lanes
         float Xm[6];                                                     // row l of M^-1 J^T
 #pragma unroll
         for (int a = 0; a < 6; ++a) Xm[a] = row_times_joint<NJ>(Mi, Jc[a]);

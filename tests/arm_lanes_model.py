@@ -64,6 +64,48 @@ def panda_chain():
             "initq": np.array([0, np.pi / 16.0, 0, -np.pi / 2.0 - np.pi / 3.0, 0, np.pi - 0.2, np.pi / 4])}
 
 
+def _quat(w, x, y, z):
+    n = np.sqrt(w * w + x * x + y * y + z * z); w, x, y, z = w / n, x / n, y / n, z / n
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def ur5e_chain():
+    """UR5e + hand + probe: six joints (robosuite robots/ur5e/robot.xml as restated in oracle/usim_oracle.c ROBOT_UR5E), joints about the
+    body y or z axis.  Every link frame is post-multiplied by Rc (z -> joint axis) so that all joints turn about local z."""
+    h = np.sqrt(0.5)
+    pos = np.array([[0, 0, 0.163], [0, 0.138, 0], [0, -0.131, 0.425], [0, 0, 0.392], [0, 0.127, 0], [0, 0, 0.1]], dtype=float)
+    quat = [(1, 0, 0, 0), (h, 0, h, 0), (1, 0, 0, 0), (h, 0, h, 0), (1, 0, 0, 0), (1, 0, 0, 0)]
+    axis = "zyyyzy"
+    mass = np.array([3.7, 8.393, 2.275, 1.219, 1.219, 0.1889])
+    com = np.array([[0, 0, 0], [0, 0, 0.2125], [0, 0, 0.196], [0, 0.127, 0], [0, 0, 0.1], [0, 0.0771683, 0]], dtype=float)
+    iquat = [(1, 0, 0, 0)] * 5 + [(h, 0, 0, h)]
+    diag = np.array([[0.0102675, 0.0102675, 0.00666], [0.133886, 0.133886, 0.0151074], [0.0311796, 0.0311796, 0.004095], [0.0025599, 0.0025599, 0.0021942],
+                     [0.0025599, 0.0025599, 0.0021942], [0.000132134, 9.90863e-05, 9.90863e-05]])
+    rcy = _quat(np.cos(-np.pi / 4), np.sin(-np.pi / 4), 0, 0)
+    rcs = [rcy if a == "y" else np.eye(3) for a in axis]
+    lpos, rfix, lcom, inertia = [], [], [], []
+    rcp = np.eye(3)
+    for i in range(6):
+        rc = rcs[i]
+        rfix.append(rcp.T @ _quat(*quat[i]) @ rc); lpos.append(rcp.T @ pos[i]); lcom.append(rc.T @ com[i])
+        ri = _quat(*iquat[i])
+        inertia.append(rc.T @ ri @ np.diag(diag[i]) @ ri.T @ rc)
+        rcp = rc
+    Rh = rcp.T @ _quat(h, -h, 0, 0)
+    hand = rcp.T @ np.array([0, 0.098, 0])
+    site = hand + Rh @ np.array([-0.004, -0.063, 0.128])
+    pcom = site + Rh @ np.array([0.0013, 0.021, -0.043])
+    pI = Rh @ np.diag([1.6e-3, 1.6e-3, 2.0e-4]) @ Rh.T
+    m, c, I = _add_body(mass[5], lcom[5], inertia[5], 0.5, hand, 0.05 * np.eye(3))
+    m, c, I = _add_body(m, c, I, 1.0, pcom, pI)
+    mass[5], lcom[5], inertia[5] = m, c, I
+    return {"nj": 6, "lpos": np.array(lpos), "rfix": np.array(rfix), "lcom": np.array(lcom), "mass": mass, "inertia": np.array(inertia),
+            "site": site, "site_rot": Rh, "hand": hand, "pcom": pcom, "pI": pI, "pmass": 1.0,
+            "qmin": np.array([-6.28319, -6.28319, -3.14159, -6.28319, -6.28319, -6.28319]), "qmax": np.array([6.28319, 6.28319, 3.14159, 6.28319, 6.28319, 6.28319]),
+            "taumax": np.array([150.0, 150, 150, 28, 28, 28]), "initq": np.array([-0.470, -1.735, 2.480, -2.275, -1.590, -1.991])}
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # plain formulation (serial chain)
 # ------------------------------------------------------------------------------------------------------------------
@@ -225,13 +267,17 @@ class Lanes:
 
     def __init__(self, ch):
         self.ch, self.T = ch, lane_tables(ch)
-        self.nj = ch["nj"]
+        self.nreal = ch["nj"]                 # joints of the robot
+        self.nj = 7                           # joint lanes of the kernel: a shorter chain is padded with locked joints
         self.lane = np.arange(NL)
+
+    def _pad(self, v):
+        return np.concatenate([np.asarray(v, dtype=float), np.zeros(NL - len(v))])
 
     # ---- kinematics: world frame of every link by a scan over the composition of the local transforms ----
     def fk(self, q):
         T, nj = self.T, self.nj
-        ql = np.zeros(NL); ql[:nj] = q
+        ql = self._pad(q)
         s, c = np.sin(ql) * T["joint"], np.where(T["joint"] > 0, np.cos(ql), 1.0)
         Rf = T["rfix"]
         R = [[None] * 3 for _ in range(3)]            # R[r][col] lane vectors: local rotation = rfix * Rz(q)
@@ -261,7 +307,7 @@ class Lanes:
     # ---- dynamics: RNE as prefix / suffix sums over the joint lanes, CRBA with suffix sums of the link inertias ----
     def dynamics(self, qd):
         T, nj = self.T, self.nj
-        qdl = np.zeros(NL); qdl[:nj] = qd
+        qdl = self._pad(qd)
         z, o, c, rc, R = self.z, self.o, self.c, self.rc, self.R
         zq = [z[r] * qdl for r in range(3)]
         w = [prefix(zq[r]) for r in range(3)]
@@ -320,6 +366,8 @@ class Lanes:
         self.M = [np.concatenate([lds[:, j], np.zeros(8)]) for j in range(nj)]        # M[j]: entry j of every lane's row
         for j in range(nj):
             self.M[j][nj:] = 0.0                                                          # lanes that own no link: zero rows
+            if T["joint"][j] == 0:
+                self.M[j][j] += 1.0                                                       # padding joint: unit diagonal, decoupled
         return self
 
     def inverse(self):
@@ -344,7 +392,7 @@ class Lanes:
         jv = cross3(z, d)
         Jc = jv + [z[0], z[1], z[2]]                                    # column j of J in lane j: Jc[a]
         for a in range(6):
-            Jc[a] = np.where(self.lane < nj, Jc[a], 0.0)
+            Jc[a] = np.where(self.T["joint"] > 0, Jc[a], 0.0)                            # no column for padding / site / idle lanes
         self.Jc = Jc
         # X = Minv J^T : row i in lane i
         X = [sum(self.Minv[j] * bc(Jc[a], j) for j in range(nj)) for a in range(6)]
@@ -376,7 +424,7 @@ class Lanes:
 
     def controller(self, q, qd, q0, gpos, G, kp, kd, wrench_override=None):
         nj, lane = self.nj, self.lane
-        ql, qdl, q0l = (np.concatenate([np.asarray(v, dtype=float), np.zeros(NL - nj)]) for v in (q, qd, q0))
+        ql, qdl, q0l = (self._pad(v) for v in (q, qd, q0))
         self.qdl = qdl
         blk = (lane >= 4)
         comp = lane % 4                                                 # component handled by a task lane
@@ -421,14 +469,14 @@ class Lanes:
                 A[c] = A[c] - g * bc(A[c], lk)
             jb = jb - g * bc(jb, lk)
         tau = self.bias + y + self.jcol_times(wr - jb)
-        tmax = np.concatenate([self.ch["taumax"], np.full(NL - nj, 1.0)])
+        tmax = np.concatenate([self.ch["taumax"], np.full(NL - self.nreal, 1.0)])
         self.tau = np.clip(tau, -tmax, tmax)
         self.wr = wr
         return self
 
     def after_contact(self, q, qd, W, dt, joint_damp=0.1):
         nj, ch = self.nj, self.ch
-        ql, qdl = (np.concatenate([np.asarray(v, dtype=float), np.zeros(NL - nj)]) for v in (q, qd))
+        ql, qdl = (self._pad(v) for v in (q, qd))
         qs = self.mat_times(self.Minv, self.tau - self.bias - joint_damp * qdl)
         alpha = self.jrow_times(qs)
         z0 = sum(self.Jc[a] * W[a] for a in range(6))
@@ -468,5 +516,7 @@ class Lanes:
         hx = [self.hand[r] - x[r] for r in range(3)]
         cw = cross3(vs2[3:], hx)
         hv = [vs2[r] + cw[r] for r in range(3)]
-        return {"qs": qs[:nj], "alpha": np.array([alpha[TASK_LANE[a]] for a in range(6)]), "qacc": qacc[:nj],
-                "tq": np.array([t[0] for t in tq]), "q": q_new[:nj], "qd": qd_new[:nj], "hv": np.array([h[0] for h in hv])}
+        nr = self.nreal
+        assert np.all(q_new[nr:] == 0) and np.all(qd_new[nr:] == 0)                  # padding joints and idle lanes stay at rest
+        return {"qs": qs[:nr], "alpha": np.array([alpha[TASK_LANE[a]] for a in range(6)]), "qacc": qacc[:nr],
+                "tq": np.array([t[0] for t in tq]), "q": q_new[:nr], "qd": qd_new[:nr], "hv": np.array([h[0] for h in hv])}

@@ -12,6 +12,7 @@ ORACLE_DIR = ROOT / "oracle"
 OBS_DIM, MAXC, NSCALAR = 19, 8, 40
 MODE = {"tracking": 0, "fixed": 1, "variable_z": 2, "wrench": 3}
 TORSO = {"none": 0, "top": 1}
+ROBOT = {"Panda": 0, "UR5e": 1}
 
 SCALAR_FIELDS = {  # name -> slice in the uso_get_state scalar block
     "q": slice(0, 7), "qd": slice(7, 14), "q0": slice(14, 21), "traj_start": slice(21, 24), "traj_end": slice(24, 27),
@@ -23,7 +24,7 @@ SCALAR_FIELDS = {  # name -> slice in the uso_get_state scalar block
 class OracleConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "mode", "torso", "horizon", "early_termination", "deterministic_trajectory", "torso_solref_randomization",
-        "initial_probe_pos_randomization", "friction_randomization", "torso_drop", "pgs_iters", "ik_iters", "env_offset", "torso_shape")] + \
+        "initial_probe_pos_randomization", "friction_randomization", "torso_drop", "pgs_iters", "ik_iters", "env_offset", "torso_shape", "robot")] + \
         [("seed", C.c_uint64)] + [(n, C.c_double) for n in (
             "control_dt", "kp_fixed", "damping_ratio", "kp_min", "kp_max", "out_max_pos", "out_max_ori", "stiffness",
             "damping", "elem_friction", "probe_friction", "probe_radius", "probe_halflen")]
@@ -84,6 +85,8 @@ class Oracle:
                 v = MODE[v]
             if k == "torso" and isinstance(v, str):
                 v = TORSO[v]
+            if k == "robot" and isinstance(v, str):
+                v = ROBOT[v]
             if not hasattr(self.cfg, k):
                 raise KeyError(k)
             setattr(self.cfg, k, v)

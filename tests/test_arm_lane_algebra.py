@@ -21,9 +21,10 @@ def _case(ch, rng):
     return q, qd, q0, G, kp, 2 * np.sqrt(kp), rng.normal(0, 3, 6)
 
 
-@pytest.mark.parametrize("robot", ["panda"])
+@pytest.mark.parametrize("robot", ["panda", "ur5e"])
 def test_lane_formulation_equals_the_serial_chain(robot):
-    ch = {"panda": alm.panda_chain}[robot]()
+    """(ur5e: six joints about body y / z axes re-expressed about local z, the seventh joint lane carries a locked padding joint)"""
+    ch = {"panda": alm.panda_chain, "ur5e": alm.ur5e_chain}[robot]()
     rng = np.random.default_rng(5)
     for trial in range(20):
         q, qd, q0, G, kp, kd, W = _case(ch, rng)
@@ -62,19 +63,44 @@ def test_lane_formulation_equals_the_serial_chain(robot):
             assert np.allclose(out[k], P[k], rtol=1e-7, atol=1e-8), k
 
 
-def test_plain_panda_model_matches_the_oracle_forward_quantities():
+@pytest.mark.parametrize("robot", ["Panda", "UR5e"])
+def test_plain_model_matches_the_oracle_forward_quantities(robot):
     """the serial-chain reference of this file is the same arm model the C oracle implements (uso_debug_forward)"""
     from oracle_lib import Oracle
-    ch = alm.panda_chain()
-    orc = Oracle(1, torso="none")
+    ch = {"Panda": alm.panda_chain, "UR5e": alm.ur5e_chain}[robot]()
+    nj = ch["nj"]
+    orc = Oracle(1, torso="none", robot=robot)
     orc.reset()
     q = orc.get_state()["q"][0]
+    assert np.all(q[nj:] == 0)
     dbg = orc.debug_forward(0)
-    K = alm.plain_fk(ch, q)
-    D = alm.plain_dynamics(ch, K, np.zeros(7))
+    K = alm.plain_fk(ch, q[:nj])
+    D = alm.plain_dynamics(ch, K, np.zeros(nj))
     base = np.array([-0.56, 0.0, 0.913])
     assert np.allclose(K["x"] + base, dbg["x"], atol=1e-9)
     assert np.allclose(K["S"], dbg["R"], atol=1e-9)
-    assert np.allclose(D["M"], dbg["M"], atol=1e-9)
-    assert np.allclose(D["bias"], dbg["bias"], atol=1e-9)
-    assert np.allclose(alm.plain_jacobian(K), dbg["J"], atol=1e-9)
+    assert np.allclose(D["M"], dbg["M"][:nj, :nj], atol=1e-9)
+    assert np.allclose(D["bias"], dbg["bias"][:nj], atol=1e-9)
+    assert np.allclose(alm.plain_jacobian(K), dbg["J"][:, :nj], atol=1e-9)
+    if nj < 7:          # locked padding joint: unit diagonal, no coupling, no Jacobian column
+        assert dbg["M"][6, 6] == 1 and np.all(dbg["M"][6, :6] == 0) and np.all(dbg["J"][:, 6] == 0)
+
+
+def test_ur5e_chain_known_answers():
+    """UR5e geometry independent of the code paths above: the zero pose of the MJCF chain against the published DH zero pose, total
+    mass, the gravity torque of the stretched-out arm by hand; the reset IK of the oracle reaches the trajectory start with the probe on
+    the goal orientation."""
+    from oracle_lib import Oracle
+    ch = alm.ur5e_chain()
+    K = alm.plain_fk(ch, np.zeros(6))
+    # wrist-3 origin of the stretched-out arm: the published UR5e zero pose (a2 + a3 = 0.817 along x, d4 = 0.134 sideways, d1 - d5 = 0.063 up)
+    assert np.allclose(K["o"][5], [0.425 + 0.392, 0.138 - 0.131 + 0.127, 0.163 - 0.1], atol=1e-12)
+    assert np.isclose(ch["mass"].sum(), 3.7 + 8.393 + 2.275 + 1.219 + 1.219 + 0.1889 + 0.5 + 1.0)
+    # gravity torque about the shoulder-lift axis (y) = -g * sum of m_i * horizontal lever arm of the links behind it
+    D = alm.plain_dynamics(ch, K, np.zeros(6))
+    lever = sum(ch["mass"][i] * (K["c"][i][0] - K["o"][1][0]) for i in range(1, 6))
+    assert np.allclose(K["z"][1], [0, 1, 0], atol=1e-12) and np.isclose(D["bias"][1], -alm.GRAV * lever, rtol=1e-12) and abs(D["bias"][0]) < 1e-12
+    orc = Oracle(256, torso="none", robot="UR5e")
+    obs = orc.reset()
+    assert np.abs(obs[:, 12:14]).max() < 0.012 and np.abs(obs[:, 14]).max() < 0.05          # position noise only (no IK bias for this robot)
+    assert np.allclose(np.abs(obs[:, 15]), 1.0, atol=1e-6) and np.abs(obs[:, 16:19]).max() < 1e-5

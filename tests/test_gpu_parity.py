@@ -20,11 +20,12 @@ MARGIN = {"contact": 5e-6,   # m     : |capsule distance| below which the contac
           "joint": 1e-4}     # rad
 
 
-def _mk(usim, n, torso, mode, seed=3, omp=False, **extra):
+def _mk(usim, n, torso, mode, seed=3, omp=False, robot="Panda", **extra):
     kw = usim.default_robosuite_kwargs()
     kw["controller_configs"] = dict(kw["controller_configs"], impedance_mode=mode)
+    kw["robots"] = robot
     env = usim.UltrasoundVecEnv(n, device="cuda:0", seed=seed, torso=torso, **kw, **extra)
-    ora = Oracle(n, precision="f64", omp=omp, mode=mode, torso="top" if torso == "soft" else "none", seed=seed, **extra)
+    ora = Oracle(n, precision="f64", omp=omp, mode=mode, torso="top" if torso == "soft" else "none", seed=seed, robot=robot, **extra)
     return env, ora
 
 
@@ -117,6 +118,13 @@ def test_rigid_torso_parity_200_steps(usim, mode):
 def test_soft_torso_parity_200_steps(usim, mode):
     """BASELINE configs[2]: soft-torso contact + force/velocity-tracking reward"""
     _run_parity(usim, 256, 200, "soft", mode)
+
+
+@pytest.mark.parametrize("torso,mode", [("rigid", "tracking"), ("soft", "tracking"), ("soft", "variable_z"), ("rigid", "fixed")])
+def test_ur5e_parity_200_steps(usim, torso, mode):
+    """the second robot of ultrasound.py:137 (six joints; the seventh joint lane carries a locked padding joint): same kernels, another
+    arm table; same bar against the oracle's generic body tree"""
+    _run_parity(usim, 256, 200, torso, mode, robot="UR5e")
 
 
 def test_full_size_parity_4096_envs(usim):

@@ -64,6 +64,12 @@ def test_default_config_is_the_shipped_rl_config(usim, tmp_path):
     assert (c.stiffness, c.damping) == (1324.17, 17.59)          # soft_box.xml:9
 
 
+def test_config_accepts_both_robots_of_the_reference(usim):
+    kw = usim.default_robosuite_kwargs()
+    assert usim.make_config(**kw).robot == 0 and usim.make_config(**{**kw, "robots": "UR5e"}).robot == 1      # ultrasound.py:137
+    assert usim.make_config(**{**kw, "robots": ["UR5e"]}).robot == 1
+
+
 def test_config_rejects_what_the_reference_rejects(usim):
     kw = usim.default_robosuite_kwargs()
     with pytest.raises(ValueError):
