@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--randomize", action="store_true", help="BASELINE configs[4]: per-env randomised stiffness/damping + probe friction")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--lanes-per-env", type=int, default=0, choices=[0, 1, 8, 16], help="kernel mapping: 16 lanes per environment (automatic), 8 (soft torso) or 1 (rigid torso)")
+    ap.add_argument("--lanes-per-env", type=int, default=0, choices=[0, 1, 8, 16, 32], help="kernel mapping: 16 lanes per environment (automatic), 8 (soft torso) or 1 (rigid torso)")
     args = ap.parse_args()
 
     import torch
@@ -165,6 +165,8 @@ def main():
         except Exception:
             traffic = None
 
+    # the mapping usim_create picks (csrc/usim_api.hip): soft torso up to 4096 envs -> two waves per quad of environments (32 lanes per env)
+    lanes = int(extra.get("lanes_per_env", 0)) or (32 if (args.workload == "soft" and n <= 4096 and not extra.get("waves_per_simd")) else 16)
     if rank == 0:
         total_steps = args.steps * n * world
         out = {
@@ -175,11 +177,11 @@ def main():
             "config": {"workload": WORKLOAD_NAME[args.workload], "envs_per_gpu": n, "global_envs": n * world,
                        "controller": "OSC_POSE impedance_mode=tracking", "rollout_block": T, "domain_randomisation": "stiffness+damping" + ("+friction" if args.randomize else ""),
                        "parallelism": f"env-shard x{world}" + (" + RCCL all-gather of transition blocks" if gather is not None else ""),
-                       "lanes_per_env": int(extra.get("lanes_per_env", 0)) or 16, "waves_per_simd": int(extra.get("waves_per_simd", 0)) or "auto"},
+                       "lanes_per_env": lanes, "waves_per_simd": int(extra.get("waves_per_simd", 0)) or "auto"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": f"{tfile.relative_to(ROOT)} (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch)" if traffic else None,
                          "algorithmic_bytes_per_launch": ALGO_BYTES[args.workload] * n, "algorithmic_bytes_per_env_step": ALGO_BYTES[args.workload],
-                         "avg_kernel_us": avg_kernel_s * 1e6, "kernel": "usim_step16_kernel" if int(extra.get("lanes_per_env", 0)) in (0, 16) else "usim_step_kernel",
+                         "avg_kernel_us": avg_kernel_s * 1e6, "kernel": {32: "usim_step32_kernel", 16: "usim_step16_kernel"}.get(lanes, "usim_step_kernel"),
                          "valu_fp32_tflops": valu_tflops, "valu_frac": valu_tflops / FP32_VALU_PEAK_TFLOPS,
                          "note": "kernel is FP32-VALU/latency bound at 4096 envs (one wave per SIMD), not HBM bound; see DESIGN.md section 5"},
         }

@@ -33,7 +33,7 @@ struct usim_handle {
     int* d_count = nullptr;           // [0] items, [1] finished workgroups of the running refill
     long long steps_since_refill = 0;
     int bank_row0 = 0;
-    size_t lds_bytes = 0, lds16_bytes = 0;
+    size_t lds_bytes = 0, lds16_bytes = 0, lds32_bytes = 0;
     std::string hip_err;
 };
 
@@ -230,7 +230,11 @@ static int launch(usim_handle* h, DevIO io, int flags, long long rstep, hipStrea
     hipError_t e;
     // 16 lanes per environment: the kernels with the distributed arm mathematics (usim_step16.h); the 8-lane / one-lane mappings run the
     // kernels of usim_kernels.hip
-    if (h->lpe == 16) {
+    if (h->lpe == 32 && MODE == 0) {
+        dim3 grid((h->n + 15) / 16), block(512);
+        hipLaunchKernelGGL(usim_step32_kernel, grid, block, h->lds32_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
+        e = hipGetLastError();
+    } else if (h->lpe == 16 || h->lpe == 32) {
         // (reset computations are not register-critical: always the two-waves-per-SIMD build)
         if (!h->n_el) e = launch_step16<0, 2, MODE>(h, io, flags, rstep, s);
         else if constexpr (MODE == 0) e = (h->occ == 1) ? launch_step16<1, 1, 0>(h, io, flags, rstep, s) : launch_step16<1, 2, 0>(h, io, flags, rstep, s);
@@ -298,15 +302,20 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
     // yields about 1024 waves wins: 16 lanes up to 4096 envs/GPU (one 4-wave workgroup per CU), 8 lanes beyond.
     // (superseded for steps by the 16-lane kernel of usim_step16.h, which is the automatic choice at every batch size; 8 lanes on request)
     // Rigid torso: 16 lanes per environment (arm mathematics distributed over the group) or, with lanes_per_env = 1, one lane each.
-    h->lpe = h->n_el ? (cfg->lanes_per_env == 0 ? 16 : cfg->lanes_per_env) : (cfg->lanes_per_env == 0 ? 16 : cfg->lanes_per_env);
-    if (h->n_el ? (h->lpe != 8 && h->lpe != 16) : (h->lpe != 1 && h->lpe != 16)) return USIM_ERR_INVALID;
-    if (cfg->robot != USIM_ROBOT_PANDA && h->lpe != 16) {
+    // Soft torso, automatic choice: up to 4096 envs/GPU the split kernel (32 lanes = two waves per quad of environments, usim_step32_kernel)
+    // unless a register budget was asked for; beyond, 16 lanes per environment with the two-waves-per-SIMD budget.
+    h->lpe = h->n_el ? (cfg->lanes_per_env == 0 ? ((n_envs <= 4096 && cfg->waves_per_simd == 0) ? 32 : 16) : cfg->lanes_per_env)
+                     : (cfg->lanes_per_env == 0 ? 16 : cfg->lanes_per_env);
+    if (h->n_el ? (h->lpe != 8 && h->lpe != 16 && h->lpe != 32) : (h->lpe != 1 && h->lpe != 16)) return USIM_ERR_INVALID;
+    if (cfg->robot != USIM_ROBOT_PANDA && h->lpe != 16 && h->lpe != 32) {
         h->hip_err = "the UR5e runs on the table-driven 16-lane kernels only (lanes_per_env 0 or 16)";
         return USIM_ERR_UNSUPPORTED;
     }
     h->occ = cfg->waves_per_simd ? cfg->waves_per_simd : (n_envs <= 4096 ? 1 : 2);
     h->lds16_bytes = h->n_el ? (size_t)GroupGeom<16>::LDS_WORDS * sizeof(float) : (size_t)16 * X16_RIGID_STRIDE * sizeof(float);
+    h->lds32_bytes = (size_t)(X2_BASE + 16 * X2_STRIDE) * sizeof(float);
     if (h->n_el) {
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds32_bytes));
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step16_kernel<1, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds16_bytes));
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step16_kernel<1, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds16_bytes));
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step16_kernel<1, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds16_bytes));
@@ -510,16 +519,16 @@ int usim_profile_step(usim_handle* h, const usim_step_io* s, int64_t step, uint6
     if (rc) return rc;
     io.act = nullptr;
     unsigned long long* d = nullptr;
-    HIPCHK(h, hipMalloc(&d, 32 * sizeof(unsigned long long)));
-    HIPCHK(h, hipMemset(d, 0, 32 * sizeof(unsigned long long)));
+    HIPCHK(h, hipMalloc(&d, 64 * sizeof(unsigned long long)));
+    HIPCHK(h, hipMemset(d, 0, 64 * sizeof(unsigned long long)));
     io.dbg = d; io.items = h->d_items; io.count = h->d_count;
     rc = launch<0>(h, io, LF_AUTO_RESET | LF_RANDOM_ACT, (long long)step, nullptr);
     if (rc == USIM_OK && ++h->steps_since_refill >= BANK_DEPTH) rc = bank_refill(h, nullptr);
     HIPCHK(h, hipDeviceSynchronize());
-    unsigned long long host[32];
+    unsigned long long host[64];
     HIPCHK(h, hipMemcpy(host, d, sizeof host, hipMemcpyDeviceToHost));
     HIPCHK(h, hipFree(d));
-    for (int i = 0; i < 17; ++i) ticks[i] = host[i];
+    for (int i = 0; i < (max_ticks < 64 ? max_ticks : 64); ++i) ticks[i] = host[i];      // 0-16: phases of the single-wave kernels; 20-29 / 30-39: arm / lattice side of the split kernel
     return rc;
 }
 

@@ -116,7 +116,8 @@ DI void torso_motion(const DevCfg& C, int tsim, float& dz, float& vz, float& az)
 // Lattice front end of one forward pass, executed by the G lanes of a group on the group's LDS block: stage (s, sdot), build
 // the right-hand side of the soft-equality system, a~ = Linv rhs, collide the probe capsule with the 99 cap spheres and
 // leave the contact records (ascending shell id; the MAXC deepest when more were found) in LDS.  Returns the number found (may exceed MAXC).
-template <int G, int NE, bool MM>
+// PART 0: everything; 1: staging + right-hand side only (needs no arm quantity); 2: solve + collision only (after a PART 1 call).
+template <int G, int NE, bool MM, int PART = 0>
 DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, const DevModel& M, const DevCfg& C, const int tsim,
                      const float kst, const float kdmp, const bool live, const float* s_pre, const float* sd_pre,
                      const f3 Kx, const f3 Ksy, const f3 Ksz, unsigned long long* dbg) {
@@ -128,6 +129,7 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
 #define EBF(off) lds[TB_WORDS + eb * GE_STRIDE + (off)]
     float dz, vz, az;
     torso_motion(C, tsim, dz, vz, az);
+                    if constexpr (PART != 2) {
                                     // ---- stage s, sdot and the spring-damper potential u = k_t s + b_t sdot: lane gl of the group owns elements
                     //      gl, gl+G, ...  u goes into a zero-bordered 11 x 13 copy of the 9 x 11 grid, so that the four neighbours of an
                     //      element are four unconditional reads; a pinned rim neighbour (s = 0) is a border cell.
@@ -167,6 +169,8 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                     }
                     if (gl == 0) EBF(GE_X + N_TOP) = 0.f;          // pad word read by the 16-byte row chunks
                     group_sync();
+                    }
+                    if constexpr (PART == 1) return 0;
                     LSTAMP(5);
                                     // ---- collision round i: probe capsule vs the cap spheres of elements i G .. i G + G - 1 (one per lane); the wave
                     //      ballot gives every hit its slot so that the contact list stays sorted by ascending shell id.  Straight-line code

@@ -158,13 +158,21 @@ constexpr int X16_RIGID_STRIDE = 68;                  // rigid-torso launches: o
 // MODE 0: one env.step() per environment; a finished environment takes its next initial state from the reset bank.
 // MODE 1: reset computation (draws, initial-pose IK, zero-torque forward pass) for the environments selected by the mask (written to the
 //         live state) or for the (env, episode) items of the refill work list (written to the reset bank).
-template <int TORSO, int OCC, int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void usim_step16_kernel(const DevModel M, const DevCfg C, float* __restrict__ st, int n, int npad, const DevIO io,
-                                                          int flags, long long rstep) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int G = 16, EPW = 4, EPB = 16, NT = 256;
+//
+// ROLE (usim_step32_kernel): the soft-torso step of four environments split over TWO waves that share a SIMD -- ROLE 1 runs the arm side
+// (kinematics ... controller, then acceleration, sensors, reward, bookkeeping), ROLE 2 the lattice / contact side (staging, right-hand side,
+// matrix-core solve, collision, contact solve, element integration).  They meet at workgroup barriers and hand over through per-environment
+// LDS mailboxes: site pose (1 -> 2), Lambda^-1 / alpha / vs (1 -> 2), contact wrench and contact list (2 -> 1).  ROLE 0 = one wave does both.
+constexpr int X2_BASE = TB_WORDS + 16 * GE_STRIDE;        // behind the sixteen per-environment blocks: arm scratch + mailboxes of the split kernel
+constexpr int X2_STRIDE = 164, MB_POSE = 64, MB_OP = 76, MB_W = 140;      // 64 transpose scratch | 12 pose | 64 op-space (6 x 8 Lambda^-1, alpha 6, vs 6) | 16 wrench + contacts
+static_assert(MB_W + 16 <= X2_STRIDE, "mailbox block");
+
+template <int TORSO, int MODE, int ROLE, int NT>
+DI void step16_body(float* lds, const DevModel& M, const DevCfg& C, float* __restrict__ st, const int n, const int npad, const DevIO& io, const int flags, const long long rstep) {
+    constexpr int G = 16, EPW = 4, EPB = 16;
     constexpr int NE = TORSO ? (N_TOP + G - 1) / G : 1;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    static_assert(ROLE == 0 || (TORSO == 1 && MODE == 0), "the split kernel is the soft-torso step");
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;      // wave within its role = quad of environments
     const int gl = lane & 15, ge = lane >> 4;
     const int gbase = lane - gl;
     const int eb = wave * EPW + ge;
@@ -189,10 +197,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 #define EB(off) lds[TB_WORDS + eb * GE_STRIDE + (off)]
 #define BK(slot, f) st[(size_t)io.bank_row0 * npad + ((size_t)ei * BANK_DEPTH + (slot)) * BANK_STRIDE + (f)]
 #define BKI(slot, f) (reinterpret_cast<int*>(st))[(size_t)io.bank_row0 * npad + ((size_t)ei * BANK_DEPTH + (slot)) * BANK_STRIDE + (f)]
-    float* const xl = TORSO ? &lds[TB_WORDS + eb * GE_STRIDE + GE_WS] : &lds[eb * X16_RIGID_STRIDE];       // transpose scratch of this environment
+    float* const xl = (ROLE != 0) ? &lds[X2_BASE + eb * X2_STRIDE]
+                                  : (TORSO ? &lds[TB_WORDS + eb * GE_STRIDE + GE_WS] : &lds[eb * X16_RIGID_STRIDE]);   // transpose scratch of this environment
     static_assert(GE_WS + X16_WORDS <= GE_STRIDE, "transpose scratch overlays the wrench records");
 
     USIM_STAMP(dbg, 0);
+    if constexpr (ROLE == 1) { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[20] = __builtin_readcyclecounter(); }
 
     // ---------------- load: this lane's link record, its joint state, the environment's scalars ----------------
     float at[AT_STRIDE];
@@ -223,7 +233,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     for (int i = 0; i < NE; ++i) {
         const int e = gl + i * G;
         s_pre[i] = 0.f; sd_pre[i] = 0.f;
-        if (TORSO && MODE == 0 && e < N_TOP) { s_pre[i] = LAT(LAT_S + e); sd_pre[i] = LAT(LAT_SD + e); }
+        if (TORSO && MODE == 0 && ROLE != 1 && e < N_TOP) { s_pre[i] = LAT(LAT_S + e); sd_pre[i] = LAT(LAT_SD + e); }
     }
     if (TORSO != 0 && item0 == item_first) {
         // workgroup-resident copy of the lattice tables: 16-byte loads, all issued before the first LDS store (and behind the state loads
@@ -240,35 +250,88 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     }
     USIM_STAMP(dbg, 1);
 
-    // ---------------- action (replicated: seven words) ----------------
-    float act[7] = {0, 0, 0, 0, 0, 0, 0};
-    if constexpr (MODE == 0) {
-    if (flags & LF_RANDOM_ACT) {
-        // the two counter blocks are evaluated side by side by the even and odd lanes of the group, then shared
-        const uint32_t gid = (uint32_t)(C.env_offset + ei);
-        const u4 r = philox(gid, (uint32_t)rstep, (uint32_t)((unsigned long long)rstep >> 32), 1u + (uint32_t)(gl & 1), C.key0, C.key1);
-        const float ra = __uint_as_float(r.a), rb = __uint_as_float(r.b), rc = __uint_as_float(r.c), rd = __uint_as_float(r.d);
-        uint32_t rr[7];
-        rr[0] = __float_as_uint(rbc<0>(ra)); rr[1] = __float_as_uint(rbc<0>(rb)); rr[2] = __float_as_uint(rbc<0>(rc)); rr[3] = __float_as_uint(rbc<0>(rd));
-        rr[4] = __float_as_uint(rbc<1>(ra)); rr[5] = __float_as_uint(rbc<1>(rb)); rr[6] = __float_as_uint(rbc<1>(rc));
-#pragma unroll
-        for (int a = 0; a < 7; ++a) {
-            const float u = u01(rr[a]);
-            const bool sgn = (C.mode == 1) || (C.mode == 3) || (C.mode == 2 && a == 6);
-            act[a] = sgn ? 2.f * u - 1.f : u;
-            if (C.mode == 3) act[a] *= WRENCH_MAX;
-            if (io.act_out && store && a < C.adim) io.act_out[(size_t)ei * C.adim + a] = act[a];
-        }
-    } else {
-#pragma unroll
-        for (int a = 0; a < 7; ++a) if (a < C.adim) {
-            const float v = io.act[(size_t)ei * C.adim + a];
-            act[a] = (v == v && fabsf(v) <= 3.0e38f) ? v : 0.f;          // a non-finite action component is treated as 0
-        }
-    }
-    t += 1;                                                              // MujocoEnv.step: timestep += 1
-    }
+    if constexpr (MODE == 0) t += 1;                                     // MujocoEnv.step: timestep += 1
     const float dt = C.dt, inv_h = rcp_((float)C.horizon);
+#if defined(USIM_TSTAMP) || defined(USIM_TSTAMP_NOWAIT)
+#define RSTAMP(k) do { if (dbg && blockIdx.x == 0 && (threadIdx.x & 255) == 0) dbg[(ROLE == 2 ? 30 : 20) + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RSTAMP(k) do { } while (0)
+#endif
+    if constexpr (ROLE == 2) {
+        // ================= lattice / contact side of the split kernel =================
+        RSTAMP(0);
+        float* const mb = &lds[X2_BASE + eb * X2_STRIDE];
+        const int* tb_shell = reinterpret_cast<const int*>(lds + TB_SHELL);
+        const int tsim = t - 1;
+        float dz, vz, az;
+        torso_motion(C, tsim, dz, vz, az);
+        lattice_front<G, NE, true, 1>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, true, s_pre, sd_pre, mk(0, 0, 0), mk(0, 0, 0), mk(0, 0, 0), dbg);
+        RSTAMP(1);
+        __syncthreads();                                                 // (1) the arm side has published the site pose
+        RSTAMP(2);
+        const f3 xs = mk(mb[MB_POSE], mb[MB_POSE + 1], mb[MB_POSE + 2]), sy = mk(mb[MB_POSE + 3], mb[MB_POSE + 4], mb[MB_POSE + 5]),
+                 sz = mk(mb[MB_POSE + 6], mb[MB_POSE + 7], mb[MB_POSE + 8]);
+        int nc = lattice_front<G, NE, true, 2>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, true, s_pre, sd_pre, xs, sy, sz, dbg);
+        int overflow = 0;
+        if (nc > MAXC) { overflow = 1; nc = MAXC; }
+        group_sync();
+        int ncmax = 0;
+#pragma unroll
+        for (int k = MAXC; k >= 1; --k) if (ncmax == 0 && __any(nc >= k)) ncmax = k;
+        float gf[MAXC], W[6] = {0, 0, 0, 0, 0, 0};
+        int cel[MAXC];
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) { gf[k] = 0.f; cel[k] = (k < nc) ? __float_as_int(EB(GE_CG + k * CG_WORDS + 6)) : 0; }
+        RSTAMP(3);
+        __syncthreads();                                                 // (2) ... and Lambda^-1, alpha = J qs, vs = J qd
+        RSTAMP(4);
+        if (ncmax > 0) {
+            float alpha[6], vs[6], Lp[21];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                alpha[a] = mb[MB_OP + 48 + a]; vs[a] = mb[MB_OP + 54 + a];
+#pragma unroll
+                for (int b = 0; b <= a; ++b) Lp[PK(a, b)] = mb[MB_OP + a * 8 + b];
+            }
+            contact_solve<G>(lds, eb, gl, M, C, nc, ncmax, cel, Lp, alpha, vs, mu, vz, W, gf, dbg);
+        }
+        if (gl == 0) {
+            *reinterpret_cast<float4*>(&mb[MB_W]) = make_float4(W[0], W[1], W[2], W[3]);
+            *reinterpret_cast<float4*>(&mb[MB_W + 4]) = make_float4(W[4], W[5], __int_as_float(nc), __int_as_float(overflow));
+#pragma unroll
+            for (int k = 0; k < MAXC; ++k) mb[MB_W + 8 + k] = __int_as_float((k < nc) ? tb_shell[cel[k]] : -1);
+        }
+        RSTAMP(5);
+        __syncthreads();                                                 // (3) contact wrench and contact list published
+        RSTAMP(6);
+        {
+            float acc_e[NE];
+#pragma unroll
+            for (int i = 0; i < NE; ++i) { const int e = gl + i * G; acc_e[i] = (e < N_TOP) ? EB(GE_A + e) : 0.f; }
+#pragma unroll
+            for (int k = 0; k < MAXC; ++k) {
+                if (k < ncmax) {
+#pragma unroll
+                    for (int i = 0; i < NE; ++i) {
+                        const int e = (gl + i * G < N_TOP) ? gl + i * G : N_TOP - 1;
+                        acc_e[i] = fmaf(lds[TB_LINV + e * LROW + cel[k]], gf[k], acc_e[i]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const int e = gl + i * G;
+                if (e >= N_TOP) continue;
+                const float sdn = EB(GE_SD + e) + dt * acc_e[i];
+                const float sn = EB(GE_S + e) + dt * sdn;
+                if (valid) { LAT(LAT_SD + e) = sdn; LAT(LAT_S + e) = sn; }
+            }
+        }
+        RSTAMP(7);
+        __syncthreads();                                                 // (4) lattice stored: the arm side may now zero it for an episode that ended
+        RSTAMP(8);
+        return;
+    }
     const int comp = gl & 3;                                             // task lanes: component of the position (quad 0) / orientation (quad 1) block
     const bool blk = (gl & 4) != 0;
     const bool is_task = (gl < 8) && comp != 3;
@@ -361,7 +424,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     // site frame = lane 7's; hand origin = a fixed point of the last link
     const f3 sx = rbc3<7>(X), sy = rbc3<7>(Y), sz = rbc3<7>(Z), xs = rbc3<7>(P);
     const f3 hand = rbc3<NJ - 1>(P + X * M.hand7[0] + Y * M.hand7[1] + Z * M.hand7[2]);
+    if constexpr (ROLE == 1) {
+        if (gl == 7) {                                                   // the site frame is lane 7's own
+            float* mbp = xl + MB_POSE;
+            mbp[0] = P.x; mbp[1] = P.y; mbp[2] = P.z; mbp[3] = Y.x; mbp[4] = Y.y; mbp[5] = Y.z; mbp[6] = Z.x; mbp[7] = Z.y; mbp[8] = Z.z;
+        }
+        if constexpr (ROLE == 1) RSTAMP(1);
+        __syncthreads();                                                 // (1)
+        if constexpr (ROLE == 1) RSTAMP(2);
+    }
 
+    // ---------------- action (replicated: seven words) ----------------
+    float act[7] = {0, 0, 0, 0, 0, 0, 0};
+    if constexpr (MODE == 0) {
+    if constexpr (ROLE != 2) {
+    if (flags & LF_RANDOM_ACT) {
+        // the two counter blocks are evaluated side by side by the even and odd lanes of the group, then shared
+        const uint32_t gid = (uint32_t)(C.env_offset + ei);
+        const u4 r = philox(gid, (uint32_t)rstep, (uint32_t)((unsigned long long)rstep >> 32), 1u + (uint32_t)(gl & 1), C.key0, C.key1);
+        const float ra = __uint_as_float(r.a), rb = __uint_as_float(r.b), rc = __uint_as_float(r.c), rd = __uint_as_float(r.d);
+        uint32_t rr[7];
+        rr[0] = __float_as_uint(rbc<0>(ra)); rr[1] = __float_as_uint(rbc<0>(rb)); rr[2] = __float_as_uint(rbc<0>(rc)); rr[3] = __float_as_uint(rbc<0>(rd));
+        rr[4] = __float_as_uint(rbc<1>(ra)); rr[5] = __float_as_uint(rbc<1>(rb)); rr[6] = __float_as_uint(rbc<1>(rc));
+#pragma unroll
+        for (int a = 0; a < 7; ++a) {
+            const float u = u01(rr[a]);
+            const bool sgn = (C.mode == 1) || (C.mode == 3) || (C.mode == 2 && a == 6);
+            act[a] = sgn ? 2.f * u - 1.f : u;
+            if (C.mode == 3) act[a] *= WRENCH_MAX;
+            if (io.act_out && store && a < C.adim) io.act_out[(size_t)ei * C.adim + a] = act[a];
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < 7; ++a) if (a < C.adim) {
+            const float v = io.act[(size_t)ei * C.adim + a];
+            act[a] = (v == v && fabsf(v) <= 3.0e38f) ? v : 0.f;          // a non-finite action component is treated as 0
+        }
+    }
+    }
+    }
     // =================================================================================================================
     // dynamics: bias forces (prefix / suffix sums over the joint lanes) and mass matrix (composite inertia by suffix sums)
     // =================================================================================================================
@@ -436,13 +537,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     });
 
     // ---------------- operational space: Jacobian column per joint lane, row per task lane, Lambda^-1 row per task lane ----------------
-    float Jc[6], Jr[8], Li[6];
+    float Jc[6], Jr[8], Li[6], Xm[6];                                    // Xm: row l of M^-1 J^T
     {
         const f3 jv = cross(Z, xs - P);
         Jc[0] = jv.x; Jc[1] = jv.y; Jc[2] = jv.z; Jc[3] = Z.x; Jc[4] = Z.y; Jc[5] = Z.z;
 #pragma unroll
         for (int a = 0; a < 6; ++a) Jc[a] = jlane ? Jc[a] : 0.f;         // no column for padding / site / idle lanes
-        float Xm[6];                                                     // row l of M^-1 J^T
 #pragma unroll
         for (int a = 0; a < 6; ++a) Xm[a] = row_times_joint<NJ>(Mi, Jc[a]);
         jacobian_rows(xl, gl, Jc, Jr);
@@ -528,11 +628,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 
     // ---------------- smooth acceleration, site-space acceleration of the unconstrained arm ----------------
     const float qs = row_times_joint<NJ>(Mi, tau - bias - JOINT_DAMP * qdj);
+    const float alpha_t = row_times_joint<NJ>(Jr, qs);                   // site acceleration of the unconstrained arm, component of this task lane
+    // ---- everything of the sensor / observation / reward that does not depend on the contact forces.  The split kernel evaluates it while
+    //      the lattice side solves the contacts; the single-wave kernels evaluate it at the same place in the arithmetic, so all variants
+    //      compute the same numbers ----
+    f3 s_rc, s_wwrc, s_nw, s_arm, s_xso;                                 // probe sensor: COM offset, centripetal term, gyroscopic moment, lever arm, site - origin
+    float qe[4], obs[OBS_DIM], pos_err_norm = 0.f, pos_rew = 0.f, ori_err = 0.f, ori_rew = 0.f, vel_rew = 0.f, force_e = 0.f, dforce_e = 0.f;
+    f3 xw, tpw;
+    auto rot_inertia = [&](f3 v) {
+        const f3 l = mk(dot(X, v), dot(Y, v), dot(Z, v));
+        const f3 tt = symmul(M.pI7, l);
+        return X * tt.x + Y * tt.y + Z * tt.z;
+    };
+    auto precompute = [&]() {
+        s_rc = X * M.pcom7[0] + Y * M.pcom7[1] + Z * M.pcom7[2];
+        s_wwrc = cross(w, cross(w, s_rc));
+        s_nw = cross(w, rot_inertia(w));
+        s_xso = xs - P;
+        s_arm = s_rc - s_xso;
+        const int tprev = (MODE == 0) ? t - 1 : 0;
+        const float up = clampf((float)tprev * inv_h + u0, 0.f, 1.f);
+        tpw = ts + (te - ts) * up;
+        xw = mk(xs.x + M.base[0], xs.y + M.base[1], xs.z + M.base[2]);
+        obs[12] = xw.x - tpw.x; obs[13] = xw.y - tpw.y; obs[14] = xw.z - tpw.z;
+        mat2quat_xyzw(sx, sy, sz, qe);
+        difference_quat(qe, M.gquat, obs + 15);                          // xyzw arrays through the wxyz routine (ultrasound.py:390)
+        if constexpr (MODE == 0) {
+            float pe0 = 90.f * (xw.x - tpw.x), pe1 = 90.f * (xw.y - tpw.y);
+            pe0 *= pe0; pe1 *= pe1;
+            pos_err_norm = sqrt_(pe0 * pe0 + pe1 * pe1);
+            pos_rew = 5.f * exp_(-pos_err_norm);
+            const float qc[4] = {qe[3], qe[0], qe[1], qe[2]};
+            ori_err = 0.2f * distance_quat_goal(qc, M.ghat, M.geps);
+            ori_rew = exp_(-ori_err);
+            float ve = 45.f * (vbar - 0.04f); ve *= ve;
+            vel_rew = exp_(-ve);
+            float fe = 0.7f * (fzbar - 5.f); fe *= fe;
+            force_e = 3.f * exp_(-fe);
+            float de = 0.01f * dfz; de *= de;
+            dforce_e = 2.f * exp_(-de);
+        }
+    };
     float W[6] = {0, 0, 0, 0, 0, 0};
     int ncon = 0, overflow = 0, con_shell[MAXC];
 #pragma unroll
     for (int k = 0; k < MAXC; ++k) con_shell[k] = -1;
-    if constexpr (TORSO != 0) {
+    if constexpr (ROLE == 1) {
+        // hand Lambda^-1 (row a from task lane a), alpha = J qs and vs = J qd to the lattice side; take the contact wrench back
+        if (is_task) {
+            const int arow = blk ? 3 + comp : comp;
+            float* mbo = xl + MB_OP;
+            *reinterpret_cast<float4*>(&mbo[arow * 8]) = make_float4(Li[0], Li[1], Li[2], Li[3]);
+            mbo[arow * 8 + 4] = Li[4]; mbo[arow * 8 + 5] = Li[5];
+            mbo[48 + arow] = alpha_t; mbo[54 + arow] = v6;
+        }
+        RSTAMP(3);
+        __syncthreads();                                                 // (2)
+        RSTAMP(4);
+        precompute();                                                    // ... while the lattice side solves the contacts
+        RSTAMP(5);
+        __syncthreads();                                                 // (3) the lattice side has solved the contacts
+        RSTAMP(6);
+        const float4 w0 = *reinterpret_cast<const float4*>(&xl[MB_W]), w1 = *reinterpret_cast<const float4*>(&xl[MB_W + 4]);
+        W[0] = w0.x; W[1] = w0.y; W[2] = w0.z; W[3] = w0.w; W[4] = w1.x; W[5] = w1.y;
+        ncon = __float_as_int(w1.z); overflow = __float_as_int(w1.w);
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) con_shell[k] = __float_as_int(xl[MB_W + 8 + k]);
+    } else if constexpr (TORSO != 0) {
         const int* tb_shell = reinterpret_cast<const int*>(lds + TB_SHELL);
         const int tsim = (t > 0) ? t - 1 : 0;
         float dz, vz, az;
@@ -551,7 +713,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         for (int k = 0; k < MAXC; ++k) { gf[k] = 0.f; cel[k] = (k < nc) ? __float_as_int(EB(GE_CG + k * CG_WORDS + 6)) : 0; }
         if (ncmax > 0) {
             // every contact lane needs Lambda^-1, alpha = J qs and vs = J qd in full: broadcasts from the task lanes
-            const float alpha_t = row_times_joint<NJ>(Jr, qs);
             float alpha[6], vs[6], Lp[21];
             static_for<6>([&](auto Ac) {
                 constexpr int a = decltype(Ac)::value;
@@ -595,31 +756,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     USIM_STAMP(dbg, 12);
 
     // ---------------- constrained arm acceleration, probe torque sensor, Euler step, hand velocity ----------------
+    if constexpr (ROLE != 1) precompute();
     float tq[3];
     f3 hv;
     {
-        float z0 = 0.f;
+        // qacc = qs + M^-1 J^T W and the site acceleration J qacc = alpha + Lambda^-1 W through the operators that are already there
+        float qacc = qs, aq_t = alpha_t;
+        if (TORSO) {
 #pragma unroll
-        for (int a = 0; a < 6; ++a) z0 = fmaf(Jc[a], W[a], z0);
-        const float qacc = qs + (TORSO ? row_times_joint<NJ>(Mi, z0) : 0.f);
+            for (int a = 0; a < 6; ++a) { qacc = fmaf(Xm[a], W[a], qacc); aq_t = fmaf(Li[a], W[a], aq_t); }
+        }
         // link accelerations from the site Jacobian: alpha = alpha_bias + Jw qacc, a(o) = a_bias + Jv qacc - (Jw qacc) x (x - o).  Every lane
         // evaluates the sensor on its own link's registers; the last link's lane holds the probe's.
-        const float aq_t = row_times_joint<NJ>(Jr, qacc);
         float aq[6];
         static_for<6>([&](auto Ac) { constexpr int a = decltype(Ac)::value; aq[a] = rbc<TASK_LANE[a]>(aq_t); });
         const f3 alq = mk(aq[3], aq[4], aq[5]);
         const f3 alt = al + alq;
-        const f3 a7 = ao + mk(aq[0], aq[1], aq[2]) - cross(alq, xs - P);
-        const f3 rc = X * M.pcom7[0] + Y * M.pcom7[1] + Z * M.pcom7[2];
-        const f3 ac = a7 + cross(alt, rc) + cross(w, cross(w, rc));
-        auto rot_inertia = [&](f3 v) {
-            const f3 l = mk(dot(X, v), dot(Y, v), dot(Z, v));
-            const f3 tt = symmul(M.pI7, l);
-            return X * tt.x + Y * tt.y + Z * tt.z;
-        };
-        const f3 N = rot_inertia(alt) + cross(w, rot_inertia(w));
+        const f3 a7 = ao + mk(aq[0], aq[1], aq[2]) - cross(alq, s_xso);
+        const f3 ac = a7 + cross(alt, s_rc) + s_wwrc;
+        const f3 N = rot_inertia(alt) + s_nw;
         const f3 Fp = ac * PROBE_MASS;
-        const f3 tw = N + cross(P + rc - xs, Fp) - mk(W[3], W[4], W[5]);
+        const f3 tw = N + cross(s_arm, Fp) - mk(W[3], W[4], W[5]);
         tq[0] = rbc<NJ - 1>(dot(sx, tw)); tq[1] = rbc<NJ - 1>(dot(sy, tw)); tq[2] = rbc<NJ - 1>(dot(sz, tw));
         USIM_STAMP(dbg, 13);
         hv = mk(0, 0, 0);
@@ -639,21 +796,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     USIM_STAMP(dbg, 14);
 
     // ---------------- observation (ultrasound.py:363-401), reward (:230-269), bookkeeping (:528-546), termination (:635-670) ----------------
-    float obs[OBS_DIM];
     bool done = false;
     {
-        const int tprev = (MODE == 0) ? t - 1 : 0;
-        const float up = clampf((float)tprev * inv_h + u0, 0.f, 1.f);
-        const f3 tpw = ts + (te - ts) * up;
         if (MODE == 1) fzbar = W[2];                                     // ultrasound.py:477
         obs[0] = W[0]; obs[1] = W[1]; obs[2] = W[2];
         obs[3] = tq[0]; obs[4] = tq[1]; obs[5] = tq[2];
         obs[6] = hv.x; obs[7] = hv.y; obs[8] = hv.z;
         obs[9] = fzbar - 5.0f; obs[10] = dfz - 0.0f; obs[11] = vbar - 0.04f;
-        const f3 xw = mk(xs.x + M.base[0], xs.y + M.base[1], xs.z + M.base[2]);
-        obs[12] = xw.x - tpw.x; obs[13] = xw.y - tpw.y; obs[14] = xw.z - tpw.z;
-        float qe[4]; mat2quat_xyzw(sx, sy, sz, qe);
-        difference_quat(qe, M.gquat, obs + 15);                          // xyzw arrays through the wxyz routine (ultrasound.py:390)
         if constexpr (MODE == 1) {
             if (overflow) status |= 1;
             if (refill) {
@@ -676,19 +825,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         } else {
         const bool contact = ncon > 0;
         if (contact) touched = 1;
-        float pe0 = 90.f * (xw.x - tpw.x), pe1 = 90.f * (xw.y - tpw.y);
-        pe0 *= pe0; pe1 *= pe1;
-        const float pos_err_norm = sqrt_(pe0 * pe0 + pe1 * pe1);
-        const float pos_rew = 5.f * exp_(-pos_err_norm);
-        const float qc[4] = {qe[3], qe[0], qe[1], qe[2]};
-        const float ori_err = 0.2f * distance_quat_goal(qc, M.ghat, M.geps);
-        const float ori_rew = exp_(-ori_err);
-        float ve = 45.f * (vbar - 0.04f); ve *= ve;
-        const float vel_rew = exp_(-ve);
-        float fe = 0.7f * (fzbar - 5.f); fe *= fe;
-        const float force_rew = contact ? 3.f * exp_(-fe) : 0.f;
-        float de = 0.01f * dfz; de *= de;
-        const float dforce_rew = contact ? 2.f * exp_(-de) : 0.f;
+        const float force_rew = contact ? force_e : 0.f, dforce_rew = contact ? dforce_e : 0.f;
         float reward = pos_rew + ori_rew + vel_rew + force_rew + dforce_rew;
         done = t >= C.horizon;
         const float hvn = sqrt_(dot(hv, hv));
@@ -753,6 +890,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         }
     }
 
+    if constexpr (ROLE == 1) { RSTAMP(7); __syncthreads(); RSTAMP(8); }   // (4) the lattice side has stored the integrated lattice
     if (MODE == 0 && need) {
         // ================= auto-reset: adopt the initial state prepared in the reset bank and queue the slot for refill =================
         episode += 1;
@@ -799,10 +937,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         }
     }
     USIM_STAMP(dbg, 16);
+    if constexpr (ROLE == 1) RSTAMP(9);
+#undef RSTAMP
 #undef LAT
 #undef EB
 #undef BK
 #undef BKI
+}
+
+template <int TORSO, int OCC, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void usim_step16_kernel(const DevModel M, const DevCfg C, float* __restrict__ st, int n, int npad,
+                                                                                                          const DevIO io, int flags, long long rstep) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    step16_body<TORSO, MODE, 0, 256>(lds, M, C, st, n, npad, io, flags, rstep);
+}
+
+// soft-torso step with two waves per quad of environments: waves 0-3 of the workgroup run the arm side, waves 4-7 the lattice / contact side
+// (wave w and wave w + 4 land on the same SIMD and fill each other's stalls: at 4096 envs/GPU a single wave issues only ~55 % of its cycles)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void usim_step32_kernel(const DevModel M, const DevCfg C, float* __restrict__ st, int n, int npad,
+                                                                                                       const DevIO io, int flags, long long rstep) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (threadIdx.x < 256) step16_body<1, 0, 1, 512>(lds, M, C, st, n, npad, io, flags, rstep);
+    else step16_body<1, 0, 2, 512>(lds, M, C, st, n, npad, io, flags, rstep);
 }
 
 }  // namespace usim

@@ -190,6 +190,12 @@ class UltrasoundVecEnv:
                 prev = t[k]
         return out
 
+    def profile_step_raw(self, step, n=48):
+        """Diagnostics (profiling build): the raw shader-clock stamps of one step (see usim_profile_step in csrc/usim_api.hip)."""
+        ticks = (C.c_uint64 * n)()
+        self._check(self.lib.usim_profile_step(self._handle, C.byref(self._io), int(step), ticks, n))
+        return list(ticks)
+
     def alloc_block(self, nsteps, with_actions=True):
         """Device tensors of one rollout block: obs [T,n,19], act [T,n,A], rew [T,n], done [T,n] (uint8)."""
         n, T = self.num_envs, int(nsteps)

@@ -12,7 +12,7 @@ spin.spin_launch.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 sink = torch.zeros(1, dtype=torch.int32, device="cuda")
 side = torch.cuda.Stream()
 K = 256
-for lpe, occ in ((16, 1), (16, 2), (8, 0)):
+for lpe, occ in ((32, 0), (16, 1), (16, 2), (8, 0)):
     env = usim.UltrasoundVecEnv(4096, torso="soft", lanes_per_env=lpe, waves_per_simd=occ, **usim.default_robosuite_kwargs())
     env.reset_tensor(); env.rollout_random(0, 128); torch.cuda.synchronize()
     for blocks in (0, 4, 16, 32, 64):

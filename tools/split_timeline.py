@@ -1,0 +1,21 @@
+"""Timeline of the split (two-wave) soft-torso step: shader-clock stamps of the arm wave and the lattice wave of workgroup 0 at their barriers."""
+import importlib, os, subprocess, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+PROF = ROOT / "robotic-ultrasound-imaging_amd" / "lib" / "libusim_prof.so"
+subprocess.run(["make", "-s", "-C", str(ROOT / "robotic-ultrasound-imaging_amd" / "csrc"), "prof"], check=True)
+os.environ["USIM_LIB"] = str(PROF)
+sys.path.insert(0, str(ROOT))
+import numpy as np, torch
+usim = importlib.import_module("robotic-ultrasound-imaging_amd")
+env = usim.UltrasoundVecEnv(4096, torso="soft", lanes_per_env=32, **usim.default_robosuite_kwargs())
+env.reset_tensor(); env.rollout_random(0, 200); torch.cuda.synchronize()
+rows = np.array([env.profile_step_raw(200 + k) for k in range(50)], dtype=np.float64)
+t0 = rows[:, 20:21]
+names_a = ["start", "fk done", "barrier1 passed", "op-space + controller done", "barrier2 passed", "precompute done", "barrier3 passed (contacts solved)", "finish done", "barrier4 passed", "end"]
+names_b = ["start", "stage+rhs done", "barrier1 passed", "solve+collide done", "barrier2 passed", "contact solve done", "barrier3 passed", "integrate done", "barrier4 passed"]
+for base, names, title in ((20, names_a, "arm wave"), (30, names_b, "lattice wave")):
+    print("==", title)
+    for i, nm in enumerate(names):
+        v = rows[:, base + i] - t0[:, 0]
+        print(f"   {nm:36s} {np.median(v):9.0f}")
