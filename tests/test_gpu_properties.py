@@ -291,3 +291,26 @@ def test_two_live_handles_with_different_torso_shapes_do_not_share_tables(usim):
     assert torch.equal(got_box, ref_box) and torch.equal(got_box_con, ref_box_con) and torch.equal(got_box2, ref_box2)
     assert torch.equal(got_cyl, ref_cyl) and torch.equal(got_cyl_con, ref_cyl_con)
     box.close(); cyl.close()
+
+
+def test_split_kernel_equals_the_single_wave_kernel_bit_for_bit(usim):
+    """lanes_per_env = 32 (arm side and lattice / contact side of a quad of environments in two waves, mailboxes in LDS; the automatic choice
+    up to 4096 envs) and lanes_per_env = 16 (one wave does both) are the same arithmetic: identical bits over 300 steps with auto-resets,
+    both register budgets of the 16-lane kernel included"""
+    envs = [_env(usim, 1000, lanes_per_env=32), _env(usim, 1000, lanes_per_env=16, waves_per_simd=1), _env(usim, 1000, lanes_per_env=16, waves_per_simd=2)]
+    obs0 = [e.reset_tensor().clone() for e in envs]
+    assert torch.equal(obs0[0], obs0[1]) and torch.equal(obs0[0], obs0[2])
+    ended = 0
+    for k in range(300):
+        act = envs[0].random_actions_tensor(k).clone()
+        res = [[x.clone() for x in e.step_tensor(act)] for e in envs]
+        for r, e in zip(res[1:], envs[1:]):
+            assert all(torch.equal(a, b) for a, b in zip(res[0], r)) and torch.equal(envs[0].contacts, e.contacts), k
+        ended += int(res[0][2].sum())
+    assert ended > 100
+    s0 = envs[0].get_state()
+    for e in envs[1:]:
+        s = e.get_state()
+        assert all(np.array_equal(s0[key], s[key]) for key in s0)
+    for e in envs:
+        e.close()

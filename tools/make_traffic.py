@@ -8,7 +8,8 @@ def mean_kb(root, sub, counter):
         with open(f) as fh:
             for r in csv.DictReader(fh):
                 name = r["Kernel_Name"].replace(" ", "")
-                is_step = "usim_step16_kernel" in name or ("usim_step_kernel" in name and name.split(">(")[0].endswith(",0"))
+                # step launches: the split kernel, or MODE 0 (last template argument) of the 16-lane / round-1 kernel templates
+                is_step = "usim_step32_kernel" in name or (("usim_step16_kernel" in name or "usim_step_kernel" in name) and name.split(">(")[0].endswith(",0"))
                 if is_step and r["Counter_Name"] == counter:
                     vals.append(float(r["Counter_Value"]))
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
