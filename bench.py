@@ -183,7 +183,7 @@ def main():
                          "algorithmic_bytes_per_launch": ALGO_BYTES[args.workload] * n, "algorithmic_bytes_per_env_step": ALGO_BYTES[args.workload],
                          "avg_kernel_us": avg_kernel_s * 1e6, "kernel": {32: "usim_step32_kernel", 16: "usim_step16_kernel"}.get(lanes, "usim_step_kernel"),
                          "valu_fp32_tflops": valu_tflops, "valu_frac": valu_tflops / FP32_VALU_PEAK_TFLOPS,
-                         "note": "kernel is FP32-VALU/latency bound at 4096 envs (one wave per SIMD), not HBM bound; see DESIGN.md section 5"},
+                         "note": "kernel is FP32-VALU/latency bound at 4096 envs (one or two waves per SIMD, serial per-environment chain), not HBM bound; see DESIGN.md section 5"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, n)
