@@ -26,6 +26,7 @@
 // Per-environment state is read and written once per step as rows of the SoA state block in HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "usim_device.h"
 #include "usim_devmath.h"
 
@@ -409,10 +410,12 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
     //      ascending order.  The owner relaxes its three rows in order (normal, t1, t2; the earlier rows' updates enter
     //      through its own block), projects on the cone and shares the three force increments; every lane then moves its
     //      residuals by its block for that contact. ----
-    for (int it = 0; it < C.pgs_iters; ++it) {
+    // (one straight-line instantiation of the sweep per wave-uniform contact count: no test per visit)
+    auto sweeps = [&](auto NCM_) {
+        constexpr int NCM = decltype(NCM_)::value;
+        for (int it = 0; it < C.pgs_iters; ++it) {
 #pragma unroll
-        for (int k = 0; k < MAXC; ++k) {
-            if (k < ncmax) {
+            for (int k = 0; k < NCM; ++k) {
                 // every lane runs the solve on its own rows (no divergence); only lane k's increments are shared and kept
                 const float f0n = fmaxf(fmaf(-cres[0], invD[0], f[0]), 0.f);
                 float d0 = f0n - f[0];
@@ -431,27 +434,55 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
                 for (int d = 0; d < 3; ++d) cres[d] = fmaf(B[k][d][2], d2, fmaf(B[k][d][1], d1, fmaf(B[k][d][0], d0, cres[d])));
             }
         }
+    };
+    switch (ncmax) {
+        case 1: sweeps(std::integral_constant<int, 1>{}); break;
+        case 2: sweeps(std::integral_constant<int, 2>{}); break;
+        case 3: sweeps(std::integral_constant<int, 3>{}); break;
+        case 4: sweeps(std::integral_constant<int, 4>{}); break;
+        case 5: sweeps(std::integral_constant<int, 5>{}); break;
+        case 6: sweeps(std::integral_constant<int, 6>{}); break;
+        case 7: sweeps(std::integral_constant<int, 7>{}); break;
+        default: sweeps(std::integral_constant<int, 8>{}); break;
     }
     USIM_STAMP(dbg, 10);
-    // ---- contact wrench on the site and impulse along each element axis: the first MAXC lanes publish (lanes without a
-    //      contact hold w = g = f = 0, i.e. publish zeros), everyone sums the slots the wave uses ----
-    if (gl < MAXC) {
-        f3 Fw = mk(w[0][0] * f[0] + w[1][0] * f[1] + w[2][0] * f[2], w[0][1] * f[0] + w[1][1] * f[1] + w[2][1] * f[2],
-                   w[0][2] * f[0] + w[1][2] * f[1] + w[2][2] * f[2]);
-        f3 Tw = mk(w[0][3] * f[0] + w[1][3] * f[1] + w[2][3] * f[2], w[0][4] * f[0] + w[1][4] * f[1] + w[2][4] * f[2],
-                   w[0][5] * f[0] + w[1][5] * f[1] + w[2][5] * f[2]);
-        const int b = GE_WS + gl * 8;
-        EB(b + 0) = Fw.x; EB(b + 1) = Fw.y; EB(b + 2) = Fw.z; EB(b + 3) = Tw.x; EB(b + 4) = Tw.y; EB(b + 5) = Tw.z;
-        EB(b + 6) = (g[0] * f[0] + g[1] * f[1] + g[2] * f[2]) * (1.0f / ELEM_MASS);
-    }
-    group_sync();
+    // ---- contact wrench on the site and impulse along each element axis (lanes without a contact hold w = g = f = 0, i.e. contribute
+    //      zeros) ----
+    {
+        const float Fw[6] = {w[0][0] * f[0] + w[1][0] * f[1] + w[2][0] * f[2], w[0][1] * f[0] + w[1][1] * f[1] + w[2][1] * f[2],
+                             w[0][2] * f[0] + w[1][2] * f[1] + w[2][2] * f[2], w[0][3] * f[0] + w[1][3] * f[1] + w[2][3] * f[2],
+                             w[0][4] * f[0] + w[1][4] * f[1] + w[2][4] * f[2], w[0][5] * f[0] + w[1][5] * f[1] + w[2][5] * f[2]};
+        const float gfo = (g[0] * f[0] + g[1] * f[1] + g[2] * f[2]) * (1.0f / ELEM_MASS);
+        if constexpr (G == 16) {
+            // sixteen lanes per environment = one DPP row: the sum over the eight contact lanes is a shifted-add reduction (lanes 8-15 carry
+            // zeros as well), the per-contact impulses are row broadcasts
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
-        if (k < ncmax) {
-            const int b = GE_WS + k * 8;
+            for (int a = 0; a < 6; ++a) {
+                float v = (gl < MAXC) ? Fw[a] : 0.f;
+                v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));      // row_shr:1
+                v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));      // row_shr:2
+                v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));      // row_shr:4
+                W[a] += group_bcast<G>(v, 7);
+            }
 #pragma unroll
-            for (int a = 0; a < 6; ++a) W[a] += EB(b + a);
-            gf[k] = EB(b + 6);
+            for (int k = 0; k < MAXC; ++k) if (k < ncmax) gf[k] = group_bcast<G>(gfo, k);
+        } else {
+            if (gl < MAXC) {
+                const int b = GE_WS + gl * 8;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) EB(b + a) = Fw[a];
+                EB(b + 6) = gfo;
+            }
+            group_sync();
+#pragma unroll
+            for (int k = 0; k < MAXC; ++k) {
+                if (k < ncmax) {
+                    const int b = GE_WS + k * 8;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) W[a] += EB(b + a);
+                    gf[k] = EB(b + 6);
+                }
+            }
         }
     }
 #undef EB
