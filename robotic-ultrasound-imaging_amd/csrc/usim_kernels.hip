@@ -45,7 +45,7 @@ constexpr int TB_TOTAL = TB_ARM + A16_LANES * AT_STRIDE;
 
 // per-environment LDS block (word offsets); GE_X must stay 16-byte aligned
 constexpr int GE_X = 0;                               // rhs[100] of the lattice solve
-constexpr int GE_S = 100;                             // s[99]
+constexpr int GE_S = 100;                             // (free: element positions stay in their owners' registers)
 constexpr int GE_SD = 200;                            // sdot[99]
 constexpr int GE_A = 300;                             // lattice acceleration a~[99]
 constexpr int GE_U = 300;                             // zero-bordered 11 x 13 grid of u = k_t s + b_t sdot; dead before a~ and the contact records land
@@ -151,7 +151,7 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                         up[i] = (ix + 1) * (LAT_NC + 2) + iz + 1;
                         const float se = live ? s_pre[i] : 0.f, sde = live ? sd_pre[i] : 0.f;
                         u_own[i] = fmaf(kten, se, bten * sde);
-                        if (e < N_TOP) { EBF(GE_S + e) = se; EBF(GE_SD + e) = sde; EBF(GE_U + up[i]) = u_own[i]; }
+                        if (e < N_TOP) { EBF(GE_SD + e) = sde; EBF(GE_U + up[i]) = u_own[i]; }     // (s itself stays in the owner's registers)
                     }
                     group_sync();
                                     // ---- lattice right-hand side: a_s + w_fix aref_fix + w_ten sum_j aref_ij
@@ -184,7 +184,7 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                     auto collide_round = [&](const int i) {
                         const int eraw = i * G + gl, e = eraw < N_TOP ? eraw : N_TOP - 1;
                         const f3 ax = mk(lds[TB_AXIS + 3 * e], lds[TB_AXIS + 3 * e + 1], lds[TB_AXIS + 3 * e + 2]);
-                        const float se = EBF(GE_S + e);
+                        const float se = live ? s_pre[i] : 0.f;                        // element i G + gl is this lane's own
                         // element collision geometry = the cap sphere (centre `tip`, radius ELEM_R); DESIGN.md section 2
                         const f3 tip = mk(M.torso[0] + lds[TB_POS + 3 * e], M.torso[1] + lds[TB_POS + 3 * e + 1], M.torso[2] + lds[TB_POS + 3 * e + 2] + dz) + ax * (se - ELEM_R);
                         const f3 c1 = madd(p1, d1, clampf(dot(d1, tip - p1) * inv_dd, 0.f, 1.f));      // closest point of the probe segment
@@ -929,8 +929,8 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                         if (e >= N_TOP) continue;
                         float sdn = 0.f, sn = 0.f;
                         if (pass == 0) {
-                            sdn = EB(GE_SD + e) + dt * acc_e[i];
-                            sn = EB(GE_S + e) + dt * sdn;
+                            sdn = sd_pre[i] + dt * acc_e[i];
+                            sn = s_pre[i] + dt * sdn;
                         }
                         if (valid && (pass == 0 || !refill)) { LAT(LAT_SD + e) = sdn; LAT(LAT_S + e) = sn; }
                     }

@@ -322,8 +322,8 @@ DI void step16_body(float* lds, const DevModel& M, const DevCfg& C, float* __res
             for (int i = 0; i < NE; ++i) {
                 const int e = gl + i * G;
                 if (e >= N_TOP) continue;
-                const float sdn = EB(GE_SD + e) + dt * acc_e[i];
-                const float sn = EB(GE_S + e) + dt * sdn;
+                const float sdn = sd_pre[i] + dt * acc_e[i];
+                const float sn = s_pre[i] + dt * sdn;
                 if (valid) { LAT(LAT_SD + e) = sdn; LAT(LAT_S + e) = sn; }
             }
         }
@@ -745,8 +745,8 @@ DI void step16_body(float* lds, const DevModel& M, const DevCfg& C, float* __res
             for (int i = 0; i < NE; ++i) {
                 const int e = gl + i * G;
                 if (e >= N_TOP) continue;
-                const float sdn = EB(GE_SD + e) + dt * acc_e[i];
-                const float sn = EB(GE_S + e) + dt * sdn;
+                const float sdn = sd_pre[i] + dt * acc_e[i];
+                const float sn = s_pre[i] + dt * sdn;
                 if (valid) { LAT(LAT_SD + e) = sdn; LAT(LAT_S + e) = sn; }
             }
         }
