@@ -1,6 +1,6 @@
 """One-off record run (by hand, on the GPU box): the parity check of test_gpu_parity.py at BASELINE's full size -- 4096 environments x
 200 steps -- for every controller mode and both torso models, plus the randomised configuration; prints the razor-edge counts.
-Lives under tests/ because it uses the oracle.   python tests/gpu_parity_fullsize.py > profiles/r01/parity_fullsize.txt"""
+Lives under tests/ because it uses the oracle.   python tests/gpu_parity_fullsize.py > profiles/<round>/parity_fullsize.txt"""
 import importlib, os, sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -14,6 +14,10 @@ for torso in ("rigid", "soft"):
         explained = T._run_parity(usim, 4096, 200, torso, mode, omp=True)
         print(f"{torso:5s} {mode:10s} 4096 envs x 200 steps: state within {T.STATE_RTOL:g} rel, done flags / contact indices bit-exact; "
               f"{explained} threshold decisions within rounding of the threshold in the oracle itself ({time.time() - t0:.0f} s)", flush=True)
+for torso in ("rigid", "soft"):
+    t0 = time.time()
+    explained = T._run_parity(usim, 4096, 200, torso, "tracking", omp=True, robot="UR5e")
+    print(f"{torso:5s} tracking   UR5e, 4096 envs x 200 steps: {explained} razor-edge decisions ({time.time() - t0:.0f} s)", flush=True)
 t0 = time.time()
 explained = T._run_parity(usim, 4096, 200, "soft", "tracking", omp=True, friction_randomization=1, elem_friction=0.0, probe_friction=0.3)
 print(f"soft  tracking   randomised friction/stiffness/damping, 4096 x 200: {explained} razor-edge decisions ({time.time() - t0:.0f} s)")
