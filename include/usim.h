@@ -151,8 +151,10 @@ int usim_get_state(usim_handle* h, float* scalars, float* lattice);
 int usim_set_state(usim_handle* h, const float* scalars, const float* lattice);
 
 /* Diagnostics: runs one step (in-kernel synthetic actions of `step`, auto-reset on) on the default stream, blocks, and returns
- * 17 shader-clock stamps taken by wave 0 of workgroup 0 at the phase boundaries of the step kernel.  Only the
- * profiling build of the library (make -C csrc prof) carries the stamps; the production build returns USIM_ERR_UNSUPPORTED. */
+ * shader-clock stamps taken in workgroup 0: ticks[0..16] by wave 0 at the phase boundaries of the single-wave step
+ * kernels, ticks[20..29] / ticks[30..38] by the arm wave / the lattice wave of the split kernel at their barriers (min(max_ticks, 64) words
+ * are written, max_ticks >= 17).  Only the profiling build of the library (make -C csrc prof) carries the stamps; the production build
+ * returns USIM_ERR_UNSUPPORTED. */
 int usim_profile_step(usim_handle* h, const usim_step_io* io, int64_t step, uint64_t* ticks, int max_ticks);
 
 const char* usim_strerror(int status);

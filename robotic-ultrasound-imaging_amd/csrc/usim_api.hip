@@ -544,6 +544,6 @@ const char* usim_strerror(int status) {
     }
 }
 const char* usim_last_hip_error(const usim_handle* h) { return h ? h->hip_err.c_str() : ""; }
-const char* usim_version(void) { return "usim 0.1 (gfx950)"; }
+const char* usim_version(void) { return "usim 0.2 (gfx950)"; }
 
 }  // extern "C"
