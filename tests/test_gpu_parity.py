@@ -24,7 +24,8 @@ def _mk(usim, n, torso, mode, seed=3, omp=False, robot="Panda", **extra):
     kw = usim.default_robosuite_kwargs()
     kw["controller_configs"] = dict(kw["controller_configs"], impedance_mode=mode)
     kw["robots"] = robot
-    env = usim.UltrasoundVecEnv(n, device="cuda:0", seed=seed, torso=torso, **kw, **extra)
+    kw.update(extra)                                   # options that exist on both sides under the same name
+    env = usim.UltrasoundVecEnv(n, device="cuda:0", seed=seed, torso=torso, **kw)
     ora = Oracle(n, precision="f64", omp=omp, mode=mode, torso="top" if torso == "soft" else "none", seed=seed, robot=robot, **extra)
     return env, ora
 
@@ -288,3 +289,38 @@ def test_reset_bank_ring_wraps(usim):
     sg, so = env.get_state(), ora.get_state()
     assert np.array_equal(sg["episode"], so["episode"]) and np.allclose(sg["traj_start"], so["traj_start"], atol=1e-6)
     env.close()
+
+
+@pytest.mark.parametrize("torso", ["soft", "rigid"])
+def test_masked_reset_leaves_the_other_environments_alone(usim, torso):
+    """env.reset() of a subset (mask): the selected environments start their next episode exactly as the oracle's do, the others keep
+    stepping as if nothing had happened -- also when a group of lanes in a wave resets next to one that does not (67 environments: ragged
+    last workgroup), and with the deterministic trajectory option (ultrasound.py:762-764)"""
+    n = 67
+    env, ora = _mk(usim, n, torso, "tracking", deterministic_trajectory=1)
+    twin, _ = _mk(usim, n, torso, "tracking", deterministic_trajectory=1)                  # never reset in the middle
+    env.reset(); ora.reset(); twin.reset()
+    sg = env.get_state()
+    assert np.allclose(sg["traj_start"], [0.062, -0.020, 0.896], atol=1e-6) and np.allclose(sg["traj_end"], [-0.032, -0.075, 0.896], atol=1e-6)
+    kw_noreset = dict(auto_reset=False)
+    for k in range(12):
+        a = ora.random_actions(k)
+        ora.step(a, auto_reset=False)
+        env.step_tensor(torch.as_tensor(a, dtype=torch.float32, device=env.device), **kw_noreset)
+        twin.step_tensor(torch.as_tensor(a, dtype=torch.float32, device=env.device), **kw_noreset)
+    mask = (np.arange(n) % 3 == 0) | (np.arange(n) >= 62)
+    og = env.reset_tensor(mask).cpu().numpy().copy()
+    oo = ora.reset(mask)
+    assert np.allclose(og[mask][:, 12:19], oo[mask][:, 12:19], atol=2e-6) and np.allclose(og[mask][:, :6], oo[mask][:, :6], atol=5e-3, rtol=1e-3)
+    sg, so, st = env.get_state(), ora.get_state(), twin.get_state()
+    assert np.array_equal(sg["episode"][mask], so["episode"][mask]) and np.all(sg["t"][mask] == 0) and np.abs(sg["q"][mask] - so["q"][mask]).max() < 5e-6
+    for key in sg:                                                                         # untouched environments: bit for bit the twin's
+        assert np.array_equal(np.asarray(sg[key])[~mask], np.asarray(st[key])[~mask]), key
+    for k in range(12, 30):
+        a = ora.random_actions(k)
+        obs_o = ora.step(a, auto_reset=False)[0]
+        obs_g = env.step_tensor(torch.as_tensor(a, dtype=torch.float32, device=env.device), **kw_noreset)[0].cpu().numpy()
+        obs_t = twin.step_tensor(torch.as_tensor(a, dtype=torch.float32, device=env.device), **kw_noreset)[0].cpu().numpy()
+        assert np.array_equal(obs_g[~mask], obs_t[~mask])
+        assert np.abs(obs_g[:, 12:19] - obs_o[:, 12:19]).max() < 2e-5
+    env.close(); twin.close()
