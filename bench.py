@@ -95,13 +95,13 @@ def main():
     n = args.envs_per_gpu
     extra = {"friction_randomization": 1} if args.randomize else {}
     with_gather = use_dist and not args.no_gather
-    if with_gather and args.workload == "soft" and args.lanes_per_env == 0:
-        # At 4096 envs the step kernel holds one wave on every SIMD of the chip.  With the register budget of one wave per SIMD the
-        # resident workgroups of the overlapped all-gather push part of every step into a second round (measured with a stand-in
-        # kernel of RCCL's footprint, tools/gpu_interference.py: 21.8 -> 33-36 us/step); with the budget of two waves per SIMD the
-        # displaced workgroups double up on other CUs instead (22.7 us alone, 25.7-28.7 us next to the stand-in).
-        extra["waves_per_simd"] = 2
-    elif args.lanes_per_env:
+    # N > 1, soft torso: the resident workgroups of the overlapped all-gather push part of every step of the split kernel (and of the
+    # one-wave-per-SIMD budget) into a second round (tools/gpu_interference.py: 19.9 -> 30 us/step), the two-waves-per-SIMD 16-lane build
+    # lets the displaced workgroups double up on other CUs (22.7 -> 26-29 us).  The mappings compute the same bits, so every block starts
+    # with the robust build for as long as the previous gather took (measured with events on the gather's stream) and finishes with the
+    # split kernel.
+    adaptive = with_gather and args.workload == "soft" and args.lanes_per_env == 0 and n <= 4096
+    if args.lanes_per_env:
         extra["lanes_per_env"] = args.lanes_per_env
     env = usim.UltrasoundVecEnv(n, device=device, seed=3, env_offset=rank * n, torso=args.workload, **extra, **usim.default_robosuite_kwargs())
     T = max(1, min(args.block, args.steps))
@@ -116,6 +116,15 @@ def main():
         env.rollout_random(step, k, blocks[0]); step += k; done_w += k
     if gather is not None:
         gather.gather_async(blocks[0]); gather.wait()
+
+    def slice_block(blk, lo, hi):
+        return {key: t[lo:hi] for key, t in blk.items()}
+
+    robust_ms = 0.023
+    if adaptive:                                           # step time of the robust build on this box (untimed)
+        env.set_mapping(16, 2)
+        robust_ms = env.time_steps(step, T, blocks[1]) / T; step += T
+        env.set_mapping(32, 0)
 
     def sync():
         torch.cuda.synchronize(device)
@@ -134,7 +143,14 @@ def main():
         k = min(T, args.steps - done_s)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        env.rollout_random(step, k, blocks[b])             # with the gather: simulate block b while block b^1 is in flight
+        m = 0
+        if adaptive:                                       # steps that run next to the gather of the previous block
+            m = k if gather.last_ms is None else min(k, int(gather.last_ms * 1.25 / robust_ms) + 1)
+            env.set_mapping(16, 2)
+            env.rollout_random(step, m, slice_block(blocks[b], 0, m))
+            env.set_mapping(32, 0)
+        if k > m:
+            env.rollout_random(step + m, k - m, slice_block(blocks[b], m, k))      # with the gather: simulate block b while block b^1 is in flight
         e1.record()
         evs.append((e0, e1))
         if gather is not None:
@@ -177,7 +193,8 @@ def main():
             "config": {"workload": WORKLOAD_NAME[args.workload], "envs_per_gpu": n, "global_envs": n * world,
                        "controller": "OSC_POSE impedance_mode=tracking", "rollout_block": T, "domain_randomisation": "stiffness+damping" + ("+friction" if args.randomize else ""),
                        "parallelism": f"env-shard x{world}" + (" + RCCL all-gather of transition blocks" if gather is not None else ""),
-                       "lanes_per_env": lanes, "waves_per_simd": int(extra.get("waves_per_simd", 0)) or "auto"},
+                       "lanes_per_env": lanes if not adaptive else "32, and 16 (two waves per SIMD) while the previous block is gathered",
+                       "waves_per_simd": int(extra.get("waves_per_simd", 0)) or "auto"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": f"{tfile.relative_to(ROOT)} (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch)" if traffic else None,
                          "algorithmic_bytes_per_launch": ALGO_BYTES[args.workload] * n, "algorithmic_bytes_per_env_step": ALGO_BYTES[args.workload],

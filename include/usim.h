@@ -113,6 +113,12 @@ int usim_default_config(usim_config* c);
 int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** out);
 void usim_destroy(usim_handle* h);
 
+/* Switch the kernel mapping of a live soft-torso handle between lanes_per_env 32 (split kernel) and 16 (waves_per_simd 0 / 1 / 2 as in
+ * usim_config).  The mappings compute the same bits, so a rollout may change between them at any step -- e.g. the two-waves-per-SIMD
+ * 16-lane build while a collective's workgroups are resident, the split kernel otherwise (bench.py, N > 1).  Takes effect with the next
+ * call that enqueues work. */
+int usim_set_mapping(usim_handle* h, int lanes_per_env, int waves_per_simd);
+
 int usim_num_envs(const usim_handle* h);
 int usim_action_dim(const usim_handle* h);     /* GymWrapper.action_space.shape[0] */
 int usim_num_elements(const usim_handle* h);   /* dynamic torso elements per env (0 or 99) */

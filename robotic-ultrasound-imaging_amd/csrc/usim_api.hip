@@ -343,6 +343,13 @@ void usim_destroy(usim_handle* h) {
     delete h;
 }
 
+int usim_set_mapping(usim_handle* h, int lanes_per_env, int waves_per_simd) {
+    if (!h || !h->n_el || h->lpe == 8 || (lanes_per_env != 16 && lanes_per_env != 32) || waves_per_simd < 0 || waves_per_simd > 2) return USIM_ERR_INVALID;
+    h->lpe = lanes_per_env;
+    h->occ = waves_per_simd ? waves_per_simd : (h->n <= 4096 ? 1 : 2);
+    return USIM_OK;
+}
+
 int usim_num_envs(const usim_handle* h) { return h ? h->n : USIM_ERR_INVALID; }
 int usim_action_dim(const usim_handle* h) { return h ? h->adim : USIM_ERR_INVALID; }
 int usim_num_elements(const usim_handle* h) { return h ? h->n_el : USIM_ERR_INVALID; }

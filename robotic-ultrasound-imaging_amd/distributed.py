@@ -51,6 +51,8 @@ class RolloutGather:
         self.device = device
         self._stream = torch.cuda.Stream(device=device) if (device is not None and torch.device(device).type == "cuda") else None
         self._pending = None
+        self.last_ms = None           # device time of the most recent finished gather (side stream), None until one has finished
+        self._timings = []            # (start, end) events of gathers whose duration has not been read yet
 
     def gather(self, block):
         packed = pack_block(block)
@@ -68,9 +70,12 @@ class RolloutGather:
         cur = torch.cuda.current_stream(self.device)
         self._stream.wait_stream(cur)                 # the block must be complete before it is packed
         with torch.cuda.stream(self._stream):
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record(self._stream)
             out = self.gather(block)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=True)
             ev.record(self._stream)
+        self._timings.append((ev0, ev))
         for t in block.values():
             t.record_stream(self._stream)
         self._pending = (out, ev)
@@ -81,6 +86,11 @@ class RolloutGather:
         out, ev = self._pending
         self._pending = None
         if ev is not None:
+            # the host runs ahead of the device: read the durations of whichever earlier gathers have finished by now, without blocking
+            # (the latest one steers the caller's kernel choice)
+            while self._timings and self._timings[0][1].query():
+                t = self._timings.pop(0)
+                self.last_ms = t[0].elapsed_time(t[1])
             cur = torch.cuda.current_stream(self.device)
             cur.wait_event(ev)
             # `out` was allocated on the side stream and is consumed on the caller's: tell the caching allocator, or the block could

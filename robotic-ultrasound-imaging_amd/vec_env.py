@@ -146,6 +146,11 @@ class UltrasoundVecEnv:
         self._last_act = a           # keep the tensor alive until the kernel has run
         return self._obs, self._rew, self._done
 
+    def set_mapping(self, lanes_per_env, waves_per_simd=0):
+        """Switch a live soft-torso env between the split kernel (lanes_per_env 32) and the single-wave 16-lane kernel (waves_per_simd
+        0 / 1 / 2).  The mappings compute the same bits; the choice only matters for speed (include/usim.h usim_set_mapping)."""
+        self._check(self.lib.usim_set_mapping(self._handle, int(lanes_per_env), int(waves_per_simd)))
+
     def random_actions_tensor(self, step, out=None):
         out = self._act if out is None else out
         self._check(self.lib.usim_random_actions(self._handle, int(step), out.data_ptr(), self._stream()))

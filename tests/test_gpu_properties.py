@@ -314,3 +314,26 @@ def test_split_kernel_equals_the_single_wave_kernel_bit_for_bit(usim):
         assert all(np.array_equal(s0[key], s[key]) for key in s0)
     for e in envs:
         e.close()
+
+
+def test_mapping_can_change_in_the_middle_of_a_rollout(usim):
+    """usim_set_mapping: a rollout that alternates between the split kernel and the 16-lane kernel (both register budgets) every few
+    steps is bit for bit the rollout of an env that never switches (what bench.py does around the all-gather for N > 1)"""
+    a, b = _env(usim, 512), _env(usim, 512)
+    a.reset_tensor(); b.reset_tensor()
+    blk_a, blk_b = a.alloc_block(96), b.alloc_block(96)
+    a.rollout_random(0, 96, blk_a)
+    maps = [(16, 2), (32, 0), (16, 1), (32, 0), (16, 0), (32, 0)]
+    for i, (lanes, waves) in enumerate(maps):
+        b.set_mapping(lanes, waves)
+        b.rollout_random(16 * i, 16, {k: t[16 * i:16 * (i + 1)] for k, t in blk_b.items()})
+    torch.cuda.synchronize()
+    for k in blk_a:
+        assert torch.equal(blk_a[k], blk_b[k]), k
+    with pytest.raises(RuntimeError):
+        b.set_mapping(8, 0)
+    rigid = _env(usim, 64, torso="rigid")
+    with pytest.raises(RuntimeError):
+        rigid.set_mapping(32, 0)
+    for e in (a, b, rigid):
+        e.close()
