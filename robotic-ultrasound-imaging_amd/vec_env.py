@@ -162,11 +162,17 @@ class UltrasoundVecEnv:
         return _lib.UsimStepIO(None, block["obs"].data_ptr(), block["rew"].data_ptr(), block["done"].data_ptr(), None, None, None, None,
                                None if act is None else act.data_ptr(), None, None)
 
-    def rollout_random(self, first_step, nsteps, block=None):
-        """Enqueue nsteps steps with in-kernel synthetic actions.  With `block`, step k
+    def block_io(self, block):
+        """The usim_step_io of a rollout block, built once and handed to rollout_random(io=...) (keeps the Python work out of a timed loop)."""
+        return self._block_io(block)
+
+    def rollout_random(self, first_step, nsteps, block=None, io=None):
+        """Enqueue nsteps steps with in-kernel synthetic actions.  With `block` (or its prepared `io`), step k
         writes slice k of the [nsteps, n, ...] tensors (the transition block that is all-gathered across GPUs)."""
-        io = self._io if block is None else self._block_io(block)
-        self._check(self.lib.usim_rollout_random(self._handle, int(first_step), int(nsteps), C.byref(io), int(block is not None), self._stream()))
+        advance = block is not None or io is not None
+        if io is None:
+            io = self._io if block is None else self._block_io(block)
+        self._check(self.lib.usim_rollout_random(self._handle, int(first_step), int(nsteps), C.byref(io), int(advance), self._stream()))
 
     def time_steps(self, first_step, nsteps, block=None):
         """Same as rollout_random but bracketed by HIP events on the current stream; returns elapsed ms."""
