@@ -288,10 +288,33 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                         for (int i = 0; i < NE; ++i) collide_round(i);
                     }
                     if (nc > MAXC) {
-                        // rare: more penetrating elements than contact slots.  Keep the MAXC deepest of the first MAXCAND candidates
-                        // (ties keep the lower id), list still in ascending shell id; one lane of the group edits the records in place.
+                        // more penetrating elements than contact slots (rare in a mixed batch, common right after a synchronous reset: 4 % of
+                        // the environments).  Keep the MAXC deepest of the first MAXCAND candidates (ties keep the lower id), list still in
+                        // ascending shell id.
                         group_sync();
-                        if (gl == 0) {
+                        if constexpr (G == 16) {
+                            // one candidate per lane of the group: rank by depth with sixteen row broadcasts, compact with a ballot
+                            const int m = nc < MAXCAND ? nc : MAXCAND;
+                            const bool cand = gl < m;
+                            const float4* rec = reinterpret_cast<const float4*>(&EBF(GE_CG + gl * CG_WORDS));
+                            const float4 r0 = rec[0], r1 = rec[1];
+                            const float d = cand ? r1.w : 1.0f;
+                            int rank = 0;
+#define USIM_RANK_STEP(I) { const float di = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x150 + I, 0xf, 0xf, true)); \
+                            rank += (di < d || (di == d && I < gl)) ? 1 : 0; }
+                            USIM_RANK_STEP(0) USIM_RANK_STEP(1) USIM_RANK_STEP(2) USIM_RANK_STEP(3) USIM_RANK_STEP(4) USIM_RANK_STEP(5) USIM_RANK_STEP(6) USIM_RANK_STEP(7)
+                            USIM_RANK_STEP(8) USIM_RANK_STEP(9) USIM_RANK_STEP(10) USIM_RANK_STEP(11) USIM_RANK_STEP(12) USIM_RANK_STEP(13) USIM_RANK_STEP(14) USIM_RANK_STEP(15)
+#undef USIM_RANK_STEP
+                            const bool keep = cand && rank < MAXC;
+                            const unsigned gm = (unsigned)(__ballot(keep) >> gbase) & 0xffffu;
+                            const int slot = __popc(gm & ((1u << gl) - 1u));
+                            group_sync();                                  // every record is in registers before any slot is overwritten
+                            if (keep) {
+                                float4* dst = reinterpret_cast<float4*>(&EBF(GE_CG + slot * CG_WORDS));
+                                dst[0] = r0; dst[1] = r1;
+                            }
+                        } else if (gl == 0) {
+                            // (8 lanes per environment: one lane of the group edits the records in place)
                             const int m = nc < MAXCAND ? nc : MAXCAND;
                             for (int drop = m - MAXC; drop > 0; --drop) {
                                 int worst = 0; float wd = -1.0e30f;
