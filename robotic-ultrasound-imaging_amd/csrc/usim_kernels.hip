@@ -402,24 +402,43 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
     }
     USIM_STAMP(dbg, 9);
     // ---- Delassus blocks: B[k][d][d'] = d(residual of row d of this lane's contact) / d(force on row d' of contact k)
-    //      = w_d . Lambda^-1 w^k_d' + g_d Km[k] g^k_d' (+ the regulariser on the diagonal of the lane's own block).  Lane k
-    //      shares Lambda^-1 w^k and g^k through DPP once; the sweeps below then need three broadcasts per visit. ----
+    //      = w_d . Lambda^-1 w^k_d' + g_d Km[k] g^k_d' (+ the regulariser on the diagonal of the lane's own block); the sweeps below then
+    //      need three broadcasts per visit.
+    //      Lane k publishes Lambda^-1 w^k (18 words) and g^k (3) once in the environment's LDS block (the right-hand-side / staging area is
+    //      free by now); every lane then reads contact k's record with six 16-byte broadcast reads -- a quarter of the issue slots the 21 DPP
+    //      broadcasts took --, the reads of contact k + 1 in flight while the block of contact k is formed.
     float B[MAXC][3][3];            // B[k] is written and read only under k < ncmax
+    static_assert(MAXC * 24 <= GE_SD, "Delassus records overlay the rhs / staging area");
+    if (gl < MAXC) {
+        float4* pub = reinterpret_cast<float4*>(&EB(gl * 24));
+        pub[0] = make_float4(Liw[0][0], Liw[0][1], Liw[0][2], Liw[0][3]); pub[1] = make_float4(Liw[0][4], Liw[0][5], Liw[1][0], Liw[1][1]);
+        pub[2] = make_float4(Liw[1][2], Liw[1][3], Liw[1][4], Liw[1][5]); pub[3] = make_float4(Liw[2][0], Liw[2][1], Liw[2][2], Liw[2][3]);
+        pub[4] = make_float4(Liw[2][4], Liw[2][5], g[0], g[1]); pub[5] = make_float4(g[2], 0.f, 0.f, 0.f);
+    }
+    group_sync();
+    float4 rk[6];
+    {
+        const float4* src = reinterpret_cast<const float4*>(&EB(0));
+#pragma unroll
+        for (int v = 0; v < 6; ++v) rk[v] = src[v];
+    }
 #pragma unroll
     for (int k = 0; k < MAXC; ++k) {
         if (k < ncmax) {
-            float gk[3];
+            const float Lk[3][6] = {{rk[0].x, rk[0].y, rk[0].z, rk[0].w, rk[1].x, rk[1].y}, {rk[1].z, rk[1].w, rk[2].x, rk[2].y, rk[2].z, rk[2].w},
+                                    {rk[3].x, rk[3].y, rk[3].z, rk[3].w, rk[4].x, rk[4].y}};
+            const float gk[3] = {rk[4].z * Km[k], rk[4].w * Km[k], rk[5].x * Km[k]};
+            if (k + 1 < MAXC) {                                          // next contact's record (a slot beyond the count holds stale words: unused)
+                const float4* src = reinterpret_cast<const float4*>(&EB((k + 1) * 24));
 #pragma unroll
-            for (int dd = 0; dd < 3; ++dd) gk[dd] = group_bcast<G>(g[dd], k) * Km[k];
+                for (int v = 0; v < 6; ++v) rk[v] = src[v];
+            }
 #pragma unroll
             for (int dd = 0; dd < 3; ++dd) {
-                float Lk[6];
-#pragma unroll
-                for (int a = 0; a < 6; ++a) Lk[a] = group_bcast<G>(Liw[dd][a], k);
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
-                    float r1 = fmaf(w[d][4], Lk[4], fmaf(w[d][2], Lk[2], w[d][0] * Lk[0]));
-                    float r2 = fmaf(w[d][5], Lk[5], fmaf(w[d][3], Lk[3], w[d][1] * Lk[1]));
+                    float r1 = fmaf(w[d][4], Lk[dd][4], fmaf(w[d][2], Lk[dd][2], w[d][0] * Lk[dd][0]));
+                    float r2 = fmaf(w[d][5], Lk[dd][5], fmaf(w[d][3], Lk[dd][3], w[d][1] * Lk[dd][1]));
                     B[k][d][dd] = fmaf(g[d], gk[dd], r1 + r2);
                 }
             }
@@ -447,7 +466,7 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
                 float t1 = f[1] + d1u, t2 = f[2] + d2u;
                 // elliptic cone: |f_t| <= mu f_n
                 const float ft2 = fmaf(t1, t1, t2 * t2), lim = mu * f0n;
-                const float sc = (ft2 > lim * lim) ? lim * rsq_(ft2) : 1.0f;
+                const float sc = fminf(lim * rsq_(ft2), 1.0f);          // lim / |f_t| where that is below one (v_min keeps the number when ft2 = 0 makes the product inf or NaN)
                 t1 *= sc; t2 *= sc;
                 float d1 = t1 - f[1], d2 = t2 - f[2];
                 const bool mine = gl == k;
