@@ -63,7 +63,7 @@ typedef struct usim_config {
     int32_t initial_probe_pos_randomization;   /* rl_config.yaml:56 */
     int32_t friction_randomization;            /* BASELINE.json configs[4] */
     int32_t torso_drop;                        /* reproduce the 4.7 mm spawn drop (ultrasound.py:313) */
-    int32_t pgs_iters;                         /* contact PGS sweeps per forward pass (default 6: converged to float32 resolution) */
+    int32_t pgs_iters;                         /* full contact sweeps per forward pass (default 4), interleaved with normal-only sweeps: N N F F N F F */
     int32_t ik_iters;                          /* reset inverse-kinematics iterations */
     int32_t env_offset;                        /* global index of env 0 of this handle (multi-GPU shard) */
     int32_t lanes_per_env;                     /* kernel mapping: 0 automatic; 16 lanes per environment (arm mathematics distributed over the group); 32 (soft torso: the

@@ -811,11 +811,18 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
                     f[c][d] = 0;
                 }
             }
-            /* ---- projected Gauss-Seidel on the dual, fixed sweep count, no warm start ---- */
+            /* ---- projected Gauss-Seidel on the dual, fixed schedule, no warm start.  pgs_iters FULL sweeps (normal row, the two friction rows,
+             * cone projection per contact), interleaved with cheap NORMAL-ONLY sweeps: two up front, one between pairs of full sweeps
+             * (4 -> N N F F N F F).  The normal rows carry the strong coupling (elements through the lattice, all contacts through the arm), the
+             * friction rows are weak (mu = 0.01): for the same fixed point this schedule is closer to it than six full sweeps at 4/5 of the
+             * work (tests/test_oracle_physics.py::test_pgs_is_converged_at_default_sweeps). ---- */
             for (int it = 0; it < S->cfg.pgs_iters; it++) {
+              const int n_normal = (it == 0) ? 2 : ((it % 2 == 0) ? 1 : 0);      /* normal-only sweeps in front of full sweep `it` */
+              for (int pass = 0; pass <= n_normal; pass++) {
+                const int normal_only = pass < n_normal;
                 for (int c = 0; c < nc; c++) {
                     int e = out->con_el[c];
-                    for (int d = 0; d < 3; d++) {
+                    for (int d = 0; d < (normal_only ? 1 : 3); d++) {
                         real res = g[c][d] * ae[c] - aref[c][d] + Rr[c][d] * f[c][d];
                         for (int a = 0; a < 6; a++) res += w[c][d][a] * alpha[a];
                         real fn = f[c][d] - res / (Ad[c][d] + Rr[c][d]);
@@ -825,6 +832,7 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
                         for (int a = 0; a < 6; a++) alpha[a] += Liw[c][d][a] * df;
                         for (int c2 = 0; c2 < nc; c2++) ae[c2] += m->lat_Linv[out->con_el[c2] * n + e] * g[c][d] * df / (real)ELEM_MASS;
                     }
+                    if (normal_only) continue;
                     /* elliptic cone: |f_t| <= mu f_n */
                     real ft = (real)sqrt((double)(f[c][1] * f[c][1] + f[c][2] * f[c][2])), lim = E->mu * f[c][0];
                     if (ft > lim) {
@@ -837,6 +845,7 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
                         }
                     }
                 }
+              }
             }
             for (int c = 0; c < nc; c++) {
                 gf[c] = 0;
@@ -1158,7 +1167,7 @@ void uso_default_config(uso_config* c) {
     memset(c, 0, sizeof *c);
     c->mode = USO_MODE_TRACKING; c->torso = USO_TORSO_TOP; c->horizon = 1000; c->early_termination = 1;
     c->deterministic_trajectory = 0; c->torso_solref_randomization = 1; c->initial_probe_pos_randomization = 1;
-    c->friction_randomization = 0; c->torso_drop = 1; c->pgs_iters = 6; c->ik_iters = 5; c->env_offset = 0; c->robot = 0;
+    c->friction_randomization = 0; c->torso_drop = 1; c->pgs_iters = 4; c->ik_iters = 5; c->env_offset = 0; c->robot = 0;
     c->seed = 3; c->control_dt = 0.002; c->kp_fixed = 300; c->damping_ratio = 1; c->kp_min = 0; c->kp_max = 500;
     c->out_max_pos = 0.05; c->out_max_ori = 0.5; c->stiffness = 1324.17; c->damping = 17.59;
     c->elem_friction = 0.01; c->probe_friction = 1e-4;

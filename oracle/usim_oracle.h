@@ -46,7 +46,7 @@ typedef struct uso_config {
     int32_t initial_probe_pos_randomization; /* rl_config.yaml:56, ultrasound.py:870-887 */
     int32_t friction_randomization;          /* BASELINE config #5 (new knob) */
     int32_t torso_drop;           /* 1: torso base follows the 4.7 mm free-fall of ultrasound.py:313 */
-    int32_t pgs_iters;            /* fixed contact-PGS sweep count */
+    int32_t pgs_iters;            /* full contact-PGS sweeps (default 4), interleaved with normal-only sweeps: N N F F N F F */
     int32_t ik_iters;             /* fixed reset-IK iteration count */
     int32_t env_offset;           /* global index of env 0 (multi-GPU shards) */
     int32_t torso_shape;          /* 0 box (soft_box.xml, use_box_torso True), 1 cylinder (soft_human_torso.xml) */

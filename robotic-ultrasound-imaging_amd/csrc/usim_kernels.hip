@@ -452,10 +452,25 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
     //      ascending order.  The owner relaxes its three rows in order (normal, t1, t2; the earlier rows' updates enter
     //      through its own block), projects on the cone and shares the three force increments; every lane then moves its
     //      residuals by its block for that contact. ----
-    // (one straight-line instantiation of the sweep per wave-uniform contact count: no test per visit)
+    //      Schedule: C.pgs_iters FULL sweeps interleaved with NORMAL-ONLY sweeps (the owner relaxes its normal row alone: 8 instructions per
+    //      visit instead of 31), two up front and one between pairs of full sweeps -- 4 -> N N F F N F F.  The normal rows carry the strong
+    //      coupling; for the same fixed point this is closer to it than six full sweeps, at 4/5 of the work.
+    // (one straight-line instantiation of the sweeps per wave-uniform contact count: no test per visit)
     auto sweeps = [&](auto NCM_) {
         constexpr int NCM = decltype(NCM_)::value;
         for (int it = 0; it < C.pgs_iters; ++it) {
+            const int n_normal = (it == 0) ? 2 : (((it & 1) == 0) ? 1 : 0);
+            for (int pass = 0; pass < n_normal; ++pass) {
+#pragma unroll
+                for (int k = 0; k < NCM; ++k) {
+                    const float f0n = fmaxf(fmaf(-cres[0], invD[0], f[0]), 0.f);
+                    float d0 = f0n - f[0];
+                    f[0] = (gl == k) ? f0n : f[0];
+                    d0 = group_bcast<G>(d0, k);
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) cres[d] = fmaf(B[k][d][0], d0, cres[d]);
+                }
+            }
 #pragma unroll
             for (int k = 0; k < NCM; ++k) {
                 // every lane runs the solve on its own rows (no divergence); only lane k's increments are shared and kept

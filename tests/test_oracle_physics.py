@@ -259,28 +259,24 @@ def test_f32_oracle_tracks_f64_oracle():
 
 
 def test_pgs_is_converged_at_default_sweeps():
-    """six cold sweeps of the block Gauss-Seidel leave the contact forces within float32 resolution of the converged solution of the
-    convex problem (forces reach ~80 N here: one float32 ulp is 8e-6 N); ten sweeps reproduce it to 1e-7 N"""
-    n = 128
-    d, ref = Oracle(n), Oracle(n, pgs_iters=300)
-    assert d.cfg.pgs_iters == 6
-    d.reset(); ref.reset()
-    for k in range(30):
-        act = ref.random_actions(k)
-        ref.step(act)
-    d.set_state(ref.get_state())
-    act = ref.random_actions(30)
-    od, orf = d.step(act, auto_reset=False)[0], ref.step(act, auto_reset=False)[0]
-    assert np.abs(orf[:, :3]).max() > 20.0 and np.abs(od[:, :3] - orf[:, :3]).max() < 2e-5
-    a, b = Oracle(n, pgs_iters=10), Oracle(n, pgs_iters=300)
-    a.reset(); b.reset()
-    for k in range(30):
-        act = a.random_actions(k)
-        a.step(act); b.step(act)
-    st = a.get_state(); b.set_state(st)
-    act = a.random_actions(30)
-    oa, ob = a.step(act, auto_reset=False)[0], b.step(act, auto_reset=False)[0]
-    assert np.abs(oa[:, :3] - ob[:, :3]).max() < 1e-7
+    """The default contact schedule -- four full sweeps of the block Gauss-Seidel interleaved with three normal-only sweeps, N N F F N F F --
+    leaves the contact forces within float32 resolution of the converged solution of the convex problem, both in the first steps after a
+    synchronous reset (up to eleven penetrating elements, forces up to ~100 N: one float32 ulp is 8e-6 N) and in a mixed batch; six full
+    sweeps reproduce it to 1e-7 N"""
+    n = 256
+    for pre in (8, 40):
+        ref = Oracle(n, pgs_iters=300)
+        assert Oracle(1).cfg.pgs_iters == 4
+        ref.reset()
+        for k in range(pre):
+            ref.step(ref.random_actions(k))
+        st, act = ref.get_state(), ref.random_actions(pre)
+        orf = ref.step(act, auto_reset=False)[0]
+        for iters, tol in ((4, 1e-5), (6, 1e-7)):
+            d = Oracle(n, pgs_iters=iters)
+            d.reset(); d.set_state(st)
+            od = d.step(act, auto_reset=False)[0]
+            assert np.abs(orf[:, :3]).max() > 20.0 and np.abs(od[:, :3] - orf[:, :3]).max() < tol, (pre, iters)
 
 
 def test_oracle_is_clean_under_asan_and_ubsan():
