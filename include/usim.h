@@ -54,6 +54,10 @@ enum { USIM_ROBOT_PANDA = 0, USIM_ROBOT_UR5E = 1 };
 /* Mirrors the `robosuite:` block of src/rl_config.yaml:18-57 (the kwargs of Ultrasound.__init__,
  * ultrasound.py:99-136) plus the knobs the MJCF assets fix in the reference. */
 typedef struct usim_config {
+    int32_t struct_size;                       /* sizeof(usim_config) of the header the CALLER was built against.  The caller sets it before
+                                                * usim_default_config(); that call and usim_create() return USIM_ERR_INVALID -- without writing
+                                                * anything -- when it differs from the library's, so a binding built against another layout of
+                                                * this struct fails loudly instead of passing shifted fields or being overrun */
     int32_t mode;                              /* controller_configs.impedance_mode */
     int32_t torso;                             /* USIM_TORSO_* */
     int32_t horizon;                           /* rl_config.yaml:27 */
@@ -79,7 +83,9 @@ typedef struct usim_config {
     double out_max_pos, out_max_ori;           /* rl_config.yaml:36 */
     double stiffness, damping;                 /* soft_box.xml:9 solrefsmooth */
     double elem_friction, probe_friction;      /* soft_box.xml:10, ultrasound_probe_gripper.xml:8 */
-    double probe_radius, probe_halflen;        /* stand-in capsule for the missing probe mesh */
+    double probe_radius, probe_halflen;        /* stand-in for the missing probe mesh (ultrasound_probe_gripper.xml:3,8), a flared blade = convex hull of two
+                                                * parallel capsules along the site x axis: tip capsule radius / half-length (its axis one radius above grip_site) ... */
+    double probe_radius2, probe_height;        /* ... upper capsule: radius, height of its axis above the tip capsule's (probe_height > |probe_radius2 - probe_radius|) */
 } usim_config;
 
 typedef struct usim_handle usim_handle;
@@ -103,7 +109,8 @@ typedef struct usim_step_io {
                                 *          Fz_mean dFz goal_dFz is_contact q7 torques7 time% pos/ori/vel/force/dforce reward action7 */
 } usim_step_io;
 
-/* fills *c with the shipped configuration (src/rl_config.yaml) */
+/* fills *c with the shipped configuration (src/rl_config.yaml).  c->struct_size must hold sizeof(usim_config) on entry:
+ *     usim_config c = { sizeof c };  usim_default_config(&c); */
 int usim_default_config(usim_config* c);
 
 /* Replaces suite.make("Ultrasound", **options) + GymWrapper (src/rl.py:36-40) for n environments on HIP

@@ -23,7 +23,7 @@
  *   torso   static base (optionally the prescribed 4.7 mm drop), 99 top-face elements = 1-DoF sliders
  *           of mass 0.01 kg held by MuJoCo-style soft equality rows (joint "fix" rows + neighbour
  *           "tendon" rows with solrefsmooth = (-stiffness,-damping)), solved exactly in primal form
- *   contact probe capsule vs element capsules, condim 3 elliptic cone, soft (solref .02/1, solimp
+ *   contact probe blade (probe_sdf) vs element capsules, condim 3 elliptic cone, soft (solref .02/1, solimp
  *           .9/.95/.001/.5/2), projected Gauss-Seidel on the dual over contact rows only
  */
 #include <math.h>
@@ -133,12 +133,15 @@ static const RobotDesc ROBOT_UR5E = {
 #define HAND_INERTIA 0.05
 static const double PROBE_POS[3] = {-0.004, -0.063, 0.128};   /* ultrasound_probe_gripper.xml:6 */
 #define PROBE_MASS 1.0                                         /* ultrasound_probe_gripper.xml:8 */
-/* The probe mesh is missing from the reference snapshot (.MISSING_LARGE_BLOBS:1): stand-in geometry */
+/* The probe mesh is missing from the reference snapshot (.MISSING_LARGE_BLOBS:1): stand-in geometry.  Collision shape = flared blade
+ * (probe_sdf), long axis = site x (docs/images/frontview.png, sideview.png: the transducer is wide along world y at goal_quat), sizes
+ * calibrated on the 192 decoded reset observations (tools/calib_probe.py; tests/test_oracle_env_formulas.py) */
 static const double PROBE_COM[3] = {0.0013, 0.021, -0.043};
 static const double PROBE_INERTIA[3] = {1.6e-3, 1.6e-3, 2.0e-4};
-#define PROBE_RADIUS 0.040
-#define PROBE_HALFLEN 0.020
-/* capsule axis = probe-frame y, centre one radius behind the tip (tip == grip_site) */
+#define PROBE_RADIUS 0.012
+#define PROBE_HALFLEN 0.030
+#define PROBE_RADIUS2 0.050
+#define PROBE_HEIGHT 0.047
 
 /* soft torso lattice (soft_box.xml:9-10) */
 #define LAT_NX 9
@@ -147,10 +150,12 @@ static const double PROBE_INERTIA[3] = {1.6e-3, 1.6e-3, 2.0e-4};
 #define LAT_SPACING 0.035
 #define ELEM_RADIUS 0.0075
 #define ELEM_HALFLEN 0.025
-/* collision geometry of an element = the outer cap sphere of its capsule (centre one radius behind the tip).  The
- * shaft is ignored: against the primitive probe stand-in it only produces inward-pointing normals at deep
- * penetration (deviations) */
-#define ELEM_COLL_HALFLEN 0.0
+/* collision geometry of an element = its capsule (soft_box.xml:10): axis segment from the centre of the outer cap (one radius behind the
+ * tip) 2 * ELEM_COLL_HALFLEN inwards */
+#define ELEM_COLL_HALFLEN 0.025
+#define SHAFT_EPS 0.005
+#define PROBE_DEEP0 (2.0 / 3.0)
+#define PROBE_DEEP1 0.96
 #define ELEM_MASS 0.01
 #define N_SHELL 270
 #define N_TOP 99
@@ -246,7 +251,6 @@ typedef struct {
     real site_pos7[3], site_rot7[9];                /* eef site (grip_site == ft_frame) in link-7 frame */
     real hand_pos7[3];                              /* right_hand body origin in link-7 frame */
     real probe_com7[3], probe_inertia7[9];          /* probe body alone (torque sensor), link-7 frame */
-    real cap_c_site[3], cap_axis_site[3];           /* probe capsule centre/axis in site frame */
     real torso_c[3];                                /* torso centre at spawn, base-centred */
     double torso_w[3], top_offset, y_range, drop;   /* world placement, trajectory height/width, spawn gap above the table */
     real goal_rot[9];                               /* rotmat of goal_quat */
@@ -264,6 +268,8 @@ typedef struct {
 
 typedef struct {
     real q[NJ], qd[NJ], q0[NJ];
+    real dq[NJ];                                    /* q - q0: the integrator accumulates the excursion from the episode's initial pose, so that the
+                                                     * float32 build rounds the per-step increment at the magnitude of dq, not of q (as the kernels do) */
     real traj_start[3], traj_end[3], u0;            /* world coordinates */
     real vbar, fzbar, fzprev, dfz;
     real kt_stiff, kt_damp, mu;                     /* per-env torso stiffness/damping, contact friction */
@@ -390,9 +396,6 @@ static void build_model(Sim* S) {
     m->mass[last] = (real)mc;
     for (int i = 0; i < 3; i++) m->com[last][i] = (real)cc[i];
     for (int i = 0; i < 9; i++) m->inertia[last][i] = (real)Ic[i];
-    /* probe collision capsule in the site frame */
-    v3set(m->cap_c_site, 0, 0, (real)(-S->cfg.probe_radius));
-    v3set(m->cap_axis_site, 0, 1, 0);
     const int cyl = S->cfg.torso_shape == 1;
     m->torso_w[0] = 0; m->torso_w[1] = 0; m->torso_w[2] = cyl ? TORSO_Z_CYL : TORSO_Z_BOX;
     m->top_offset = cyl ? TOP_TORSO_OFFSET_CYL : TOP_TORSO_OFFSET_BOX; m->y_range = cyl ? Y_RANGE_CYL : Y_RANGE_BOX;
@@ -653,6 +656,7 @@ typedef struct {
     real fc[3];                 /* cfrc_ext[probe][3:6]: net contact force on the probe, world axes */
     real tq_sensor[3];          /* torque sensor at ft_frame, site frame */
     real min_margin;            /* smallest |dist| among near-contact candidate pairs (threshold diagnostics) */
+    real con_f[USO_MAXC][3], con_n[USO_MAXC][3], con_t[USO_MAXC];   /* diagnostics: contact-frame forces, normals, position along the shaft */
     int overflow;
 } Fwd;
 
@@ -667,26 +671,37 @@ static real torso_dz(const Sim* S, int t, real* vz, real* az) {
     return (real)z;
 }
 
-/* closest points between segments p1+s*d1 (s in [0,1]) and p2+t*d2 (Ericson, Real-Time Collision Detection 5.1.9) */
-static void seg_seg(const real* p1, const real* d1, const real* p2, const real* d2, real* c1, real* c2) {
-    real r[3]; v3sub(r, p1, p2);
-    real a = v3dot(d1, d1), e = v3dot(d2, d2), f = v3dot(d2, r), s, t;
-    const real EPS = (real)1e-12;
-    if (a <= EPS && e <= EPS) { s = t = 0; }
-    else if (a <= EPS) { s = 0; t = f / e; t = t < 0 ? 0 : (t > 1 ? 1 : t); }
-    else {
-        real c = v3dot(d1, r);
-        if (e <= EPS) { t = 0; s = -c / a; s = s < 0 ? 0 : (s > 1 ? 1 : s); }
-        else {
-            real b = v3dot(d1, d2), den = a * e - b * b;
-            s = (den > EPS) ? (b * f - c * e) / den : 0;
-            s = s < 0 ? 0 : (s > 1 ? 1 : s);
-            t = (b * s + f) / e;
-            if (t < 0) { t = 0; s = -c / a; s = s < 0 ? 0 : (s > 1 ? 1 : s); }
-            else if (t > 1) { t = 1; s = (b - c) / a; s = s < 0 ? 0 : (s > 1 ? 1 : s); }
-        }
+/* Probe collision geometry (stand-in for the missing mesh, ultrasound_probe_gripper.xml:3,8; MuJoCo collides the convex hull of a mesh):
+ * a flared blade = convex hull of two parallel capsules of half-length h along the site x axis -- the tip capsule (radius r1, axis r1 above the
+ * tip == grip_site) and an upper capsule (radius r2, axis H above the tip capsule's).  Signed distance of a point given in the site
+ * frame (site z points from the tip away from the probe body) and its gradient; exact (round-cone distance on the cross-section). */
+static real probe_sdf(const Sim* S, const real* p, real* g) {
+    const real r1 = (real)S->cfg.probe_radius, r2 = (real)S->cfg.probe_radius2, H = (real)S->cfg.probe_height, h = (real)S->cfg.probe_halflen;
+    const real ax = p[0], lat = p[1], py = -p[2] - r1;
+    const real aax = (real)fabs((double)ax), e = aax > h ? aax - h : 0;
+    const real px = (real)sqrt((double)(lat * lat + e * e));
+    const real b = (r1 - r2) / H, a = (real)sqrt((double)(1 - b * b));
+    const real kk = py * a - px * b;
+    const real qy = py - H, lc = (real)sqrt((double)(px * px + qy * qy));          /* distance from the upper circle's centre */
+    real d, gx, gy;
+    if (kk < 0) { real l = (real)sqrt((double)(px * px + py * py)); d = l - r1; if (l > (real)1e-9) { gx = px / l; gy = py / l; } else { gx = 0; gy = -1; } }
+    else if (kk > a * H) { d = lc - r2; if (lc > (real)1e-9) { gx = px / lc; gy = qy / lc; } else { gx = 0; gy = -1; } }
+    else { d = px * a + py * b - r1; gx = a; gy = b; }
+    /* Direction field.  The gradient of a convex body's distance is undefined on its medial axis -- here the tip capsule's axis, r1 below the
+     * surface, and the centre plane above it; a probe spawned 2 cm deep (ultrasound.py:880) reaches it.  Like the centre-to-centre search
+     * direction of MuJoCo's convex collider [RESTATED: MPR], the direction turns, between PROBE_DEEP0 r1 and PROBE_DEEP1 r1 below the surface, into
+     * the one seen from an interior reference point (the centre of the upper circle of the cross-section).  The distance itself stays exact. */
+    const real deep0 = (real)PROBE_DEEP0 * r1, deep1 = (real)PROBE_DEEP1 * r1;
+    real beta = (-d - deep0) / (deep1 - deep0); if (beta < 0) beta = 0; if (beta > 1) beta = 1;
+    if (beta > 0 && lc > (real)1e-9) {
+        real bx = gx + beta * (px / lc - gx), by = gy + beta * (qy / lc - gy), bn = (real)sqrt((double)(bx * bx + by * by));
+        gx = bx / bn; gy = by / bn;
     }
-    v3addscl(c1, p1, d1, s); v3addscl(c2, p2, d2, t);
+    const real ipx = px > (real)1e-9 ? 1 / px : 0;
+    g[0] = gx * e * ipx * (ax < 0 ? -1 : 1);
+    g[1] = px > (real)1e-9 ? gx * lat * ipx : gx;
+    g[2] = -gy;
+    return d;
 }
 
 static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, const real* tau, Fwd* out) {
@@ -721,34 +736,44 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
         }
         chol_solve(m->lat_L, n, rhs);            /* rhs now holds a~ (element accelerations without contacts) */
 
-        /* ---- collision: probe capsule vs every dynamic element capsule, ascending shell id ---- */
-        real cc[3], ax[3], t3[3], p1[3], d1[3];
-        m3mulv(t3, k->Rs, m->cap_c_site); v3add(cc, k->x, t3);
-        m3mulv(ax, k->Rs, m->cap_axis_site);
-        v3addscl(p1, cc, ax, (real)(-S->cfg.probe_halflen)); v3set(d1, ax[0] * (real)(2 * S->cfg.probe_halflen), ax[1] * (real)(2 * S->cfg.probe_halflen), ax[2] * (real)(2 * S->cfg.probe_halflen));
+        /* ---- collision: probe blade vs every dynamic element capsule, ascending shell id ---- */
         /* candidates: the first USO_MAXCAND penetrating elements in ascending shell id; when more than USO_MAXC are found the
          * USO_MAXC deepest are kept (ties keep the lower id) and the list stays in ascending shell id.  MuJoCo keeps every contact;
          * the slot limit is a design choice of this simulator, reported in status bit 0. */
         int nc = 0, ncand = 0, cand_el[USO_MAXCAND];
-        real cn[USO_MAXCAND][3], cp[USO_MAXCAND][3], cdist[USO_MAXCAND];
+        real cn[USO_MAXCAND][3], cp[USO_MAXCAND][3], cdist[USO_MAXCAND], ctt[USO_MAXCAND];
         for (int e = 0; e < n; e++) {
-            real tip[3], p2[3], d2[3], c1[3], c2[3], d[3];
+            real tip[3], c2[3], nrm[3], best = (real)1e30, tt;
             for (int a = 0; a < 3; a++) tip[a] = m->torso_c[a] + m->el_pos[e][a] + (E->s[e] - (real)ELEM_RADIUS) * m->el_axis[e][a];
             tip[2] += dz;
-            v3addscl(p2, tip, m->el_axis[e], (real)(-2 * ELEM_COLL_HALFLEN));
-            v3set(d2, m->el_axis[e][0] * (real)(2 * ELEM_COLL_HALFLEN), m->el_axis[e][1] * (real)(2 * ELEM_COLL_HALFLEN), m->el_axis[e][2] * (real)(2 * ELEM_COLL_HALFLEN));
-            seg_seg(p1, d1, p2, d2, c1, c2);
-            v3sub(d, c1, c2);
-            real len = v3norm(d), dist = len - (real)(S->cfg.probe_radius + ELEM_RADIUS);
+            {
+                /* closest point of the element's axis segment (cap centre t = 0 ... inner end t = 1) to the probe: the distance d(t) is convex along
+                 * the segment.  With the slopes s0, s1 at the two ends, t minimises the quadratic model d0 + s0 t + (s1 - s0 + eps) t^2 / 2 on [0, 1];
+                 * eps (SHAFT_EPS, in metres per segment) settles the point near the cap when the shaft lies flat against a flank of the probe
+                 * (s0 ~ s1 ~ 0: every point of the segment is equally close and the minimiser would be ill-conditioned). */
+                real rel[3], p0[3], us[3], uw[3], g0[3], g1[3], gs[3], ps[3], gw[3];
+                v3sub(rel, tip, k->x); m3tmulv(p0, k->Rs, rel);
+                v3set(uw, -m->el_axis[e][0] * (real)(2 * ELEM_COLL_HALFLEN), -m->el_axis[e][1] * (real)(2 * ELEM_COLL_HALFLEN), -m->el_axis[e][2] * (real)(2 * ELEM_COLL_HALFLEN));
+                m3tmulv(us, k->Rs, uw);
+                v3add(ps, p0, us);
+                real s0 = v3dot(g0, us);   /* (set below) */
+                (void)probe_sdf(S, p0, g0); s0 = v3dot(g0, us);
+                (void)probe_sdf(S, ps, g1);
+                real s1 = v3dot(g1, us), curv = s1 - s0; if (curv < 0) curv = 0;
+                tt = -s0 / (curv + (real)SHAFT_EPS); if (tt < 0) tt = 0; if (tt > 1) tt = 1;
+                v3addscl(ps, p0, us, tt); best = probe_sdf(S, ps, gs);
+                m3mulv(gw, k->Rs, gs); v3addscl(c2, tip, uw, tt); v3set(nrm, -gw[0], -gw[1], -gw[2]);
+            }
+            real dist = best - (real)ELEM_RADIUS;
             real am = (real)fabs((double)dist);
             if (am < out->min_margin) out->min_margin = am;
             out->el_dist[e] = dist;
             if (dist < 0) {
                 if (ncand >= USO_MAXC) out->overflow = 1;
                 if (ncand >= USO_MAXCAND) continue;
-                if (len > (real)1e-9) { for (int a = 0; a < 3; a++) cn[ncand][a] = d[a] / len; } else v3set(cn[ncand], 0, 0, 1);
+                v3cpy(cn[ncand], nrm);
                 for (int a = 0; a < 3; a++) cp[ncand][a] = c2[a] + cn[ncand][a] * ((real)ELEM_RADIUS + (real)0.5 * dist);
-                cdist[ncand] = dist; cand_el[ncand] = e; ncand++;
+                cdist[ncand] = dist; cand_el[ncand] = e; ctt[ncand] = tt; ncand++;
             }
         }
         {
@@ -763,7 +788,8 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
             for (int c = 0; c < ncand; c++) {
                 if (!alive[c]) continue;
                 if (ncand > USO_MAXC) { real gap = (real)fabs((double)(last_dropped - cdist[c])); if (gap < out->min_margin) out->min_margin = gap; }
-                if (nc != c) { v3cpy(cn[nc], cn[c]); v3cpy(cp[nc], cp[c]); cdist[nc] = cdist[c]; }
+                if (nc != c) { v3cpy(cn[nc], cn[c]); v3cpy(cp[nc], cp[c]); cdist[nc] = cdist[c]; ctt[nc] = ctt[c]; }
+                out->con_t[nc] = ctt[nc];
                 out->con_el[nc] = cand_el[c]; out->con_dist[nc] = cdist[nc]; nc++;
             }
         }
@@ -847,6 +873,7 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
                 }
               }
             }
+            for (int c = 0; c < nc; c++) { for (int d = 0; d < 3; d++) { out->con_f[c][d] = f[c][d]; out->con_n[c][d] = cn[c][d]; } }
             for (int c = 0; c < nc; c++) {
                 gf[c] = 0;
                 for (int d = 0; d < 3; d++) {
@@ -1060,7 +1087,7 @@ static void reset_env(Sim* S, int i, const double* ex /* explicit draws or NULL 
         chol(A6, 6); chol_solve(A6, 6, e);
         for (int j = 0; j < NJ; j++) { real s = 0; for (int a = 0; a < 6; a++) s += J[a][j] * e[a]; q[j] += s; }
     }
-    for (int j = 0; j < NJ; j++) { E->q[j] = q[j]; E->q0[j] = q[j]; E->qd[j] = 0; }   /* :462-465 */
+    for (int j = 0; j < NJ; j++) { E->q[j] = q[j]; E->q0[j] = q[j]; E->qd[j] = 0; E->dq[j] = 0; }   /* :462-465 */
     E->t = 0; E->fzprev = 0; E->dfz = 0; E->ep_return = 0;   /* :468-471 */
     /* sim.forward() with zero ctrl -> initial contact force, running means (:474-477) */
     Pass P; forward_pass(S, E, 0, 1, &P);
@@ -1069,6 +1096,7 @@ static void reset_env(Sim* S, int i, const double* ex /* explicit draws or NULL 
     E->fzbar = P.f.fc[2];
     E->ncon = P.f.ncon; for (int cix = 0; cix < P.f.ncon; cix++) E->con_el[cix] = m->el_shell_id[P.f.con_el[cix]];
     if (P.f.overflow) E->status |= 1;         /* the status word covers the reset forward pass too */
+    E->info[7] = (double)P.f.min_margin;      /* threshold diagnostics of the reset forward pass (contact distances, ties of the slot selection) */
     if (obs_out) {
         real ob[USO_OBS_DIM], tpw[3]; traj_eval(S, E, 0, tpw);
         make_obs(S, E, &P.k, &P.f, P.tq, hv, tpw, ob);
@@ -1092,7 +1120,7 @@ static void step_env(Sim* S, int i, const double* act_d, double* obs, double* re
     memcpy(Md, P.k.M, sizeof Md);
     for (int a = 0; a < NJ; a++) Md[a * NJ + a] += dt * (real)JOINT_DAMPING;
     chol(Md, NJ); chol_solve(Md, NJ, rhs);
-    for (int a = 0; a < NJ; a++) { E->qd[a] += dt * rhs[a]; E->q[a] += dt * E->qd[a]; }
+    for (int a = 0; a < NJ; a++) { E->qd[a] += dt * rhs[a]; E->dq[a] += dt * E->qd[a]; E->q[a] = E->q0[a] + E->dq[a]; }
     for (int e = 0; e < m->n_el; e++) { E->sd[e] += dt * P.f.ael[e]; E->s[e] += dt * E->sd[e]; }
     /* sensors read mj_step's data: kinematics/contacts from before the integration, qvel from after
      * (SURVEY C.4 "after mj_step, cfrc_ext/contacts describe the pre-integration state") */
@@ -1143,7 +1171,7 @@ static void step_env(Sim* S, int i, const double* act_d, double* obs, double* re
     }
     /* termination cause bitmask (1 horizon, 2 joint limit, 4 position, 8 orientation, 16 lost contact) and the
      * distance of every thresholded quantity from its threshold, for razor-edge analysis in the parity tests */
-    double info_tmp[8] = {(double)cause, (double)pos_err_norm, (double)ori_err, jmargin, (double)P.f.min_margin, (double)P.f.ncon, (double)reward, 0};
+    double info_tmp[8] = {(double)cause, (double)pos_err_norm, (double)ori_err, jmargin, (double)P.f.min_margin, (double)P.f.ncon, (double)reward, 1e9};
     E->ep_return += reward;
     E->ncon = P.f.ncon; for (int cix = 0; cix < P.f.ncon; cix++) E->con_el[cix] = m->el_shell_id[P.f.con_el[cix]];
     if (P.f.overflow) E->status |= 1;
@@ -1156,7 +1184,7 @@ static void step_env(Sim* S, int i, const double* act_d, double* obs, double* re
     if (done_out) *done_out = (uint8_t)done;
     if (term_obs) for (int a = 0; a < USO_OBS_DIM; a++) term_obs[a] = (double)ob[a];
     if (obs) for (int a = 0; a < USO_OBS_DIM; a++) obs[a] = (double)ob[a];
-    if (done && auto_reset) reset_env(S, i, 0, obs);       /* SB3 VecEnv: obs of a finished env is its reset obs */
+    if (done && auto_reset) { reset_env(S, i, 0, obs); info_tmp[7] = S->env[i].info[7]; }   /* SB3 VecEnv: obs of a finished env is its reset obs */
     memcpy(S->env[i].info, info_tmp, sizeof info_tmp);
 }
 
@@ -1171,7 +1199,7 @@ void uso_default_config(uso_config* c) {
     c->seed = 3; c->control_dt = 0.002; c->kp_fixed = 300; c->damping_ratio = 1; c->kp_min = 0; c->kp_max = 500;
     c->out_max_pos = 0.05; c->out_max_ori = 0.5; c->stiffness = 1324.17; c->damping = 17.59;
     c->elem_friction = 0.01; c->probe_friction = 1e-4;
-    c->probe_radius = PROBE_RADIUS; c->probe_halflen = PROBE_HALFLEN; c->torso_shape = 0;
+    c->probe_radius = PROBE_RADIUS; c->probe_halflen = PROBE_HALFLEN; c->probe_radius2 = PROBE_RADIUS2; c->probe_height = PROBE_HEIGHT; c->torso_shape = 0;
 }
 void* uso_create(const uso_config* c, int n) {
     Sim* S = (Sim*)calloc(1, sizeof(Sim));
@@ -1224,7 +1252,7 @@ int uso_set_state(void* h, const double* sc, const double* lat) {
     Sim* S = (Sim*)h; int n_el = S->m.n_el;
     for (int i = 0; i < S->n; i++) {
         Env* E = &S->env[i]; const double* o = sc + (size_t)i * USO_NSCALAR;
-        for (int j = 0; j < NJ; j++) { E->q[j] = (real)o[j]; E->qd[j] = (real)o[7 + j]; E->q0[j] = (real)o[14 + j]; }
+        for (int j = 0; j < NJ; j++) { E->q[j] = (real)o[j]; E->qd[j] = (real)o[7 + j]; E->q0[j] = (real)o[14 + j]; E->dq[j] = (real)(o[j] - o[14 + j]); }
         for (int a = 0; a < 3; a++) { E->traj_start[a] = (real)o[21 + a]; E->traj_end[a] = (real)o[24 + a]; }
         E->u0 = (real)o[27]; E->vbar = (real)o[28]; E->fzbar = (real)o[29]; E->fzprev = (real)o[30]; E->dfz = (real)o[31];
         E->kt_stiff = (real)o[32]; E->kt_damp = (real)o[33]; E->mu = (real)o[34];
@@ -1266,6 +1294,21 @@ int uso_debug_forward(void* h, int env, double* out) {
     out[116] = (double)P.f.ncon; out[117] = (double)P.f.min_margin;
     for (int j = 0; j < NJ; j++) out[118 + j] = (double)P.f.qacc[j];
     return 0;
+}
+/* diagnostics: the contacts of the forward pass at the CURRENT state of `env` under the action `act` (NULL: zero torque): per contact
+ * element, distance, normal (3), contact-frame force (normal, t1, t2) -> out[USO_MAXC][8]; returns the number of contacts */
+int uso_debug_contacts(void* h, int env, const double* act_d, double* out) {
+    Sim* S = (Sim*)h; Env* E = &S->env[env];
+    if (S->cfg.torso == USO_TORSO_NONE) return -1;
+    real act[8] = {0};
+    if (act_d) for (int a = 0; a < S->adim; a++) act[a] = (real)act_d[a];
+    Env T = *E; if (act_d) T.t += 1;
+    Pass P; forward_pass(S, &T, act, act_d ? 0 : 1, &P);
+    for (int c = 0; c < P.f.ncon; c++) {
+        out[c * 8] = P.f.con_el[c] + 0.001 * (double)(int)(999 * P.f.con_t[c]); out[c * 8 + 1] = (double)P.f.con_dist[c];   /* element . position along the shaft */
+        for (int d = 0; d < 3; d++) { out[c * 8 + 2 + d] = (double)P.f.con_n[c][d]; out[c * 8 + 5 + d] = (double)P.f.con_f[c][d]; }
+    }
+    return P.f.ncon;
 }
 int uso_element_distances(void* h, int env, double* dist_out, int32_t* contacts_out) {
     Sim* S = (Sim*)h; Env* E = &S->env[env];

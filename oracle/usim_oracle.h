@@ -60,7 +60,8 @@ typedef struct uso_config {
     double stiffness, damping;    /* soft_box.xml:9 solrefsmooth (1324.17, 17.59) */
     double elem_friction;         /* soft_box.xml:10 (0.01) */
     double probe_friction;        /* ultrasound_probe_gripper.xml:8 (1e-4) */
-    double probe_radius, probe_halflen;   /* stand-in capsule for the missing probe mesh (.MISSING_LARGE_BLOBS:1) */
+    double probe_radius, probe_halflen;   /* stand-in for the missing probe mesh (.MISSING_LARGE_BLOBS:1): tip radius, half-length */
+    double probe_radius2, probe_height;   /* ... radius of the upper edge of the flared blade and its height above the tip axis */
 } uso_config;
 
 void  uso_default_config(uso_config* c);
@@ -101,6 +102,7 @@ int uso_random_actions(void* h, int64_t step, double* act);
 int uso_debug_forward(void* h, int env, double* out);
 /* diagnostics: signed probe distance of the 99 elements (element order) at the current state, the contact list the forward
  * pass keeps (count + element indices, not shell ids); returns the overflow flag */
+int uso_debug_contacts(void* h, int env, const double* act, double* out /* [USO_MAXC][8] */);
 int uso_element_distances(void* h, int env, double* dist_out, int32_t* contacts_out);
 
 #ifdef __cplusplus

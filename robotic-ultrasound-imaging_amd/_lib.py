@@ -24,12 +24,12 @@ ROBOT = {"Panda": 0, "UR5e": 1}             # ultrasound.py:137
 class UsimConfig(C.Structure):
     """struct usim_config (include/usim.h)"""
     _fields_ = [(n, C.c_int32) for n in (
-        "mode", "torso", "horizon", "early_termination", "deterministic_trajectory", "torso_solref_randomization",
+        "struct_size", "mode", "torso", "horizon", "early_termination", "deterministic_trajectory", "torso_solref_randomization",
         "initial_probe_pos_randomization", "friction_randomization", "torso_drop", "pgs_iters", "ik_iters", "env_offset",
         "lanes_per_env", "torso_shape", "waves_per_simd", "robot")] + \
         [("seed", C.c_uint64)] + [(n, C.c_double) for n in (
             "control_dt", "kp_fixed", "damping_ratio", "kp_min", "kp_max", "out_max_pos", "out_max_ori", "stiffness", "damping",
-            "elem_friction", "probe_friction", "probe_radius", "probe_halflen")]
+            "elem_friction", "probe_friction", "probe_radius", "probe_halflen", "probe_radius2", "probe_height")]
 
 
 class UsimStepIO(C.Structure):

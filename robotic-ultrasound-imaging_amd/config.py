@@ -13,7 +13,7 @@ _IGNORED = {
 }
 # extensions of this build (not kwargs of the reference env)
 _NATIVE = {"torso", "friction_randomization", "torso_drop", "pgs_iters", "ik_iters", "lanes_per_env", "waves_per_simd", "stiffness", "damping",
-           "elem_friction", "probe_friction", "probe_radius", "probe_halflen"}
+           "elem_friction", "probe_friction", "probe_radius", "probe_halflen", "probe_radius2", "probe_height"}
 
 
 def default_robosuite_kwargs():
@@ -45,6 +45,7 @@ def make_config(seed=3, env_offset=0, **kw):
     ValueError, mirroring the asserts at ultrasound.py:134-141."""
     lib = _lib.load()
     c = _lib.UsimConfig()
+    c.struct_size = C.sizeof(c)
     _lib.check(lib, lib.usim_default_config(C.byref(c)))
     kw = dict(kw)
     robots = kw.pop("robots", "Panda")
@@ -94,7 +95,7 @@ def make_config(seed=3, env_offset=0, **kw):
     for k in ("friction_randomization", "torso_drop", "pgs_iters", "ik_iters", "lanes_per_env", "waves_per_simd", "waves_per_simd"):
         if k in kw:
             setattr(c, k, int(kw.pop(k)))
-    for k in ("stiffness", "damping", "elem_friction", "probe_friction", "probe_radius", "probe_halflen"):
+    for k in ("stiffness", "damping", "elem_friction", "probe_friction", "probe_radius", "probe_halflen", "probe_radius2", "probe_height"):
         if k in kw:
             setattr(c, k, float(kw.pop(k)))
     for k in list(kw):

@@ -249,18 +249,21 @@ static int launch(usim_handle* h, DevIO io, int flags, long long rstep, hipStrea
 extern "C" {
 
 int usim_default_config(usim_config* c) {
-    if (!c) return USIM_ERR_INVALID;
+    if (!c || c->struct_size != (int32_t)sizeof(usim_config)) return USIM_ERR_INVALID;   // nothing is written to a struct of another layout
     std::memset(c, 0, sizeof *c);
     c->mode = USIM_MODE_TRACKING; c->torso = USIM_TORSO_TOP; c->horizon = 1000; c->early_termination = 1;
     c->deterministic_trajectory = 0; c->torso_solref_randomization = 1; c->initial_probe_pos_randomization = 1;
     c->friction_randomization = 0; c->torso_drop = 1; c->pgs_iters = 4; c->ik_iters = 5; c->env_offset = 0; c->lanes_per_env = 0; c->torso_shape = 0; c->waves_per_simd = 0; c->robot = 0; c->seed = 3;
     c->control_dt = 0.002; c->kp_fixed = 300; c->damping_ratio = 1; c->kp_min = 0; c->kp_max = 500; c->out_max_pos = 0.05; c->out_max_ori = 0.5;
-    c->stiffness = 1324.17; c->damping = 17.59; c->elem_friction = 0.01; c->probe_friction = 1e-4; c->probe_radius = 0.04; c->probe_halflen = 0.02;
+    c->stiffness = 1324.17; c->damping = 17.59; c->elem_friction = 0.01; c->probe_friction = 1e-4; c->probe_radius = 0.012; c->probe_halflen = 0.03;
+    c->probe_radius2 = 0.05; c->probe_height = 0.047; c->struct_size = (int32_t)sizeof(usim_config);
     return USIM_OK;
 }
 
 int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** out) {
     if (!cfg || !out || n_envs <= 0) return USIM_ERR_INVALID;
+    if (cfg->struct_size != (int32_t)sizeof(usim_config)) return USIM_ERR_INVALID;     // built against another layout of include/usim.h
+    if (cfg->probe_radius2 <= 0 || !(cfg->probe_height > std::fabs(cfg->probe_radius2 - cfg->probe_radius))) return USIM_ERR_INVALID;
     if (cfg->mode < 0 || cfg->mode > 3 || cfg->torso < 0 || cfg->torso > 1 || cfg->horizon <= 0 || cfg->control_dt <= 0 ||
         cfg->probe_halflen < 1e-4 || cfg->probe_radius <= 0 || cfg->pgs_iters < 0 || cfg->ik_iters < 0 || cfg->torso_shape < 0 ||
         cfg->torso_shape > 1 || cfg->waves_per_simd < 0 || cfg->waves_per_simd > 2 || cfg->robot < 0 || cfg->robot > 1) return USIM_ERR_INVALID;
@@ -284,6 +287,12 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
     C.damping = (float)cfg->damping; C.elem_fric = (float)cfg->elem_friction; C.probe_fric = (float)cfg->probe_friction;
     C.probe_r = (float)cfg->probe_radius; C.probe_hl = (float)cfg->probe_halflen;
     {
+        const double cb = (cfg->probe_radius - cfg->probe_radius2) / cfg->probe_height, ca = std::sqrt(1.0 - cb * cb);
+        C.probe_r2 = (float)cfg->probe_radius2; C.probe_h = (float)cfg->probe_height; C.probe_ca = (float)ca; C.probe_cb = (float)cb;
+        C.probe_cah = C.probe_ca * C.probe_h;
+        C.probe_deep0 = (float)(cfg->probe_radius * (2.0 / 3.0)); C.probe_inv_band = (float)(1.0 / (cfg->probe_radius * (0.96 - 2.0 / 3.0)));
+    }
+    {
         const int shape = cfg->torso_shape ? 1 : 0;
         C.top_off = (float)kTopOff[shape]; C.y_range = (float)kYRange[shape]; C.drop = (float)(kTorsoZ[shape] - 0.0525 - 0.8);
     }
@@ -297,10 +306,7 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
     HIPCHK(h, hipMemset(h->d_count, 0, 2 * sizeof(int)));
     HIPCHK(h, hipEventCreate(&h->ev0));
     HIPCHK(h, hipEventCreate(&h->ev1));
-    // kernel mapping: rigid torso -> one environment per lane; soft torso -> 8 or 16 lanes per
-    // environment.  The step kernel needs the whole register file of a SIMD (one wave per SIMD), so the mapping that
-    // yields about 1024 waves wins: 16 lanes up to 4096 envs/GPU (one 4-wave workgroup per CU), 8 lanes beyond.
-    // (superseded for steps by the 16-lane kernel of usim_step16.h, which is the automatic choice at every batch size; 8 lanes on request)
+    // kernel mapping
     // Rigid torso: 16 lanes per environment (arm mathematics distributed over the group) or, with lanes_per_env = 1, one lane each.
     // Soft torso, automatic choice: up to 4096 envs/GPU the split kernel (32 lanes = two waves per quad of environments, usim_step32_kernel)
     // unless a register budget was asked for; beyond, 16 lanes per environment with the two-waves-per-SIMD budget.
@@ -472,6 +478,7 @@ int usim_get_state(usim_handle* h, float* scalars, float* lattice) {
     const int int_fields[4] = {F_T, F_TOUCH, F_EPISODE, F_STATUS};
     for (int i = 0; i < h->n; ++i) {
         for (int f = 0; f < F_NSCALAR; ++f) scalars[(size_t)i * USIM_NSCALAR + f] = buf[scalar_index(f, i)];
+        for (int j = 0; j < NJ; ++j) scalars[(size_t)i * USIM_NSCALAR + F_Q + j] = buf[scalar_index(F_Q0 + j, i)] + buf[scalar_index(F_Q + j, i)];   // device holds dq = q - q0
         for (int k = 0; k < 4; ++k) {
             int v; std::memcpy(&v, &buf[scalar_index(int_fields[k], i)], 4);
             scalars[(size_t)i * USIM_NSCALAR + int_fields[k]] = (float)v;
@@ -494,6 +501,7 @@ int usim_set_state(usim_handle* h, const float* scalars, const float* lattice) {
     const int int_fields[4] = {F_T, F_TOUCH, F_EPISODE, F_STATUS};
     for (int i = 0; i < h->n; ++i) {
         for (int f = 0; f < F_NSCALAR; ++f) buf[scalar_index(f, i)] = scalars[(size_t)i * USIM_NSCALAR + f];
+        for (int j = 0; j < NJ; ++j) buf[scalar_index(F_Q + j, i)] = scalars[(size_t)i * USIM_NSCALAR + F_Q + j] - scalars[(size_t)i * USIM_NSCALAR + F_Q0 + j];   // device holds dq = q - q0
         for (int k = 0; k < 4; ++k) {
             int v = (int)scalars[(size_t)i * USIM_NSCALAR + int_fields[k]];
             std::memcpy(&buf[scalar_index(int_fields[k], i)], &v, 4);
@@ -551,6 +559,9 @@ const char* usim_strerror(int status) {
     }
 }
 const char* usim_last_hip_error(const usim_handle* h) { return h ? h->hip_err.c_str() : ""; }
-const char* usim_version(void) { return "usim 0.2 (gfx950)"; }
+#ifndef USIM_SRC_HASH
+#define USIM_SRC_HASH "unhashed"
+#endif
+const char* usim_version(void) { return "usim 0.3 (gfx950) src " USIM_SRC_HASH; }
 
 }  // extern "C"

@@ -21,7 +21,8 @@ constexpr int LINV_NBLK = 13;     // ceil(99 / 8)
 constexpr int LOG_WIDTH = 53;      // words per environment of the optional episode record
 constexpr int WG = 64;            // one wave64 per workgroup: one environment per lane
 
-// scalar state fields (same order as usim_get_state's [n][USIM_NSCALAR] block)
+// scalar state fields (same order as usim_get_state's [n][USIM_NSCALAR] block; on the device the F_Q words hold dq = q - q0, the excursion from
+// the initial pose of the episode -- usim_get_state / usim_set_state convert)
 enum Field : int {
     F_Q = 0, F_QD = 7, F_Q0 = 14, F_TS = 21, F_TE = 24, F_U0 = 27, F_VBAR = 28, F_FZBAR = 29, F_FZPREV = 30,
     F_DFZ = 31, F_KST = 32, F_KDMP = 33, F_MU = 34, F_T = 35, F_TOUCH = 36, F_EPISODE = 37, F_EPRET = 38,
@@ -66,6 +67,8 @@ struct DevCfg {
     uint32_t key0, key1;
     float dt, kp_fixed, damping_ratio, kp_min, kp_max, out_pos, out_ori;
     float stiffness, damping, elem_fric, probe_fric, probe_r, probe_hl;
+    float probe_deep0, probe_inv_band;                           // direction field below the surface: blend band (probe_sdf)
+    float probe_r2, probe_h, probe_ca, probe_cb, probe_cah;   // flared blade (usim_kernels.hip probe_sdf): upper radius, height, flank direction (ca, cb), ca * h
     float top_off, y_range, drop;       // trajectory height above the torso centre, half width of the waypoint grid, spawn gap
 };
 

@@ -52,7 +52,8 @@ __device__ constexpr float INITQ[NJ] = {0.f, 0.19634954084936207f, 0.f, -2.61799
 constexpr float JOINT_DAMP = 0.1f;
 constexpr float GRAV = 9.81f;
 constexpr float PROBE_MASS = 1.0f;
-constexpr float ELEM_R = 0.0075f, ELEM_MASS = 0.01f;
+constexpr float SHAFT_EPS = 0.005f;                                      // regulariser of the contact point along an element's shaft (metres per segment)
+constexpr float ELEM_R = 0.0075f, ELEM_HL = 0.025f, ELEM_MASS = 0.01f;   // capsule size="0.0075 0.025" mass="0.01" (soft_box.xml:10)
 // MuJoCo default soft-constraint parameters (solref 0.02 1, solimp 0.9 0.95 0.001 0.5 2) and robosuite's impratio
 constexpr float SR_TC = 0.02f, SI_D0 = 0.9f, SI_DMAX = 0.95f, SI_WIDTH = 0.001f, IMPRATIO = 20.f;
 constexpr float PI_F = 3.14159265358979323846f;

@@ -114,6 +114,36 @@ DI void torso_motion(const DevCfg& C, int tsim, float& dz, float& vz, float& az)
     }
 }
 
+// Probe collision geometry (stand-in for the missing mesh, ultrasound_probe_gripper.xml:3,8; MuJoCo collides the convex hull of a mesh): a flared
+// blade = convex hull of two parallel capsules of half-length probe_hl along the site x axis -- the tip capsule (radius probe_r, axis probe_r above
+// the tip = grip_site) and an upper capsule (radius probe_r2, axis probe_h above the tip capsule's).  Signed distance of a point given in the site
+// frame (site z points from the tip away from the probe body) and its gradient: the round-cone distance on the cross-section.
+DI float probe_sdf(const DevCfg& C, const f3 p, f3& g) {
+    const float py = -p.z - C.probe_r, e = fmaxf(fabsf(p.x) - C.probe_hl, 0.f);
+    const float px2 = fmaf(p.y, p.y, e * e), px = sqrt_(px2);
+    const float kk = fmaf(py, C.probe_ca, -(px * C.probe_cb));
+    const bool low = kk < 0.f, flank = !low && !(kk > C.probe_cah);
+    const float qy = py - C.probe_h;
+    const float lc = sqrt_(fmaf(qy, qy, px2)), ilc = rcp_(lc);                        // seen from the centre of the upper circle of the cross-section
+    const float ll = sqrt_(fmaf(py, py, px2)), ill = rcp_(ll);                        // ... of the tip circle
+    const bool okc = lc > 1e-9f, okl = ll > 1e-9f;
+    const float cx = px * ilc, cy = qy * ilc;
+    float d = low ? ll - C.probe_r : lc - C.probe_r2;
+    float gx = low ? (okl ? px * ill : 0.f) : (okc ? cx : 0.f), gy = low ? (okl ? py * ill : -1.f) : (okc ? cy : -1.f);
+    if (flank) { d = fmaf(px, C.probe_ca, fmaf(py, C.probe_cb, -C.probe_r)); gx = C.probe_ca; gy = C.probe_cb; }
+    // direction field: the distance gradient is undefined on the medial axis of the body (the tip capsule's axis, probe_r below the surface, and
+    // the centre plane above it); between 2/3 and 0.96 probe_r below the surface the direction turns into the one seen from the upper centre
+    // (like the centre-to-centre search direction of a convex collider).  The distance stays exact.
+    const float beta = okc ? clampf((-d - C.probe_deep0) * C.probe_inv_band, 0.f, 1.f) : 0.f;
+    const float bx = fmaf(beta, cx - gx, gx), by = fmaf(beta, cy - gy, gy);
+    const float rn = beta > 0.f ? rsq_(fmaf(bx, bx, by * by)) : 1.f;
+    gx = bx * rn; gy = by * rn;
+    const bool pxok = px > 1e-9f;
+    const float ipx = pxok ? rcp_(px) : 0.f, gxi = gx * ipx;
+    g = mk(copysignf(gxi * e, p.x), pxok ? gxi * p.y : gx, -gy);
+    return d;
+}
+
 // Lattice front end of one forward pass, executed by the G lanes of a group on the group's LDS block: stage (s, sdot), build
 // the right-hand side of the soft-equality system, a~ = Linv rhs, collide the probe capsule with the 99 cap spheres and
 // leave the contact records (ascending shell id; the MAXC deepest when more were found) in LDS.  Returns the number found (may exceed MAXC).
@@ -173,27 +203,31 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                     }
                     if constexpr (PART == 1) return 0;
                     LSTAMP(5);
-                                    // ---- collision round i: probe capsule vs the cap spheres of elements i G .. i G + G - 1 (one per lane); the wave
+                                    // ---- collision round i: probe blade vs the capsules of elements i G .. i G + G - 1 (one per lane); the wave
                     //      ballot gives every hit its slot so that the contact list stays sorted by ascending shell id.  Straight-line code
                     //      (a miss writes its record to a spare slot), so that the rounds can be scheduled between the matrix instructions
-                    //      of the lattice solve ----
-                    f3 cc = Kx - Ksz * C.probe_r;                       // capsule centre one radius behind the tip
-                    f3 p1 = cc - Ksy * C.probe_hl, d1 = Ksy * (2.f * C.probe_hl);
-                    const float inv_dd = rcp_(dot(d1, d1));
+                    //      of the lattice solve.  Element = capsule (soft_box.xml:10): axis segment from the cap centre `tip` (t = 0) to the
+                    //      inner end (t = 1); the probe distance d(t) is convex along it.  With the slopes s0, s1 at the two ends, t minimises the
+                    //      quadratic model d0 + s0 t + (s1 - s0 + eps) t^2 / 2 on [0, 1]; eps settles the point near the cap when the shaft lies
+                    //      flat against a flank of the probe (every point equally close: the plain minimiser would be ill-conditioned) ----
+                    const f3 Ksx = cross(Ksy, Ksz);
                     int nc = 0;
                     auto collide_round = [&](const int i) {
                         const int eraw = i * G + gl, e = eraw < N_TOP ? eraw : N_TOP - 1;
                         const f3 ax = mk(lds[TB_AXIS + 3 * e], lds[TB_AXIS + 3 * e + 1], lds[TB_AXIS + 3 * e + 2]);
                         const float se = live ? s_pre[i] : 0.f;                        // element i G + gl is this lane's own
-                        // element collision geometry = the cap sphere (centre `tip`, radius ELEM_R); DESIGN.md section 2
                         const f3 tip = mk(M.torso[0] + lds[TB_POS + 3 * e], M.torso[1] + lds[TB_POS + 3 * e + 1], M.torso[2] + lds[TB_POS + 3 * e + 2] + dz) + ax * (se - ELEM_R);
-                        const f3 c1 = madd(p1, d1, clampf(dot(d1, tip - p1) * inv_dd, 0.f, 1.f));      // closest point of the probe segment
-                        const f3 dd = c1 - tip;
-                        const float len = sqrt_(dot(dd, dd));
-                        const float dist = len - (C.probe_r + ELEM_R);
+                        const f3 rel = tip - Kx;
+                        const f3 p0 = mk(dot(Ksx, rel), dot(Ksy, rel), dot(Ksz, rel));               // site frame
+                        const f3 us = mk(dot(Ksx, ax), dot(Ksy, ax), dot(Ksz, ax)) * (-2.f * ELEM_HL);
+                        f3 g0, g1, gs;
+                        const float d0 = probe_sdf(C, p0, g0), s0 = dot(g0, us);
+                        const float d1 = probe_sdf(C, p0 + us, g1), s1 = dot(g1, us);
+                        const float tt = clampf(-s0 * rcp_(fmaxf(s1 - s0, 0.f) + SHAFT_EPS), 0.f, 1.f);
+                        const float dist = probe_sdf(C, madd(p0, us, tt), gs) - ELEM_R;
                         const bool hit = (eraw < N_TOP) && (dist < 0.f);
-                        const f3 nn = (len > 1e-9f) ? dd * rcp_(len) : mk(0, 0, 1);
-                        const f3 rr = tip + nn * (ELEM_R + 0.5f * dist) - Kx;
+                        const f3 nn = (Ksx * gs.x + Ksy * gs.y + Ksz * gs.z) * -1.f;                 // from the element towards the probe
+                        const f3 rr = madd(tip, ax, -2.f * ELEM_HL * tt) + nn * (ELEM_R + 0.5f * dist) - Kx;
                         const unsigned long long bal = __ballot(hit);
                         const unsigned gm = (unsigned)(bal >> gbase) & ((1u << G) - 1u);
                         const int slot = nc + __popc(gm & ((1u << gl) - 1u));
@@ -623,9 +657,9 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
 #pragma unroll
         for (int v = 0; v < F_NSCALAR / 4; ++v) { const float4 x = sp[v]; sv[4 * v] = x.x; sv[4 * v + 1] = x.y; sv[4 * v + 2] = x.z; sv[4 * v + 3] = x.w; }
     }
-    float q[NJ], qd[NJ], q0[NJ];
+    float q[NJ], qd[NJ], q0[NJ], dq[NJ];             // the joint words of the state hold dq = q - q0 (usim_device.h)
 #pragma unroll
-    for (int i = 0; i < NJ; ++i) { q[i] = sv[F_Q + i]; qd[i] = sv[F_QD + i]; q0[i] = sv[F_Q0 + i]; }
+    for (int i = 0; i < NJ; ++i) { dq[i] = sv[F_Q + i]; qd[i] = sv[F_QD + i]; q0[i] = sv[F_Q0 + i]; q[i] = q0[i] + dq[i]; }
     f3 ts = mk(sv[F_TS], sv[F_TS + 1], sv[F_TS + 2]), te = mk(sv[F_TE], sv[F_TE + 1], sv[F_TE + 2]);
     float u0 = sv[F_U0], vbar = sv[F_VBAR], fzbar = sv[F_FZBAR], fzprev = sv[F_FZPREV], dfz = sv[F_DFZ];
     float kst = sv[F_KST], kdmp = sv[F_KDMP], mu = sv[F_MU], epret = sv[F_EPRET];
@@ -764,7 +798,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < NJ; ++i) { q0[i] = q[i]; qd[i] = 0.f; }
+                for (int i = 0; i < NJ; ++i) { q0[i] = q[i]; qd[i] = 0.f; dq[i] = 0.f; }
                 t = 0; touched = 0; fzprev = 0.f; dfz = 0.f; vbar = 0.f; epret = 0.f; status = 0;
             }
         } else {
@@ -1054,7 +1088,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                     for (int i = 0; i < NJ; ++i) rhs[i] = fmaf(-hd, xk[i], qacc[i]);
                 }
 #pragma unroll
-                for (int i = 0; i < NJ; ++i) { qd[i] = fmaf(dt, rhs[i], qd[i]); q[i] = fmaf(dt, qd[i], q[i]); }
+                for (int i = 0; i < NJ; ++i) { qd[i] = fmaf(dt, rhs[i], qd[i]); dq[i] = fmaf(dt, qd[i], dq[i]); q[i] = q0[i] + dq[i]; }
                 // hand velocity: Jacobian from before the integration, qvel from after (mj_step data semantics)
                 float vs2[6];
 #pragma unroll
@@ -1186,7 +1220,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
         episode += 1;
         const int sl = episode & (BANK_DEPTH - 1);
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) { q[i] = BK(sl, BQ0 + i); q0[i] = q[i]; qd[i] = 0.f; }
+        for (int i = 0; i < NJ; ++i) { q[i] = BK(sl, BQ0 + i); q0[i] = q[i]; qd[i] = 0.f; dq[i] = 0.f; }
         ts = mk(BK(sl, BTS), BK(sl, BTS + 1), BK(sl, BTS + 2)); te = mk(BK(sl, BTE), BK(sl, BTE + 1), BK(sl, BTE + 2));
         u0 = BK(sl, BU0); kst = BK(sl, BKST); kdmp = BK(sl, BKDMP); mu = BK(sl, BMU); fzbar = BK(sl, BFZ);
         t = 0; touched = 0; fzprev = 0.f; dfz = 0.f; vbar = 0.f; epret = 0.f; status = BKI(sl, BSTATUS);
@@ -1208,7 +1242,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
             // constants only when an episode starts
             float o[F_NSCALAR];
 #pragma unroll
-            for (int i = 0; i < NJ; ++i) { o[F_Q + i] = q[i]; o[F_QD + i] = qd[i]; o[F_Q0 + i] = q0[i]; }
+            for (int i = 0; i < NJ; ++i) { o[F_Q + i] = dq[i]; o[F_QD + i] = qd[i]; o[F_Q0 + i] = q0[i]; }
             o[F_TS] = ts.x; o[F_TS + 1] = ts.y; o[F_TS + 2] = ts.z; o[F_TE] = te.x; o[F_TE + 1] = te.y; o[F_TE + 2] = te.z;
             o[F_U0] = u0; o[F_VBAR] = vbar; o[F_FZBAR] = fzbar; o[F_FZPREV] = fzprev; o[F_DFZ] = dfz;
             o[F_KST] = kst; o[F_KDMP] = kdmp; o[F_MU] = mu; o[F_EPRET] = epret;

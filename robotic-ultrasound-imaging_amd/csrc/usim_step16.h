@@ -214,8 +214,11 @@ DI void step16_body(float* lds, const DevModel& M, const DevCfg& C, float* __res
     const float* const sp = st + scalar_index(0, (size_t)ei);
     const bool jlane = at[AT_JOINT] != 0.f;                       // lanes that own a joint (a chain of fewer than seven joints pads with locked ones)
     const int jl = jlane ? gl : NJ - 1;
-    float qj = sp[F_Q + jl], qdj = sp[F_QD + jl], q0j = sp[F_Q0 + jl];
-    if (!jlane) { qj = 0.f; qdj = 0.f; q0j = 0.f; }
+    // the joint words of the state hold dq = q - q0 (usim_device.h): the per-step increment dt qd is then rounded at the magnitude of the
+    // excursion (~0.05 rad), not of the angle (~3 rad) -- the rounding of q would otherwise accumulate to micrometres at the probe over 200 steps
+    float dqj = sp[F_Q + jl], qdj = sp[F_QD + jl], q0j = sp[F_Q0 + jl];
+    if (!jlane) { dqj = 0.f; qdj = 0.f; q0j = 0.f; }
+    float qj = q0j + dqj;
     float sv[20];                                                  // scalar words 20 .. 39
     {
         const float4* s4 = reinterpret_cast<const float4*>(sp + 20);
@@ -410,7 +413,7 @@ DI void step16_body(float* lds, const DevModel& M, const DevCfg& C, float* __res
             qj = jlane ? qj + dq : 0.f;
             group_sync();                                                // the scratch is rewritten by the next iteration / the forward pass
         }
-        q0j = qj; qdj = 0.f;
+        q0j = qj; qdj = 0.f; dqj = 0.f;
         t = 0; touched = 0; fzprev = 0.f; dfz = 0.f; vbar = 0.f; epret = 0.f; status = 0;
     }
 
@@ -784,8 +787,9 @@ DI void step16_body(float* lds, const DevModel& M, const DevCfg& C, float* __res
             // mj_Euler with implicit joint damping: (M + h D) x = M qacc, one fixed-point step on M^-1
             const float xk = row_times_joint<NJ>(Mi, qacc);
             const float rhs = fmaf(-dt * JOINT_DAMP, xk, qacc);
-            qdj = fmaf(dt, rhs, qdj); qj = fmaf(dt, qdj, qj);
-            if (!jlane) { qdj = 0.f; qj = 0.f; }
+            qdj = fmaf(dt, rhs, qdj); dqj = fmaf(dt, qdj, dqj);
+            if (!jlane) { qdj = 0.f; dqj = 0.f; }
+            qj = q0j + dqj;
             // hand velocity: Jacobian from before the integration, qvel from after (mj_step data semantics)
             const float v2_t = row_times_joint<NJ>(Jr, qdj);
             float v2[6];
@@ -895,7 +899,7 @@ DI void step16_body(float* lds, const DevModel& M, const DevCfg& C, float* __res
         // ================= auto-reset: adopt the initial state prepared in the reset bank and queue the slot for refill =================
         episode += 1;
         const int sl = episode & (BANK_DEPTH - 1);
-        qj = jlane ? BK(sl, BQ0 + jl) : 0.f; q0j = qj; qdj = 0.f;
+        qj = jlane ? BK(sl, BQ0 + jl) : 0.f; q0j = qj; qdj = 0.f; dqj = 0.f;
         ts = mk(BK(sl, BTS), BK(sl, BTS + 1), BK(sl, BTS + 2)); te = mk(BK(sl, BTE), BK(sl, BTE + 1), BK(sl, BTE + 2));
         u0 = BK(sl, BU0); kst = BK(sl, BKST); kdmp = BK(sl, BKDMP); mu = BK(sl, BMU); fzbar = BK(sl, BFZ);
         t = 0; touched = 0; fzprev = 0.f; dfz = 0.f; vbar = 0.f; epret = 0.f; status = BKI(sl, BSTATUS);
@@ -912,7 +916,7 @@ DI void step16_body(float* lds, const DevModel& M, const DevCfg& C, float* __res
     if (valid && (MODE == 0 || (need && !refill))) {
         float* const so = st + scalar_index(0, (size_t)ei);
         if (jlane) {
-            so[F_Q + gl] = qj; so[F_QD + gl] = qdj;
+            so[F_Q + gl] = dqj; so[F_QD + gl] = qdj;
             if (need) so[F_Q0 + gl] = q0j;
         }
         if (gl == 0) {

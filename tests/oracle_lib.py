@@ -27,7 +27,7 @@ class OracleConfig(C.Structure):
         "initial_probe_pos_randomization", "friction_randomization", "torso_drop", "pgs_iters", "ik_iters", "env_offset", "torso_shape", "robot")] + \
         [("seed", C.c_uint64)] + [(n, C.c_double) for n in (
             "control_dt", "kp_fixed", "damping_ratio", "kp_min", "kp_max", "out_max_pos", "out_max_ori", "stiffness",
-            "damping", "elem_friction", "probe_friction", "probe_radius", "probe_halflen")]
+            "damping", "elem_friction", "probe_friction", "probe_radius", "probe_halflen", "probe_radius2", "probe_height")]
 
 
 def build_oracle(native=False):
@@ -142,11 +142,12 @@ class Oracle:
 
     def last_info(self):
         """per env: cause bitmask (1 horizon, 2 joint limit, 4 position, 8 orientation, 16 lost contact), pos_err_norm,
-        ori_err, joint-limit margin, smallest |contact distance|, ncon, reward"""
+        ori_err, joint-limit margin, smallest |contact distance|, ncon, reward, and -- for an env that was auto-reset in the step -- the
+        smallest |contact distance| / slot-selection gap of the reset's forward pass (1e9 otherwise)"""
         out = np.zeros((self.n, 8))
         self.lib.uso_last_info(self.h, _ptr(out))
         return {"cause": out[:, 0].astype(int), "pos_err": out[:, 1], "ori_err": out[:, 2], "joint_margin": out[:, 3],
-                "contact_margin": out[:, 4], "ncon": out[:, 5].astype(int), "reward": out[:, 6]}
+                "contact_margin": out[:, 4], "ncon": out[:, 5].astype(int), "reward": out[:, 6], "reset_margin": out[:, 7]}
 
     def debug_forward(self, env=0):
         out = np.zeros(128)

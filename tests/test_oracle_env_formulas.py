@@ -106,29 +106,59 @@ def test_reset_position_noise_statistics(pins):
     assert np.all(np.abs(ref.std(0) / d.std(0) - 1) < 0.3)
 
 
-def test_reset_force_depth_relation(pins):
-    """Contact onset and force-vs-depth at reset against the pooled reference rows:
-    no contact above z_err ~ 0.0146+, Fz ~ -4372 z_err + 57.9 N over the contacting rows."""
-    ref = np.concatenate([pins[m + "_reset_obs"] for m in ("tracking", "variable_z", "wrench")])
-    o = Oracle(4096)
-    obs = o.reset()
+REF_MODELS = ("tracking", "variable_z", "wrench")
+DEPTH_BINS = ((-0.030, -0.015), (-0.015, -0.005), (-0.005, 0.0), (0.0, 0.005), (0.005, 0.010), (0.010, 0.015))
+
+
+def check_reset_rows_against_reference(obs, ref):
+    """Shared by the oracle test below and its GPU twin (tests/test_gpu_properties.py): the six force / torque channels of a batch of
+    reset observations against the 192 reset rows decoded from the reference checkpoints (calibration record
+    profiles/r03/calib_probe.txt, tools/calib_probe.py).  Bands: +-30 % on the spread of Fx, Fz, torque x, torque y, +-25 % + 2 N on
+    the binned force-depth curve.  KNOWN GAP, asserted at its measured size so that it cannot grow silently: the spread of Fy (reference
+    8.4 N, here 3.8 N) and of the torque about the probe axis (0.33 vs 0.09 N m) -- the reference's lateral forces act through
+    fewer, stronger contacts than this lattice + primitive probe produces."""
     z, fz = obs[:, 14], obs[:, 2]
     rz, rfz = ref[:, 14], ref[:, 2]
-    # onset: first contact where the eef site reaches the nominal top surface (torso centre + 0.0525 -> z_err 0.0135)
-    assert 0.0125 < z[fz > 0].max() < 0.0185
+    # onset: first contact where the eef site reaches the nominal top surface (torso centre + 0.0525 -> z_err 0.0135);
+    # tilted outboard elements stand a little higher (reference: last contact at 0.0166)
     assert rz[rfz > 0].max() < 0.0185
-    assert np.all(fz[z > 0.0185] == 0)
-    # binned force-depth curve in the range where the reference has dense data
-    for lo, hi in ((-0.005, 0.0), (0.0, 0.005), (0.005, 0.010), (0.010, 0.015)):
+    assert 0.0125 < np.quantile(z[fz > 0], 0.995) < 0.0185 and z[fz > 0].max() < 0.0200
+    assert np.all(fz[z > 0.0200] == 0)
+    # binned force-depth curve, including the deep rows (reference: 167 N at 15 .. 30 mm below the trajectory height)
+    for lo, hi in DEPTH_BINS:
         m, r = (z >= lo) & (z < hi), (rz >= lo) & (rz < hi)
-        assert r.sum() >= 20
+        assert r.sum() >= 6 and m.sum() >= 30
         ours, theirs = fz[m].mean(), rfz[r].mean()
-        assert abs(ours - theirs) < 0.45 * theirs + 3.0, (lo, hi, ours, theirs)
-    # overall slope of the contacting rows, shallow-to-moderate penetration
-    sel = (fz > 0) & (z > -0.010)
-    rsel = (rfz > 0) & (rz > -0.010)
+        assert abs(ours - theirs) < 0.25 * theirs + 2.0, (lo, hi, ours, theirs)
+    sel, rsel = (fz > 0) & (z > -0.010), (rfz > 0) & (rz > -0.010)
     slope, slope_ref = np.polyfit(z[sel], fz[sel], 1)[0], np.polyfit(rz[rsel], rfz[rsel], 1)[0]
-    assert 0.6 < slope / slope_ref < 1.4, (slope, slope_ref)
+    assert 0.75 < slope / slope_ref < 1.25, (slope, slope_ref)
+    c, rc = fz > 0.5, rfz > 0.5
+    assert abs(c.mean() - rc.mean()) < 0.06                                   # fraction of resets that start in contact (0.80)
+    F, T, RF, RT = obs[c, 0:3], obs[c, 3:6], ref[rc, 0:3], ref[rc, 3:6]
+    ratio_F, ratio_T = F.std(0) / RF.std(0), T.std(0) / RT.std(0)
+    assert 0.70 < ratio_F[0] < 1.30 and 0.70 < ratio_F[2] < 1.30, ratio_F     # Fx 13.2 N, Fz 38.3 N
+    assert 0.70 < ratio_T[0] < 1.30 and 0.70 < ratio_T[1] < 1.30, ratio_T     # torque x 0.29, y 0.27 N m
+    assert 0.40 < ratio_F[1] < 1.30, ratio_F                                  # known gap: Fy 8.4 N
+    assert 0.22 < ratio_T[2] < 1.30, ratio_T                                  # known gap: torque z 0.33 N m
+    # the systematic part: the torso pushes the probe towards its centre line, x is sampled off-centre (ultrasound.py:787) => mean Fx < 0,
+    # the more so the deeper; Fy has no preferred sign
+    assert -1.3 * 5.59 < F[:, 0].mean() < -0.4 * 5.59 and abs(F[:, 1].mean()) < 2.5
+    assert np.corrcoef(F[:, 0], F[:, 2])[0, 1] < -0.25                        # reference -0.58
+    assert abs(F[:, 2].mean() - RF[:, 2].mean()) < 0.2 * RF[:, 2].mean()
+    lat, rlat = np.hypot(F[:, 0], F[:, 1]) / F[:, 2], np.hypot(RF[:, 0], RF[:, 1]) / RF[:, 2]
+    assert 0.5 < np.median(lat) / np.median(rlat) < 1.3                       # reference 0.38
+    q99, rq99 = np.quantile(np.abs(F[:, 0]), 0.99), np.quantile(np.abs(RF[:, 0]), 0.99)
+    assert 0.7 < q99 / rq99 < 1.3                                             # lateral |Fx| up to 35-44 N
+    # (not pinned: the torque channels WITHOUT contact, reference (0.091, -0.033, -0.007) N m at reset while the arm sags under zero control;
+    #  the stand-in centre of mass of the probe is chosen for the torque under the tracking policy instead, DESIGN.md section 6)
+
+
+def test_reset_forces_and_torques_against_reference_rows(pins):
+    """Contact onset, force-vs-depth and the spread of all six force / torque channels at reset against the pooled reference rows."""
+    ref = np.concatenate([pins[m + "_reset_obs"] for m in REF_MODELS])
+    o = Oracle(4096)
+    check_reset_rows_against_reference(o.reset(), ref)
 
 
 def test_trajectory_sampling_grid():
