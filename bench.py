@@ -26,7 +26,8 @@ ALGO_BYTES = {"rigid": 316, "soft": 1912}
 # algorithmic flops per env-step of this build's step
 ALGO_FLOPS = {"rigid": 9.0e3, "soft": 5.5e4}
 WORKLOAD_NAME = {"rigid": "configs[1]: 4096 envs/GPU, rigid torso (contact solver off), OSC controller only",
-                 "soft": "configs[2]: 4096 envs/GPU, soft-torso contact + force/velocity-tracking reward"}
+                 "soft": "configs[2]: 4096 envs/GPU, soft-torso contact + force/velocity-tracking reward",
+                 "randomised": "configs[4]: 8192 envs/GPU with domain-randomised torso stiffness/damping + probe friction"}
 
 
 def cpu_baseline(workload, n_envs, budget_s=float(os.environ.get("USIM_CPU_BUDGET_S", "15"))):
@@ -69,6 +70,11 @@ def main():
     ap.add_argument("--randomize", action="store_true", help="BASELINE configs[4]: per-env randomised stiffness/damping + probe friction")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--adaptive", action="store_true", help="N > 1: start every block with the collective-tolerant mapping only for as long as the previous "
+                    "block's all-gather took, then switch to the split kernel (default: the collective-tolerant mapping for the whole block)")
+    ap.add_argument("--gather", choices=["rccl", "p2p"], default="rccl", help="N > 1: RCCL all-gather (resident workgroups on the CUs) or peer-to-peer copies "
+                    "of the packed block (copy engines, no CUs; distributed.P2PRolloutGather)")
+    ap.add_argument("--steps-per-launch", type=int, default=0, help="consecutive steps per kernel launch of the rollout (1 .. 64; default: the library's, 64)")
     ap.add_argument("--lanes-per-env", type=int, default=0, choices=[0, 1, 8, 16, 32], help="kernel mapping: 16 lanes per environment (automatic), 8 (soft torso) or 1 (rigid torso)")
     args = ap.parse_args()
 
@@ -95,18 +101,24 @@ def main():
     n = args.envs_per_gpu
     extra = {"friction_randomization": 1} if args.randomize else {}
     with_gather = use_dist and not args.no_gather
-    # N > 1, soft torso: the resident workgroups of the overlapped all-gather push part of every step of the split kernel (and of the
+    # N > 1, soft torso: the resident workgroups of an overlapped RCCL all-gather push part of every step of the split kernel (and of the
     # one-wave-per-SIMD budget) into a second round (tools/gpu_interference.py: 19.9 -> 30 us/step), the two-waves-per-SIMD 16-lane build
-    # lets the displaced workgroups double up on other CUs (22.7 -> 26-29 us).  The mappings compute the same bits, so every block starts
-    # with the robust build for as long as the previous gather took (measured with events on the gather's stream) and finishes with the
-    # split kernel.
-    adaptive = with_gather and args.workload == "soft" and args.lanes_per_env == 0 and n <= 4096
+    # lets the displaced workgroups double up on other CUs (22.7 -> 26-29 us).  The mappings compute the same bits.  Default ("plain"): the
+    # collective-tolerant mapping for the whole run.  --adaptive: every block starts with it for as long as the previous gather took
+    # (events on the gather's stream) and finishes with the split kernel -- tuned on a stand-in kernel, never run next to real peers, hence
+    # opt-in.  --gather p2p moves the blocks with the copy engines instead: no CUs taken, the split kernel runs throughout.
+    tolerant = with_gather and args.gather == "rccl" and args.workload == "soft" and args.lanes_per_env == 0 and n <= 4096
+    adaptive = tolerant and args.adaptive
     if args.lanes_per_env:
         extra["lanes_per_env"] = args.lanes_per_env
     env = usim.UltrasoundVecEnv(n, device=device, seed=3, env_offset=rank * n, torso=args.workload, **extra, **usim.default_robosuite_kwargs())
     T = max(1, min(args.block, args.steps))
     blocks = [env.alloc_block(T), env.alloc_block(T)]      # double-buffered: gather block b while simulating b^1
-    gather = dmod.RolloutGather(device=device) if with_gather else None
+    gather = (dmod.P2PRolloutGather(device=device) if args.gather == "p2p" else dmod.RolloutGather(device=device)) if with_gather else None
+    if args.steps_per_launch:
+        env.set_steps_per_launch(args.steps_per_launch)
+    if tolerant and not adaptive:
+        env.set_mapping(16, 2)
 
     env.reset_tensor()
     step = 0
@@ -193,17 +205,22 @@ def main():
     valu_tflops = ALGO_FLOPS[args.workload] * n / avg_kernel_s / 1e12
 
     traffic = None
-    tfile = next((f for f in (ROOT / "profiles" / r / "traffic.json" for r in ("r02", "r01")) if f.exists()), ROOT / "profiles" / "r02" / "traffic.json")
+    tfile = next((f for f in (ROOT / "profiles" / r / "traffic.json" for r in ("r03", "r02", "r01")) if f.exists()), ROOT / "profiles" / "r03" / "traffic.json")
     if tfile.exists() and n == 4096:
         try:
             tj = json.loads(tfile.read_text()).get(args.workload)
             if tj:
-                traffic = (tj["fetch_kb"] + tj["write_kb"]) * 1024.0      # bytes per launch, committed PMC profile of this command
+                traffic = (tj["fetch_kb"] + tj["write_kb"]) * 1024.0      # bytes per env-step batch (one step of all envs), committed PMC profile of this command
         except Exception:
             traffic = None
 
     # the mapping usim_create picks (csrc/usim_api.hip): soft torso up to 4096 envs -> two waves per quad of environments (32 lanes per env)
     lanes = int(extra.get("lanes_per_env", 0)) or (32 if (args.workload == "soft" and n <= 4096 and not extra.get("waves_per_simd")) else 16)
+    if tolerant and not adaptive:
+        lanes = 16
+    spl = env.steps_per_launch if lanes in (16, 32) else 1        # consecutive steps per kernel launch (usim_set_steps_per_launch)
+    spl = max(1, min(spl, T, args.steps))
+    wl = "randomised" if (args.randomize and args.workload == "soft" and n == 8192) else args.workload
     if rank == 0:
         total_steps = args.steps * n * world
         out = {
@@ -211,15 +228,20 @@ def main():
             "value": total_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOAD_NAME[args.workload], "envs_per_gpu": n, "global_envs": n * world,
+            "config": {"workload": WORKLOAD_NAME[wl], "envs_per_gpu": n, "global_envs": n * world,
                        "controller": "OSC_POSE impedance_mode=tracking", "rollout_block": T, "domain_randomisation": "stiffness+damping" + ("+friction" if args.randomize else ""),
-                       "parallelism": f"env-shard x{world}" + (" + RCCL all-gather of transition blocks" if gather is not None else ""),
+                       "parallelism": f"env-shard x{world}" + ("" if gather is None else (" + RCCL all-gather of transition blocks" if args.gather == "rccl" else
+                                                                 " + peer-to-peer copies of transition blocks (copy engines)")),
+                       "gather": None if gather is None else args.gather, "mapping_next_to_gather": None if gather is None else ("adaptive" if adaptive else "plain"),
+                       "steps_per_launch": spl,
                        "lanes_per_env": lanes if not adaptive else "32, and 16 (two waves per SIMD) while the previous block is gathered",
                        "waves_per_simd": int(extra.get("waves_per_simd", 0)) or "auto"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": f"{tfile.relative_to(ROOT)} (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch)" if traffic else None,
-                         "algorithmic_bytes_per_launch": ALGO_BYTES[args.workload] * n, "algorithmic_bytes_per_env_step": ALGO_BYTES[args.workload],
-                         "avg_kernel_us": avg_kernel_s * 1e6, "kernel": {32: "usim_step32_kernel", 16: "usim_step16_kernel"}.get(lanes, "usim_step_kernel"),
+                         "traffic": traffic, "traffic_source": f"{tfile.relative_to(ROOT)} (rocprofv3 FETCH_SIZE + WRITE_SIZE, per step of all environments; multiply by steps_per_launch for a launch)" if traffic else None,
+                         # one launch advances all n environments by `steps_per_launch` steps; achieved = algorithmic bytes per launch / launch duration
+                         "algorithmic_bytes_per_launch": ALGO_BYTES[args.workload] * n * spl, "algorithmic_bytes_per_env_step": ALGO_BYTES[args.workload],
+                         "steps_per_launch": spl, "avg_launch_us": avg_kernel_s * 1e6 * spl,
+                         "avg_kernel_us": avg_kernel_s * 1e6, "kernel": {32: "usim_step32_kernel", 16: "usim_step16_kernel"}.get(lanes, "usim_step_kernel") + ("<multi-step>" if spl > 1 else ""),
                          "valu_fp32_tflops": valu_tflops, "valu_frac": valu_tflops / FP32_VALU_PEAK_TFLOPS,
                          "note": "kernel is FP32-VALU/latency bound at 4096 envs (one or two waves per SIMD, serial per-environment chain), not HBM bound; see DESIGN.md section 5"},
         }

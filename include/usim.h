@@ -152,6 +152,11 @@ int usim_random_actions(usim_handle* h, int64_t step, float* act_dev, void* stre
  * slice k (SB3 RolloutBuffer layout, the unit that is all-gathered across GPUs). */
 int usim_rollout_random(usim_handle* h, int64_t first_step, int nsteps, const usim_step_io* io, int block_advance, void* stream);
 
+/* usim_rollout_random enqueues its steps in launches of up to `steps` consecutive steps each (1 .. 64, default 64; the 16- and 32-lane
+ * mappings -- the others always launch step by step): inside a launch the lattice tables stay in LDS and launch latency is paid once, every
+ * step still reads and writes its state and its slice of the rollout block in HBM.  The results do not depend on the value (bit for bit). */
+int usim_set_steps_per_launch(usim_handle* h, int steps);
+
 /* Like usim_rollout_random, bracketed by HIP events on `stream`; blocks until done and returns the elapsed
  * device time in milliseconds (bench.py roofline leg). */
 int usim_time_steps(usim_handle* h, int64_t first_step, int nsteps, const usim_step_io* io, int block_advance, void* stream, float* elapsed_ms);

@@ -11,6 +11,6 @@ from .config import default_robosuite_kwargs, load_yaml, make_config
 from .spaces import Box
 from .vec_env import UltrasoundEnv, UltrasoundVecEnv
 
-from . import episode_log, policy  # noqa: E402  (checkpoint readers, on-device VecNormalize, MLP policy replay)
+from . import episode_log, error_metrics, policy  # noqa: E402  (checkpoint readers, on-device VecNormalize, MLP policy replay, CSV dump, error metrics)
 
-__all__ = ["UltrasoundVecEnv", "UltrasoundEnv", "Box", "default_robosuite_kwargs", "load_yaml", "make_config", "policy", "episode_log", "_lib"]
+__all__ = ["UltrasoundVecEnv", "UltrasoundEnv", "Box", "default_robosuite_kwargs", "load_yaml", "make_config", "policy", "episode_log", "error_metrics", "_lib"]

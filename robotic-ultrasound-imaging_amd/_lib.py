@@ -45,6 +45,7 @@ SYMBOLS = {
     "usim_create": (C.c_int, [C.POINTER(UsimConfig), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "usim_destroy": (None, [C.c_void_p]),
     "usim_set_mapping": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "usim_set_steps_per_launch": (C.c_int, [C.c_void_p, C.c_int]),
     "usim_num_envs": (C.c_int, [C.c_void_p]),
     "usim_action_dim": (C.c_int, [C.c_void_p]),
     "usim_num_elements": (C.c_int, [C.c_void_p]),

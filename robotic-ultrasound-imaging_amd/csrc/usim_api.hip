@@ -32,6 +32,7 @@ struct usim_handle {
     int2* d_items = nullptr;          // refill work list, capacity 2 * n * BANK_DEPTH
     int* d_count = nullptr;           // [0] items, [1] finished workgroups of the running refill
     long long steps_since_refill = 0;
+    int steps_per_launch = 64;      // usim_rollout_random: consecutive steps per launch of the 16-lane kernels (USIM_STEPS_PER_LAUNCH overrides, 1 .. 64)
     int bank_row0 = 0;
     size_t lds_bytes = 0, lds16_bytes = 0, lds32_bytes = 0;
     std::string hip_err;
@@ -220,7 +221,8 @@ static hipError_t launch_step(usim_handle* h, const DevIO& io, int flags, long l
 template <int TORSO, int OCC, int MODE>
 static hipError_t launch_step16(usim_handle* h, const DevIO& io, int flags, long long rstep, hipStream_t s) {
     dim3 grid((h->n + 15) / 16), block(256);
-    hipLaunchKernelGGL((usim_step16_kernel<TORSO, OCC, MODE>), grid, block, h->lds16_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
+    if (MODE == 0 && io.nsub > 1) hipLaunchKernelGGL((usim_step16_kernel<TORSO, OCC, MODE, MODE == 0>), grid, block, h->lds16_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
+    else hipLaunchKernelGGL((usim_step16_kernel<TORSO, OCC, MODE, false>), grid, block, h->lds16_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
     return hipGetLastError();
 }
 
@@ -232,7 +234,8 @@ static int launch(usim_handle* h, DevIO io, int flags, long long rstep, hipStrea
     // kernels of usim_kernels.hip
     if (h->lpe == 32 && MODE == 0) {
         dim3 grid((h->n + 15) / 16), block(512);
-        hipLaunchKernelGGL(usim_step32_kernel, grid, block, h->lds32_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
+        if (io.nsub > 1) hipLaunchKernelGGL(usim_step32_kernel<true>, grid, block, h->lds32_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
+        else hipLaunchKernelGGL(usim_step32_kernel<false>, grid, block, h->lds32_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
         e = hipGetLastError();
     } else if (h->lpe == 16 || h->lpe == 32) {
         // (reset computations are not register-critical: always the two-waves-per-SIMD build)
@@ -296,6 +299,7 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
         const int shape = cfg->torso_shape ? 1 : 0;
         C.top_off = (float)kTopOff[shape]; C.y_range = (float)kYRange[shape]; C.drop = (float)(kTorsoZ[shape] - 0.0525 - 0.8);
     }
+    if (const char* spl = std::getenv("USIM_STEPS_PER_LAUNCH")) { const int v = std::atoi(spl); if (v >= 1 && v <= BANK_DEPTH) h->steps_per_launch = v; }
     h->nfields = h->n_el ? F_TOTAL_TOP : F_NSCALAR;
     h->bank_row0 = h->nfields;                                  // two reset-bank slots follow the live state rows
     size_t bytes = (size_t)(h->nfields + BANK_ROWS) * h->npad * sizeof(float);
@@ -321,10 +325,13 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
     h->lds16_bytes = h->n_el ? (size_t)GroupGeom<16>::LDS_WORDS * sizeof(float) : (size_t)16 * X16_RIGID_STRIDE * sizeof(float);
     h->lds32_bytes = (size_t)(X2_BASE + 16 * X2_STRIDE) * sizeof(float);
     if (h->n_el) {
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds32_bytes));
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step16_kernel<1, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds16_bytes));
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step16_kernel<1, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds16_bytes));
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step16_kernel<1, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds16_bytes));
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds32_bytes));
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds32_bytes));
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step16_kernel<1, 1, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds16_bytes));
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step16_kernel<1, 1, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds16_bytes));
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step16_kernel<1, 2, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds16_bytes));
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step16_kernel<1, 2, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds16_bytes));
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step16_kernel<1, 2, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds16_bytes));
     }
     h->lds_bytes = 0;
     if (h->n_el && h->lpe == 8) {
@@ -353,6 +360,12 @@ int usim_set_mapping(usim_handle* h, int lanes_per_env, int waves_per_simd) {
     if (!h || !h->n_el || h->lpe == 8 || (lanes_per_env != 16 && lanes_per_env != 32) || waves_per_simd < 0 || waves_per_simd > 2) return USIM_ERR_INVALID;
     h->lpe = lanes_per_env;
     h->occ = waves_per_simd ? waves_per_simd : (h->n <= 4096 ? 1 : 2);
+    return USIM_OK;
+}
+
+int usim_set_steps_per_launch(usim_handle* h, int steps) {
+    if (!h || steps < 1 || steps > BANK_DEPTH) return USIM_ERR_INVALID;
+    h->steps_per_launch = steps;
     return USIM_OK;
 }
 
@@ -441,16 +454,25 @@ int usim_rollout_random(usim_handle* h, int64_t first_step, int nsteps, const us
     if (rc) return rc;
     io.act = nullptr;
     const size_t n = (size_t)h->n;
-    for (int k = 0; k < nsteps; ++k) {
+    // the 16-lane kernels run up to h->steps_per_launch consecutive steps per launch (usim_step16.h step16_body); a launch never crosses the
+    // refill period of the reset bank (an environment consumes at most one ring slot per step)
+    const int kmax = (h->lpe == 16 || h->lpe == 32) ? h->steps_per_launch : 1;
+    for (int k = 0; k < nsteps;) {
+        int kk = nsteps - k < kmax ? nsteps - k : kmax;
+        if (kk > BANK_DEPTH - (int)h->steps_since_refill) kk = BANK_DEPTH - (int)h->steps_since_refill;
+        io.nsub = kk; io.block = block_advance ? 1 : 0;
+        h->steps_since_refill += kk - 1;                      // (step_common counts the launch as one step)
         rc = step_common(h, io, LF_AUTO_RESET | LF_RANDOM_ACT, (long long)(first_step + k), stream);
         if (rc) return rc;
+        k += kk;
         if (block_advance) {
-            io.obs += n * OBS_DIM; io.rew += n; io.done += n;
-            if (io.term_obs) io.term_obs += n * OBS_DIM;
-            if (io.contacts) io.contacts += n * (1 + MAXC);
-            if (io.ep_ret) io.ep_ret += n;
-            if (io.ep_len) io.ep_len += n;
-            if (io.act_out) io.act_out += n * h->adim;
+            const size_t adv = n * (size_t)kk;
+            io.obs += adv * OBS_DIM; io.rew += adv; io.done += adv;
+            if (io.term_obs) io.term_obs += adv * OBS_DIM;
+            if (io.contacts) io.contacts += adv * (1 + MAXC);
+            if (io.ep_ret) io.ep_ret += adv;
+            if (io.ep_len) io.ep_len += adv;
+            if (io.act_out) io.act_out += adv * h->adim;
         }
     }
     return USIM_OK;

@@ -86,6 +86,9 @@ struct DevIO {
     int bank_row0;                  // first row of the reset bank inside the state block
     unsigned long long* dbg;        // phase timeline probe (diagnostics; nullptr in production launches)
     int refill;                     // reset launches: 0 = reset the live state of the masked envs, 1 = compute the listed bank episodes
+    int nsub;                       // step launches of the 16-lane kernels: consecutive steps per launch (0 / 1 = one); step k draws the actions of
+                                    // rstep + k and, with block != 0, writes slice k of rollout blocks [nsub][n][...]
+    int block;
 };
 
 enum LaunchFlags : int { LF_AUTO_RESET = 1, LF_RANDOM_ACT = 4 };

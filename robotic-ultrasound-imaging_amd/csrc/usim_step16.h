@@ -168,7 +168,8 @@ constexpr int X2_STRIDE = 164, MB_POSE = 64, MB_OP = 76, MB_W = 140;      // 64 
 static_assert(MB_W + 16 <= X2_STRIDE, "mailbox block");
 
 template <int TORSO, int MODE, int ROLE, int NT>
-DI void step16_body(float* lds, const DevModel& M, const DevCfg& C, float* __restrict__ st, const int n, const int npad, const DevIO& io, const int flags, const long long rstep) {
+DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __restrict__ st, const int n, const int npad, const DevIO& io, const int flags, const long long rstep,
+                   const bool first_pass) {
     constexpr int G = 16, EPW = 4, EPB = 16;
     constexpr int NE = TORSO ? (N_TOP + G - 1) / G : 1;
     static_assert(ROLE == 0 || (TORSO == 1 && MODE == 0), "the split kernel is the soft-torso step");
@@ -238,7 +239,7 @@ DI void step16_body(float* lds, const DevModel& M, const DevCfg& C, float* __res
         s_pre[i] = 0.f; sd_pre[i] = 0.f;
         if (TORSO && MODE == 0 && ROLE != 1 && e < N_TOP) { s_pre[i] = LAT(LAT_S + e); sd_pre[i] = LAT(LAT_SD + e); }
     }
-    if (TORSO != 0 && item0 == item_first) {
+    if (TORSO != 0 && item0 == item_first && first_pass) {
         // workgroup-resident copy of the lattice tables: 16-byte loads, all issued before the first LDS store (and behind the state loads
         // above, whose HBM latency the copy then covers)
         const float4* src = reinterpret_cast<const float4*>(M.tables);
@@ -949,20 +950,56 @@ DI void step16_body(float* lds, const DevModel& M, const DevCfg& C, float* __res
 #undef BKI
 }
 
-template <int TORSO, int OCC, int MODE>
+// One launch = io.nsub consecutive steps (usim_rollout_random: the actions are drawn in-kernel, so step k + 1 needs nothing from the host).
+// The lattice tables stay in LDS, launch latency and the kernel-argument / first-load round trip are paid once; every step still reads its
+// state from HBM and writes it back together with its slice of the transition block, so the algorithmic traffic per step is unchanged.
+template <int TORSO, int MODE, int ROLE, int NT, bool MULTI = false>
+DI void step16_body(float* lds, const DevModel& M, const DevCfg& C, float* __restrict__ st, const int n, const int npad, const DevIO& io0, const int flags, const long long rstep) {
+    // (MULTI is a template parameter: the single-step instantiation -- usim_step, a policy in the loop -- keeps the register allocation of a
+    // straight-line kernel; the loop costs it 2 us per step)
+    const int nsub = (MULTI && MODE == 0 && io0.nsub > 1) ? io0.nsub : 1;
+    DevIO io = io0;
+    for (int ks = 0; ks < nsub; ++ks) {
+        step16_one<TORSO, MODE, ROLE, NT>(lds, M, C, st, n, npad, io, flags, rstep + ks, ks == 0);
+        if (ks + 1 < nsub) {
+            // the next step reads the state words this one stored -- some through other lanes of the group, the per-episode scalars through the
+            // other wave of the pair (split kernel): order the stores, then meet.  (Both roles of the split kernel pass here once per step.)
+            __threadfence_block();
+            __syncthreads();
+            if (io0.block) {
+                const size_t nn = (size_t)n;
+                io.obs += nn * OBS_DIM; io.rew += nn; io.done += nn;
+                if (io.term_obs) io.term_obs += nn * OBS_DIM;
+                if (io.contacts) io.contacts += nn * (1 + MAXC);
+                if (io.ep_ret) io.ep_ret += nn;
+                if (io.ep_len) io.ep_len += nn;
+                if (io.act_out) io.act_out += nn * C.adim;
+            }
+        }
+    }
+}
+
+template <int TORSO, int OCC, int MODE, bool MULTI = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void usim_step16_kernel(const DevModel M, const DevCfg C, float* __restrict__ st, int n, int npad,
                                                                                                           const DevIO io, int flags, long long rstep) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    step16_body<TORSO, MODE, 0, 256>(lds, M, C, st, n, npad, io, flags, rstep);
+    step16_body<TORSO, MODE, 0, 256, MULTI>(lds, M, C, st, n, npad, io, flags, rstep);
 }
 
 // soft-torso step with two waves per quad of environments: waves 0-3 of the workgroup run the arm side, waves 4-7 the lattice / contact side
 // (wave w and wave w + 4 land on the same SIMD and fill each other's stalls: at 4096 envs/GPU a single wave issues only ~55 % of its cycles)
+// BARRIER INVARIANT (outside the HIP programming model; holds on gfx950 because s_barrier counts waves, not program points): the two roles
+// execute __syncthreads() at DIFFERENT program points, so both must execute exactly the same NUMBER of barriers on every path -- per step: the
+// table copy (first step of a launch), hand-offs (1)-(4) of step16_one, and the one between consecutive steps of a multi-step launch.  An
+// early return, a barrier under a branch that is not uniform over the whole workgroup, or a fifth hand-off on one side only would hang the
+// GPU instead of failing a test.  The profiling build counts the barriers of both roles (USIM_TSTAMP: dbg[29] / dbg[39]) and
+// tests/test_gpu_properties.py compares them; the split-vs-single-wave bit-exactness tests cover ragged workgroups and slot overflow.
+template <bool MULTI>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void usim_step32_kernel(const DevModel M, const DevCfg C, float* __restrict__ st, int n, int npad,
                                                                                                        const DevIO io, int flags, long long rstep) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    if (threadIdx.x < 256) step16_body<1, 0, 1, 512>(lds, M, C, st, n, npad, io, flags, rstep);
-    else step16_body<1, 0, 2, 512>(lds, M, C, st, n, npad, io, flags, rstep);
+    if (threadIdx.x < 256) step16_body<1, 0, 1, 512, MULTI>(lds, M, C, st, n, npad, io, flags, rstep);
+    else step16_body<1, 0, 2, 512, MULTI>(lds, M, C, st, n, npad, io, flags, rstep);
 }
 
 }  // namespace usim

@@ -97,3 +97,7 @@ class RolloutGather:
             # be handed to the next gather while the caller's kernels still read it
             out.record_stream(cur)
         return out
+
+
+class P2PRolloutGather(RolloutGather):
+    """placeholder until the peer-to-peer implementation lands (same interface)"""

@@ -70,21 +70,36 @@ def load_sb3_zip(path):
     return sd, data
 
 
-def save_sb3_zip(path, policy, data=None):
-    """Write `policy` (MlpActorCritic) in the on-disk layout of `PPO.save` (src/rl.py:157): zip{data json, policy.pth state dict under
-    SB3's layer names, pytorch_variables.pth, _stable_baselines3_version}.  `data` is the json dictionary of the checkpoint; pass the
-    one returned by load_sb3_zip for a reference checkpoint (it carries the serialized policy class and spaces PPO.load asks for) --
-    without it only the numeric hyper-parameters of src/rl.py are written, enough for load_sb3_zip / policy.load_state_dict."""
+def adam_state_dict(sd, step=0, lr=3e-4, eps=1e-5):
+    """`policy.optimizer.pth` of an SB3 PPO checkpoint: the state dict of torch.optim.Adam(lr 3e-4, eps 1e-5: SB3's PPO defaults, as stored in
+    the reference zips) over the policy parameters in state-dict order.  step == 0 writes a fresh optimizer (empty state)."""
+    names = list(sd)
+    state = {}
+    if step > 0:
+        state = {i: {"step": int(step), "exp_avg": torch.zeros_like(sd[k]), "exp_avg_sq": torch.zeros_like(sd[k])} for i, k in enumerate(names)}
+    return {"state": state, "param_groups": [{"lr": lr, "betas": (0.9, 0.999), "eps": eps, "weight_decay": 0, "amsgrad": False,
+                                               "params": list(range(len(names)))}]}
+
+
+def save_sb3_zip(path, policy, data=None, optimizer_state=None):
+    """Write `policy` (MlpActorCritic) in the on-disk layout of `PPO.save` (src/rl.py:157) -- the five members of the reference zips
+    (src/trained_rl_models/*.zip): data json, pytorch_variables.pth, policy.pth (state dict under SB3's layer names), policy.optimizer.pth
+    (Adam state dict: PPO.load -> set_parameters(exact_match=True) raises without it), _stable_baselines3_version.  `data` is the json
+    dictionary of the checkpoint; pass the one returned by load_sb3_zip for a reference checkpoint (it carries the serialized policy class and
+    spaces PPO.load asks for) -- without it only the numeric hyper-parameters of src/rl.py are written, enough for load_sb3_zip /
+    policy.load_state_dict.  `optimizer_state`: an Adam state dict (e.g. torch.optim.Adam(policy.parameters()).state_dict() mapped to SB3's
+    parameter order); default a fresh optimizer."""
     sd = policy.to_sb3_state_dict()
     if data is None:
         data = {"gamma": 0.99, "gae_lambda": 0.95, "n_steps": 2048, "n_envs": None,
                 "policy_kwargs": {"activation_fn": "tanh", "net_arch": [{"pi": list(policy.pi_sizes), "vf": list(policy.vf_sizes)}]}}
-    buf, var = io.BytesIO(), io.BytesIO()
-    torch.save(sd, buf); torch.save(None, var)
+    buf, var, opt = io.BytesIO(), io.BytesIO(), io.BytesIO()
+    torch.save(sd, buf); torch.save({}, var); torch.save(optimizer_state if optimizer_state is not None else adam_state_dict(sd), opt)
     with zipfile.ZipFile(path, "w") as z:
         z.writestr("data", json.dumps(data, indent=4))
-        z.writestr("policy.pth", buf.getvalue())
         z.writestr("pytorch_variables.pth", var.getvalue())
+        z.writestr("policy.pth", buf.getvalue())
+        z.writestr("policy.optimizer.pth", opt.getvalue())
         z.writestr("_stable_baselines3_version", "1.1.0a5")
 
 

@@ -57,6 +57,7 @@ class UltrasoundVecEnv:
         self._report_truncation = bool(report_truncation)
         self._env_offset = int(env_offset)
         self._handle = C.c_void_p()
+        self.steps_per_launch = 64                   # usim_set_steps_per_launch default (csrc/usim_api.hip)
         self._create(seed)
         lo, hi = _ACTION_BOX[self.cfg.mode]
         self.action_space = Box(np.array(lo), np.array(hi))
@@ -145,6 +146,11 @@ class UltrasoundVecEnv:
         self._check(self.lib.usim_step(self._handle, C.byref(self._io), int(auto_reset), self._stream()))
         self._last_act = a           # keep the tensor alive until the kernel has run
         return self._obs, self._rew, self._done
+
+    def set_steps_per_launch(self, steps):
+        """rollout_random / time_steps: consecutive steps per kernel launch (1 .. 64, default 64; include/usim.h usim_set_steps_per_launch)"""
+        self._check(self.lib.usim_set_steps_per_launch(self._handle, int(steps)))
+        self.steps_per_launch = int(steps)
 
     def set_mapping(self, lanes_per_env, waves_per_simd=0):
         """Switch a live soft-torso env between the split kernel (lanes_per_env 32) and the single-wave 16-lane kernel (waves_per_simd

@@ -260,9 +260,12 @@ def test_f32_oracle_tracks_f64_oracle():
 
 def test_pgs_is_converged_at_default_sweeps():
     """The default contact schedule -- four full sweeps of the block Gauss-Seidel interleaved with three normal-only sweeps, N N F F N F F --
-    leaves the contact forces within float32 resolution of the converged solution of the convex problem, both in the first steps after a
-    synchronous reset (up to eleven penetrating elements, forces up to ~100 N: one float32 ulp is 8e-6 N) and in a mixed batch; six full
-    sweeps reproduce it to 1e-7 N"""
+    leaves the contact forces within 3e-5 N of the converged solution of the convex problem (measured 1.8e-5 N on forces up to 70 N, where one
+    float32 ulp is 8e-6 N; with the round-2 probe stand-in, whose contact normals were nearly parallel, it was 2.9e-6), in a mixed batch as in
+    the first steps after a synchronous reset; six full sweeps reach 5e-7 N.  (A direct solve of the normal block followed by two or three
+    full sweeps was tried and is two to three orders of magnitude WORSE: the slow modes are the friction rows, whose regulariser is 20 times
+    smaller -- impratio -- not the normal rows.)  With domain-randomised friction of 0.15 .. 0.6 (BASELINE configs[4]) the fixed schedule is
+    0.6 N away from convergence; both sides run the same schedule, which is what the parity tests compare."""
     n = 256
     for pre in (8, 40):
         ref = Oracle(n, pgs_iters=300)
@@ -272,7 +275,7 @@ def test_pgs_is_converged_at_default_sweeps():
             ref.step(ref.random_actions(k))
         st, act = ref.get_state(), ref.random_actions(pre)
         orf = ref.step(act, auto_reset=False)[0]
-        for iters, tol in ((4, 5e-5), (6, 1e-6)):      # (interim bound with the blade geometry; the direct normal solve replaces it)
+        for iters, tol in ((4, 3e-5), (6, 1e-6)):
             d = Oracle(n, pgs_iters=iters)
             d.reset(); d.set_state(st)
             od = d.step(act, auto_reset=False)[0]

@@ -75,7 +75,21 @@ def test_checkpoint_writers_roundtrip_the_reference_policy(tmp_path):
     zp = tmp_path / "tracking_copy.zip"
     pol.save_sb3_zip(zp, net, data={"n_envs": 64, "gamma": 0.99, "policy_class": {":type:": "<class 'abc.ABCMeta'>"}})
     with zipfile.ZipFile(zp) as z:
-        assert {"data", "policy.pth", "pytorch_variables.pth", "_stable_baselines3_version"} <= set(z.namelist())
+        # the five members of the reference checkpoints (zipfile.ZipFile("src/trained_rl_models/tracking.zip").namelist()); PPO.load ->
+        # set_parameters(exact_match=True) raises when "policy.optimizer" is missing
+        assert z.namelist() == ["data", "pytorch_variables.pth", "policy.pth", "policy.optimizer.pth", "_stable_baselines3_version"]
+        opt = torch.load(io.BytesIO(z.read("policy.optimizer.pth")), map_location="cpu", weights_only=True)
+        assert z.read("_stable_baselines3_version") == b"1.1.0a5" and torch.load(io.BytesIO(z.read("pytorch_variables.pth")), weights_only=True) == {}
+    # Adam state dict as stored in the reference zips: one group, lr 3e-4, eps 1e-5, one index per policy tensor (13), loadable by torch
+    assert set(opt) == {"state", "param_groups"} and len(opt["param_groups"]) == 1
+    grp = opt["param_groups"][0]
+    assert {k: grp[k] for k in ("lr", "betas", "eps", "weight_decay", "amsgrad")} == {"lr": 3e-4, "betas": (0.9, 0.999), "eps": 1e-5, "weight_decay": 0, "amsgrad": False}
+    assert grp["params"] == list(range(len(sd))) and len(sd) == 13
+    sb3_order = [torch.nn.Parameter(v.clone()) for v in net.to_sb3_state_dict().values()]
+    torch.optim.Adam(sb3_order, lr=1.0).load_state_dict(opt)
+    warm = pol.adam_state_dict(net.to_sb3_state_dict(), step=5)
+    assert warm["state"][0]["exp_avg"].shape == sb3_order[0].shape and warm["state"][12]["step"] == 5
+    torch.optim.Adam(sb3_order, lr=1.0).load_state_dict(warm)
     sd2, data = pol.load_sb3_zip(zp)
     assert set(sd2) == set(sd) and all(torch.equal(sd[k], sd2[k]) for k in sd) and data["n_envs"] == 64
     net2 = pol.MlpActorCritic.from_sb3_state_dict(sd2)
