@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--adaptive", action="store_true", help="N > 1: start every block with the collective-tolerant mapping only for as long as the previous "
-                    "block's all-gather took, then switch to the split kernel (default: the collective-tolerant mapping for the whole block)")
+                    "block's all-gather took, then switch to the split kernel (default: the split kernel throughout)")
     ap.add_argument("--gather", choices=["rccl", "p2p"], default="rccl", help="N > 1: RCCL all-gather (resident workgroups on the CUs) or peer-to-peer copies "
                     "of the packed block (copy engines, no CUs; distributed.P2PRolloutGather)")
     ap.add_argument("--steps-per-launch", type=int, default=0, help="consecutive steps per kernel launch of the rollout (1 .. 64; default: the library's, 64)")
@@ -101,14 +101,14 @@ def main():
     n = args.envs_per_gpu
     extra = {"friction_randomization": 1} if args.randomize else {}
     with_gather = use_dist and not args.no_gather
-    # N > 1, soft torso: the resident workgroups of an overlapped RCCL all-gather push part of every step of the split kernel (and of the
-    # one-wave-per-SIMD budget) into a second round (tools/gpu_interference.py: 19.9 -> 30 us/step), the two-waves-per-SIMD 16-lane build
-    # lets the displaced workgroups double up on other CUs (22.7 -> 26-29 us).  The mappings compute the same bits.  Default ("plain"): the
-    # collective-tolerant mapping for the whole run.  --adaptive: every block starts with it for as long as the previous gather took
-    # (events on the gather's stream) and finishes with the split kernel -- tuned on a stand-in kernel, never run next to real peers, hence
-    # opt-in.  --gather p2p moves the blocks with the copy engines instead: no CUs taken, the split kernel runs throughout.
-    tolerant = with_gather and args.gather == "rccl" and args.workload == "soft" and args.lanes_per_env == 0 and n <= 4096
-    adaptive = tolerant and args.adaptive
+    # N > 1, soft torso.  The step kernel wants one 512-thread workgroup per CU with the whole register file; the resident workgroups of an
+    # overlapped RCCL all-gather take CUs away, and the displaced step workgroups then run in a second round (tools/gpu_interference.py, a
+    # stand-in of RCCL's footprint: 19.9 -> 30 us/step).  Default ("plain"): the same split kernel as for N = 1 and the RCCL all-gather on a
+    # side stream -- nothing tuned on measurements that could not be taken here (the pool has one GPU per box).  --adaptive: start every
+    # block with the two-waves-per-SIMD 16-lane mapping for as long as the previous gather took, then switch (round 2; the mappings compute
+    # the same bits).  --gather p2p: move the blocks with peer-to-peer copies instead of a collective kernel -- no CUs taken
+    # (distributed.P2PRolloutGather; validated with two processes on one GPU only).
+    adaptive = with_gather and args.adaptive and args.gather == "rccl" and args.workload == "soft" and args.lanes_per_env == 0 and n <= 4096
     if args.lanes_per_env:
         extra["lanes_per_env"] = args.lanes_per_env
     env = usim.UltrasoundVecEnv(n, device=device, seed=3, env_offset=rank * n, torso=args.workload, **extra, **usim.default_robosuite_kwargs())
@@ -117,8 +117,6 @@ def main():
     gather = (dmod.P2PRolloutGather(device=device) if args.gather == "p2p" else dmod.RolloutGather(device=device)) if with_gather else None
     if args.steps_per_launch:
         env.set_steps_per_launch(args.steps_per_launch)
-    if tolerant and not adaptive:
-        env.set_mapping(16, 2)
 
     env.reset_tensor()
     step = 0
@@ -216,8 +214,6 @@ def main():
 
     # the mapping usim_create picks (csrc/usim_api.hip): soft torso up to 4096 envs -> two waves per quad of environments (32 lanes per env)
     lanes = int(extra.get("lanes_per_env", 0)) or (32 if (args.workload == "soft" and n <= 4096 and not extra.get("waves_per_simd")) else 16)
-    if tolerant and not adaptive:
-        lanes = 16
     spl = env.steps_per_launch if lanes in (16, 32) else 1        # consecutive steps per kernel launch (usim_set_steps_per_launch)
     spl = max(1, min(spl, T, args.steps))
     wl = "randomised" if (args.randomize and args.workload == "soft" and n == 8192) else args.workload
@@ -250,6 +246,8 @@ def main():
         result = json.dumps(out)
     else:
         result = None
+    if gather is not None:
+        gather.close()
     env.close()
     if use_dist:
         dist.destroy_process_group()

@@ -119,17 +119,20 @@ DI void torso_motion(const DevCfg& C, int tsim, float& dz, float& vz, float& az)
 // the tip = grip_site) and an upper capsule (radius probe_r2, axis probe_h above the tip capsule's).  Signed distance of a point given in the site
 // frame (site z points from the tip away from the probe body) and its gradient: the round-cone distance on the cross-section.
 DI float probe_sdf(const DevCfg& C, const f3 p, f3& g) {
+    // (v_rsq_f32 is a quarter-rate instruction like v_sqrt_f32 / v_rcp_f32: every length and its reciprocal come from one of them)
     const float py = -p.z - C.probe_r, e = fmaxf(fabsf(p.x) - C.probe_hl, 0.f);
-    const float px2 = fmaf(p.y, p.y, e * e), px = sqrt_(px2);
+    const float px2 = fmaf(p.y, p.y, e * e);
+    const bool pxok = px2 > 1e-18f;
+    const float ipx = pxok ? rsq_(px2) : 0.f, px = px2 * ipx;
     const float kk = fmaf(py, C.probe_ca, -(px * C.probe_cb));
     const bool low = kk < 0.f, flank = !low && !(kk > C.probe_cah);
     const float qy = py - C.probe_h;
-    const float lc = sqrt_(fmaf(qy, qy, px2)), ilc = rcp_(lc);                        // seen from the centre of the upper circle of the cross-section
-    const float ll = sqrt_(fmaf(py, py, px2)), ill = rcp_(ll);                        // ... of the tip circle
-    const bool okc = lc > 1e-9f, okl = ll > 1e-9f;
+    const float lc2 = fmaf(qy, qy, px2), ll2 = fmaf(py, py, px2);
+    const bool okc = lc2 > 1e-18f, okl = ll2 > 1e-18f;
+    const float ilc = okc ? rsq_(lc2) : 0.f, ill = okl ? rsq_(ll2) : 0.f;             // seen from the centre of the upper circle of the cross-section / of the tip circle
     const float cx = px * ilc, cy = qy * ilc;
-    float d = low ? ll - C.probe_r : lc - C.probe_r2;
-    float gx = low ? (okl ? px * ill : 0.f) : (okc ? cx : 0.f), gy = low ? (okl ? py * ill : -1.f) : (okc ? cy : -1.f);
+    float d = low ? ll2 * ill - C.probe_r : lc2 * ilc - C.probe_r2;
+    float gx = low ? px * ill : cx, gy = low ? (okl ? py * ill : -1.f) : (okc ? cy : -1.f);
     if (flank) { d = fmaf(px, C.probe_ca, fmaf(py, C.probe_cb, -C.probe_r)); gx = C.probe_ca; gy = C.probe_cb; }
     // direction field: the distance gradient is undefined on the medial axis of the body (the tip capsule's axis, probe_r below the surface, and
     // the centre plane above it); between 2/3 and 0.96 probe_r below the surface the direction turns into the one seen from the upper centre
@@ -138,17 +141,106 @@ DI float probe_sdf(const DevCfg& C, const f3 p, f3& g) {
     const float bx = fmaf(beta, cx - gx, gx), by = fmaf(beta, cy - gy, gy);
     const float rn = beta > 0.f ? rsq_(fmaf(bx, bx, by * by)) : 1.f;
     gx = bx * rn; gy = by * rn;
-    const bool pxok = px > 1e-9f;
-    const float ipx = pxok ? rcp_(px) : 0.f, gxi = gx * ipx;
+    const float gxi = gx * ipx;
     g = mk(copysignf(gxi * e, p.x), pxok ? gxi * p.y : gx, -gy);
     return d;
+}
+
+// One collision round: the probe blade against element i G + gl of this lane's environment (one element per lane); the wave ballot gives every
+// hit its slot in the record area `recs` (MAXCAND records + one spare for misses), so that the list stays sorted by ascending shell id.
+// Straight-line code (a miss writes its record to the spare slot): the rounds can be scheduled between the matrix instructions of the lattice
+// solve.  Element = capsule (soft_box.xml:10): axis segment from the cap centre `tip` (t = 0) to the inner end (t = 1); the probe distance d(t)
+// is convex along it.  With the slopes s0, s1 at the two ends, t minimises the quadratic model d0 + s0 t + (s1 - s0 + eps) t^2 / 2 on [0, 1];
+// eps settles the point near the cap when the shaft lies flat against a flank of the probe (every point equally close: the plain minimiser
+// would be ill-conditioned).
+template <int G>
+DI void collide_one(const float* lds, float* recs, const int i, const int gl, const int gbase, const DevModel& M, const DevCfg& C, const float se, const float dz,
+                    const f3 Kx, const f3 Ksx, const f3 Ksy, const f3 Ksz, int& nc) {
+    const int eraw = i * G + gl, e = eraw < N_TOP ? eraw : N_TOP - 1;
+    const f3 ax = mk(lds[TB_AXIS + 3 * e], lds[TB_AXIS + 3 * e + 1], lds[TB_AXIS + 3 * e + 2]);
+    const f3 tip = mk(M.torso[0] + lds[TB_POS + 3 * e], M.torso[1] + lds[TB_POS + 3 * e + 1], M.torso[2] + lds[TB_POS + 3 * e + 2] + dz) + ax * (se - ELEM_R);
+    const f3 rel = tip - Kx;
+    const f3 p0 = mk(dot(Ksx, rel), dot(Ksy, rel), dot(Ksz, rel));               // site frame
+    const f3 us = mk(dot(Ksx, ax), dot(Ksy, ax), dot(Ksz, ax)) * (-2.f * ELEM_HL);
+    f3 g0, g1, gs;
+    (void)probe_sdf(C, p0, g0);
+    (void)probe_sdf(C, p0 + us, g1);
+    const float s0 = dot(g0, us), s1 = dot(g1, us);
+    const float tt = clampf(-s0 * rcp_(fmaxf(s1 - s0, 0.f) + SHAFT_EPS), 0.f, 1.f);
+    const float dist = probe_sdf(C, madd(p0, us, tt), gs) - ELEM_R;
+    const bool hit = (eraw < N_TOP) && (dist < 0.f);
+    const f3 nn = (Ksx * gs.x + Ksy * gs.y + Ksz * gs.z) * -1.f;                 // from the element towards the probe
+    const f3 rr = madd(tip, ax, -2.f * ELEM_HL * tt) + nn * (ELEM_R + 0.5f * dist) - Kx;
+    const unsigned long long bal = __ballot(hit);
+    const unsigned gm = (unsigned)(bal >> gbase) & ((1u << G) - 1u);
+    const int slot = nc + __popc(gm & ((1u << gl) - 1u));
+    const int sl = (hit && slot < MAXCAND) ? slot : MAXCAND;                      // MAXCAND = the spare record
+    float4* rec = reinterpret_cast<float4*>(&recs[sl * CG_WORDS]);
+    rec[0] = make_float4(nn.x, nn.y, nn.z, rr.x);
+    rec[1] = make_float4(rr.y, rr.z, __int_as_float(e), dist);
+    nc += __popc(gm);
+}
+
+// More penetrating elements than contact slots (rare in a mixed batch, common right after a synchronous reset): keep the MAXC deepest of the
+// first MAXCAND candidates (ties keep the lower id), list still in ascending shell id.  The caller clamps its count to MAXC afterwards.
+template <int G>
+DI void contact_overflow(float* lds, const int eb, const int gl, const int gbase, const int nc) {
+#define EBF(off) lds[TB_WORDS + eb * GE_STRIDE + (off)]
+    if (nc > MAXC) {
+                        // more penetrating elements than contact slots (rare in a mixed batch, common right after a synchronous reset: 4 % of
+                        // the environments).  Keep the MAXC deepest of the first MAXCAND candidates (ties keep the lower id), list still in
+                        // ascending shell id.
+                        group_sync();
+                        if constexpr (G == 16) {
+                            // one candidate per lane of the group: rank by depth with sixteen row broadcasts, compact with a ballot
+                            const int m = nc < MAXCAND ? nc : MAXCAND;
+                            const bool cand = gl < m;
+                            const float4* rec = reinterpret_cast<const float4*>(&EBF(GE_CG + gl * CG_WORDS));
+                            const float4 r0 = rec[0], r1 = rec[1];
+                            const float d = cand ? r1.w : 1.0f;
+                            int rank = 0;
+#define USIM_RANK_STEP(I) { const float di = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x150 + I, 0xf, 0xf, true)); \
+                            rank += (di < d || (di == d && I < gl)) ? 1 : 0; }
+                            USIM_RANK_STEP(0) USIM_RANK_STEP(1) USIM_RANK_STEP(2) USIM_RANK_STEP(3) USIM_RANK_STEP(4) USIM_RANK_STEP(5) USIM_RANK_STEP(6) USIM_RANK_STEP(7)
+                            USIM_RANK_STEP(8) USIM_RANK_STEP(9) USIM_RANK_STEP(10) USIM_RANK_STEP(11) USIM_RANK_STEP(12) USIM_RANK_STEP(13) USIM_RANK_STEP(14) USIM_RANK_STEP(15)
+#undef USIM_RANK_STEP
+                            const bool keep = cand && rank < MAXC;
+                            const unsigned gm = (unsigned)(__ballot(keep) >> gbase) & 0xffffu;
+                            const int slot = __popc(gm & ((1u << gl) - 1u));
+                            group_sync();                                  // every record is in registers before any slot is overwritten
+                            if (keep) {
+                                float4* dst = reinterpret_cast<float4*>(&EBF(GE_CG + slot * CG_WORDS));
+                                dst[0] = r0; dst[1] = r1;
+                            }
+                        } else if (gl == 0) {
+                            // (8 lanes per environment: one lane of the group edits the records in place)
+                            const int m = nc < MAXCAND ? nc : MAXCAND;
+                            for (int drop = m - MAXC; drop > 0; --drop) {
+                                int worst = 0; float wd = -1.0e30f;
+                                for (int j = 0; j < m; ++j) {
+                                    const float dj = EBF(GE_CG + j * CG_WORDS + 7);
+                                    if (dj < 0.f && dj >= wd) { wd = dj; worst = j; }
+                                }
+                                EBF(GE_CG + worst * CG_WORDS + 7) = 1.0f;                       // dropped
+                            }
+                            int wpos = 0;
+                            for (int j = 0; j < m; ++j) {
+                                if (EBF(GE_CG + j * CG_WORDS + 7) < 0.f) {
+                                    if (wpos != j)
+                                        for (int a = 0; a < CG_WORDS; ++a) EBF(GE_CG + wpos * CG_WORDS + a) = EBF(GE_CG + j * CG_WORDS + a);
+                                    ++wpos;
+                                }
+                            }
+                        }
+                    }
+#undef EBF
 }
 
 // Lattice front end of one forward pass, executed by the G lanes of a group on the group's LDS block: stage (s, sdot), build
 // the right-hand side of the soft-equality system, a~ = Linv rhs, collide the probe capsule with the 99 cap spheres and
 // leave the contact records (ascending shell id; the MAXC deepest when more were found) in LDS.  Returns the number found (may exceed MAXC).
 // PART 0: everything; 1: staging + right-hand side only (needs no arm quantity); 2: solve + collision only (after a PART 1 call).
-template <int G, int NE, bool MM, int PART = 0>
+template <int G, int NE, bool MM, int PART = 0, int R0 = 0>
 DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, const DevModel& M, const DevCfg& C, const int tsim,
                      const float kst, const float kdmp, const bool live, const float* s_pre, const float* sd_pre,
                      const f3 Kx, const f3 Ksy, const f3 Ksz, unsigned long long* dbg) {
@@ -203,39 +295,14 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                     }
                     if constexpr (PART == 1) return 0;
                     LSTAMP(5);
-                                    // ---- collision round i: probe blade vs the capsules of elements i G .. i G + G - 1 (one per lane); the wave
-                    //      ballot gives every hit its slot so that the contact list stays sorted by ascending shell id.  Straight-line code
-                    //      (a miss writes its record to a spare slot), so that the rounds can be scheduled between the matrix instructions
-                    //      of the lattice solve.  Element = capsule (soft_box.xml:10): axis segment from the cap centre `tip` (t = 0) to the
-                    //      inner end (t = 1); the probe distance d(t) is convex along it.  With the slopes s0, s1 at the two ends, t minimises the
-                    //      quadratic model d0 + s0 t + (s1 - s0 + eps) t^2 / 2 on [0, 1]; eps settles the point near the cap when the shaft lies
-                    //      flat against a flank of the probe (every point equally close: the plain minimiser would be ill-conditioned) ----
+                                    // ---- collision rounds R0 .. NE - 1 (collide_one): scheduled between the pieces of the matrix-core solve below.  (The
+                    //      split kernel gives rounds 0 .. R0 - 1 to the arm wave, which has the site pose first and would otherwise wait for this
+                    //      wave at the barrier; the two lists are merged after it: merge_contact_lists.) ----
                     const f3 Ksx = cross(Ksy, Ksz);
                     int nc = 0;
                     auto collide_round = [&](const int i) {
-                        const int eraw = i * G + gl, e = eraw < N_TOP ? eraw : N_TOP - 1;
-                        const f3 ax = mk(lds[TB_AXIS + 3 * e], lds[TB_AXIS + 3 * e + 1], lds[TB_AXIS + 3 * e + 2]);
-                        const float se = live ? s_pre[i] : 0.f;                        // element i G + gl is this lane's own
-                        const f3 tip = mk(M.torso[0] + lds[TB_POS + 3 * e], M.torso[1] + lds[TB_POS + 3 * e + 1], M.torso[2] + lds[TB_POS + 3 * e + 2] + dz) + ax * (se - ELEM_R);
-                        const f3 rel = tip - Kx;
-                        const f3 p0 = mk(dot(Ksx, rel), dot(Ksy, rel), dot(Ksz, rel));               // site frame
-                        const f3 us = mk(dot(Ksx, ax), dot(Ksy, ax), dot(Ksz, ax)) * (-2.f * ELEM_HL);
-                        f3 g0, g1, gs;
-                        const float d0 = probe_sdf(C, p0, g0), s0 = dot(g0, us);
-                        const float d1 = probe_sdf(C, p0 + us, g1), s1 = dot(g1, us);
-                        const float tt = clampf(-s0 * rcp_(fmaxf(s1 - s0, 0.f) + SHAFT_EPS), 0.f, 1.f);
-                        const float dist = probe_sdf(C, madd(p0, us, tt), gs) - ELEM_R;
-                        const bool hit = (eraw < N_TOP) && (dist < 0.f);
-                        const f3 nn = (Ksx * gs.x + Ksy * gs.y + Ksz * gs.z) * -1.f;                 // from the element towards the probe
-                        const f3 rr = madd(tip, ax, -2.f * ELEM_HL * tt) + nn * (ELEM_R + 0.5f * dist) - Kx;
-                        const unsigned long long bal = __ballot(hit);
-                        const unsigned gm = (unsigned)(bal >> gbase) & ((1u << G) - 1u);
-                        const int slot = nc + __popc(gm & ((1u << gl) - 1u));
-                        const int sl = (hit && slot < MAXCAND) ? slot : MAXCAND;          // MAXCAND = the spare record
-                        float4* rec = reinterpret_cast<float4*>(&EBF(GE_CG + sl * CG_WORDS));
-                        rec[0] = make_float4(nn.x, nn.y, nn.z, rr.x);
-                        rec[1] = make_float4(rr.y, rr.z, __int_as_float(e), dist);
-                        nc += __popc(gm);
+                        if (i < R0) return;
+                        collide_one<G>(lds, &EBF(GE_CG), i, gl, gbase, M, C, live ? s_pre[i] : 0.f, dz, Kx, Ksx, Ksy, Ksz, nc);
                     };
                                     // ---- a~ = Linv * rhs ----
                     if constexpr (MM) {
@@ -321,53 +388,7 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
     #pragma unroll
                         for (int i = 0; i < NE; ++i) collide_round(i);
                     }
-                    if (nc > MAXC) {
-                        // more penetrating elements than contact slots (rare in a mixed batch, common right after a synchronous reset: 4 % of
-                        // the environments).  Keep the MAXC deepest of the first MAXCAND candidates (ties keep the lower id), list still in
-                        // ascending shell id.
-                        group_sync();
-                        if constexpr (G == 16) {
-                            // one candidate per lane of the group: rank by depth with sixteen row broadcasts, compact with a ballot
-                            const int m = nc < MAXCAND ? nc : MAXCAND;
-                            const bool cand = gl < m;
-                            const float4* rec = reinterpret_cast<const float4*>(&EBF(GE_CG + gl * CG_WORDS));
-                            const float4 r0 = rec[0], r1 = rec[1];
-                            const float d = cand ? r1.w : 1.0f;
-                            int rank = 0;
-#define USIM_RANK_STEP(I) { const float di = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x150 + I, 0xf, 0xf, true)); \
-                            rank += (di < d || (di == d && I < gl)) ? 1 : 0; }
-                            USIM_RANK_STEP(0) USIM_RANK_STEP(1) USIM_RANK_STEP(2) USIM_RANK_STEP(3) USIM_RANK_STEP(4) USIM_RANK_STEP(5) USIM_RANK_STEP(6) USIM_RANK_STEP(7)
-                            USIM_RANK_STEP(8) USIM_RANK_STEP(9) USIM_RANK_STEP(10) USIM_RANK_STEP(11) USIM_RANK_STEP(12) USIM_RANK_STEP(13) USIM_RANK_STEP(14) USIM_RANK_STEP(15)
-#undef USIM_RANK_STEP
-                            const bool keep = cand && rank < MAXC;
-                            const unsigned gm = (unsigned)(__ballot(keep) >> gbase) & 0xffffu;
-                            const int slot = __popc(gm & ((1u << gl) - 1u));
-                            group_sync();                                  // every record is in registers before any slot is overwritten
-                            if (keep) {
-                                float4* dst = reinterpret_cast<float4*>(&EBF(GE_CG + slot * CG_WORDS));
-                                dst[0] = r0; dst[1] = r1;
-                            }
-                        } else if (gl == 0) {
-                            // (8 lanes per environment: one lane of the group edits the records in place)
-                            const int m = nc < MAXCAND ? nc : MAXCAND;
-                            for (int drop = m - MAXC; drop > 0; --drop) {
-                                int worst = 0; float wd = -1.0e30f;
-                                for (int j = 0; j < m; ++j) {
-                                    const float dj = EBF(GE_CG + j * CG_WORDS + 7);
-                                    if (dj < 0.f && dj >= wd) { wd = dj; worst = j; }
-                                }
-                                EBF(GE_CG + worst * CG_WORDS + 7) = 1.0f;                       // dropped
-                            }
-                            int wpos = 0;
-                            for (int j = 0; j < m; ++j) {
-                                if (EBF(GE_CG + j * CG_WORDS + 7) < 0.f) {
-                                    if (wpos != j)
-                                        for (int a = 0; a < CG_WORDS; ++a) EBF(GE_CG + wpos * CG_WORDS + a) = EBF(GE_CG + j * CG_WORDS + a);
-                                    ++wpos;
-                                }
-                            }
-                        }
-                    }
+                    if constexpr (R0 == 0) contact_overflow<G>(lds, eb, gl, gbase, nc);
     return nc;
 #undef EBF
 #undef LSTAMP

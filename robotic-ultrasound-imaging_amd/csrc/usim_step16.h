@@ -164,8 +164,12 @@ constexpr int X16_RIGID_STRIDE = 68;                  // rigid-torso launches: o
 // matrix-core solve, collision, contact solve, element integration).  They meet at workgroup barriers and hand over through per-environment
 // LDS mailboxes: site pose (1 -> 2), Lambda^-1 / alpha / vs (1 -> 2), contact wrench and contact list (2 -> 1).  ROLE 0 = one wave does both.
 constexpr int X2_BASE = TB_WORDS + 16 * GE_STRIDE;        // behind the sixteen per-environment blocks: arm scratch + mailboxes of the split kernel
-constexpr int X2_STRIDE = 164, MB_POSE = 64, MB_OP = 76, MB_W = 140;      // 64 transpose scratch | 12 pose | 64 op-space (6 x 8 Lambda^-1, alpha 6, vs 6) | 16 wrench + contacts
-static_assert(MB_W + 16 <= X2_STRIDE, "mailbox block");
+// 64 transpose scratch | 12 pose (+ the arm side's hit count in word 9) | 64 op-space (6 x 8 Lambda^-1, alpha 6, vs 6) | 16 wrench + contacts | the arm side's contact records
+constexpr int MB_POSE = 64, MB_OP = 76, MB_W = 140, MB_CA = 156, X2_STRIDE = MB_CA + (MAXCAND + 1) * CG_WORDS;
+static_assert(MB_W + 16 <= MB_CA && (MB_CA % 4) == 0 && (X2_STRIDE % 4) == 0, "mailbox block");
+// Collision rounds of the split kernel that the ARM side runs (elements 0 .. 16 ARM_ROUNDS - 1): it has the site pose first and would
+// otherwise wait at hand-off (2) for the lattice side, whose matrix-core solve + seven rounds are the longer path (profiles/r03/timeline_*)
+constexpr int ARM_ROUNDS = 7;
 
 template <int TORSO, int MODE, int ROLE, int NT>
 DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __restrict__ st, const int n, const int npad, const DevIO& io, const int flags, const long long rstep,
@@ -238,6 +242,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         const int e = gl + i * G;
         s_pre[i] = 0.f; sd_pre[i] = 0.f;
         if (TORSO && MODE == 0 && ROLE != 1 && e < N_TOP) { s_pre[i] = LAT(LAT_S + e); sd_pre[i] = LAT(LAT_SD + e); }
+        if (TORSO && MODE == 0 && ROLE == 1 && i < ARM_ROUNDS && e < N_TOP) s_pre[i] = LAT(LAT_S + e);      // the arm side collides these elements
     }
     if (TORSO != 0 && item0 == item_first && first_pass) {
         // workgroup-resident copy of the lattice tables: 16-byte loads, all issued before the first LDS store (and behind the state loads
@@ -275,7 +280,22 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         RSTAMP(2);
         const f3 xs = mk(mb[MB_POSE], mb[MB_POSE + 1], mb[MB_POSE + 2]), sy = mk(mb[MB_POSE + 3], mb[MB_POSE + 4], mb[MB_POSE + 5]),
                  sz = mk(mb[MB_POSE + 6], mb[MB_POSE + 7], mb[MB_POSE + 8]);
-        int nc = lattice_front<G, NE, true, 2>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, true, s_pre, sd_pre, xs, sy, sz, dbg);
+        const int ncl = lattice_front<G, NE, true, 2, ARM_ROUNDS>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, true, s_pre, sd_pre, xs, sy, sz, dbg);
+        RSTAMP(3);
+        __syncthreads();                                                 // (2) ... and Lambda^-1, alpha = J qs, vs = J qd, and the arm side's contact records
+        RSTAMP(4);
+        // one list in ascending shell id: the arm side's records (elements 0 .. 16 ARM_ROUNDS - 1) first, this side's behind them
+        const int nca = __float_as_int(mb[MB_POSE + 9]);
+        int nc = nca + ncl;
+        if (__any(nca > 0)) {
+            const int na = nca < MAXCAND ? nca : MAXCAND, li = gl - na;
+            const float4* src = reinterpret_cast<const float4*>(gl < na ? &mb[MB_CA + gl * CG_WORDS] : &EB(GE_CG + (li > 0 ? li : 0) * CG_WORDS));
+            const float4 r0 = src[0], r1 = src[1];
+            group_sync();                                                // every record is in registers before any slot is overwritten
+            float4* dst = reinterpret_cast<float4*>(&EB(GE_CG + gl * CG_WORDS));
+            dst[0] = r0; dst[1] = r1;
+        }
+        contact_overflow<G>(lds, eb, gl, gbase, nc);
         int overflow = 0;
         if (nc > MAXC) { overflow = 1; nc = MAXC; }
         group_sync();
@@ -286,9 +306,6 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         int cel[MAXC];
 #pragma unroll
         for (int k = 0; k < MAXC; ++k) { gf[k] = 0.f; cel[k] = (k < nc) ? __float_as_int(EB(GE_CG + k * CG_WORDS + 6)) : 0; }
-        RSTAMP(3);
-        __syncthreads();                                                 // (2) ... and Lambda^-1, alpha = J qs, vs = J qd
-        RSTAMP(4);
         if (ncmax > 0) {
             float alpha[6], vs[6], Lp[21];
 #pragma unroll
@@ -678,6 +695,16 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
 #pragma unroll
     for (int k = 0; k < MAXC; ++k) con_shell[k] = -1;
     if constexpr (ROLE == 1) {
+        {
+            // the arm side's share of the collision: elements 0 .. 16 ARM_ROUNDS - 1 against the site pose it computed itself
+            float dz_, vz_, az_;
+            torso_motion(C, t - 1, dz_, vz_, az_);
+            const f3 sxc = cross(sy, sz);
+            int nca = 0;
+#pragma unroll
+            for (int i = 0; i < ARM_ROUNDS; ++i) collide_one<G>(lds, xl + MB_CA, i, gl, gbase, M, C, s_pre[i], dz_, xs, sxc, sy, sz, nca);
+            if (gl == 0) xl[MB_POSE + 9] = __int_as_float(nca);
+        }
         // hand Lambda^-1 (row a from task lane a), alpha = J qs and vs = J qd to the lattice side; take the contact wrench back
         if (is_task) {
             const int arow = blk ? 3 + comp : comp;

@@ -98,6 +98,104 @@ class RolloutGather:
             out.record_stream(cur)
         return out
 
+    def close(self):
+        pass
 
-class P2PRolloutGather(RolloutGather):
-    """placeholder until the peer-to-peer implementation lands (same interface)"""
+
+
+class P2PRolloutGather:
+    """The same gather without a collective kernel: every rank copies its packed block into slot `rank` of every peer's receive buffer with
+    plain device-to-device copies into IPC-mapped memory (hipMemcpy between peers: the copy engines over xGMI), so no workgroups sit on the
+    CUs next to the step kernels -- the split kernel keeps every SIMD ("N > 1").  Interface of RolloutGather:
+    gather_async(block) right after the block has been enqueued, wait() before its consumers are enqueued; the tensor wait() returns
+    ([world, T, n_local, C], a view of this rank's receive buffer) stays valid until the next gather_async() call but one.
+
+    Protocol (DEPTH = 3 receive buffers per rank, round g uses buffer g % 3):
+      set-up   every rank allocates its receive buffers, exports them (torch.multiprocessing's CUDA-IPC reduction: hipIpcGetMemHandle) and opens
+               those of its peers; handles travel through `ctrl_group` (any backend; a gloo group is created when none is given).
+      round g  side stream: wait for the caller's stream (the block is complete), pack, one copy per peer into peer.recv[g % 3][rank].
+      wait()   host: synchronise the side stream (my copies have landed), then a barrier on ctrl_group (everybody's have).  Nothing else
+               orders the ranks: a buffer is rewritten three rounds later, after two such barriers, each of which is passed only when
+               every rank's block g - 1 -- enqueued behind the consumers of round g - 3 -- has finished on its GPU.
+    Not yet run across real peers (the pool has one GPU per box): validated with two processes sharing one GPU (tests/test_gpu_p2p_gather.py)
+    and against RolloutGather's result."""
+    DEPTH = 3
+
+    def __init__(self, group=None, device=None, ctrl_group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("P2PRolloutGather needs an initialised torch.distributed process group (for the handle exchange and barriers)")
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.type != "cuda":
+            raise RuntimeError("P2PRolloutGather moves device memory between GPUs; use RolloutGather on the CPU")
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.ctrl = ctrl_group if ctrl_group is not None else (group if dist.get_backend(group) == "gloo" else dist.new_group(backend="gloo"))
+        self._stream = torch.cuda.Stream(device=self.device)
+        self._recv = None            # [DEPTH, world, T, n, C] on this rank's device
+        self._peer = None            # _peer[p]: rank p's receive buffers, opened in this process
+        self._round = 0
+        self._pending = None
+        self.last_ms = None
+        self._timings = []
+
+    def _setup(self, shape, dtype):
+        from torch.multiprocessing.reductions import reduce_tensor
+        with torch.cuda.device(self.device):
+            self._recv = torch.zeros((self.DEPTH, self.world) + tuple(shape), dtype=dtype, device=self.device)
+        torch.cuda.synchronize(self.device)
+        fn, args = reduce_tensor(self._recv)
+        handles = [None] * self.world
+        dist.all_gather_object(handles, (fn, args), group=self.ctrl)
+        self._peer = [self._recv if p == self.rank else handles[p][0](*handles[p][1]) for p in range(self.world)]
+        dist.barrier(group=self.ctrl)                 # every peer has opened every buffer before the exporting tensors can go away
+        self._shape = tuple(shape)
+
+    def gather_async(self, block):
+        cur = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(cur)                 # the block must be complete before it is packed
+        with torch.cuda.stream(self._stream):
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record(self._stream)
+            packed = pack_block(block)
+            if self._recv is None:
+                self._setup(packed.shape, packed.dtype)
+            if tuple(packed.shape) != self._shape:
+                raise ValueError(f"block shape changed: {tuple(packed.shape)} vs {self._shape} (allocate one gather per block shape)")
+            slot = self._round % self.DEPTH
+            for k in range(self.world):               # start with the right-hand neighbour: the ranks do not all write to rank 0 first
+                p = (self.rank + k) % self.world
+                self._peer[p][slot, self.rank].copy_(packed, non_blocking=True)
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record(self._stream)
+        self._timings.append((ev0, ev1))
+        for t in block.values():
+            t.record_stream(self._stream)
+        packed.record_stream(self._stream)
+        self._pending = slot
+        self._round += 1
+
+    def wait(self):
+        if self._pending is None:
+            return None
+        slot, self._pending = self._pending, None
+        self._stream.synchronize()                    # my copies have landed in every peer's buffer ...
+        dist.barrier(group=self.ctrl)                 # ... and so have everybody else's in mine
+        while self._timings and self._timings[0][1].query():
+            t = self._timings.pop(0)
+            self.last_ms = t[0].elapsed_time(t[1])
+        return self._recv[slot]
+
+    def gather(self, block):
+        self.gather_async(block)
+        return self.wait()
+
+    def close(self):
+        """Release the peers' buffers before this rank's own go away (CUDA-IPC reference counting: a producer that exits while a consumer
+        still maps its memory is reported by the allocator)."""
+        if self._pending is not None:
+            self.wait()
+        if self._peer is not None:
+            self._peer = None
+            torch.cuda.synchronize(self.device)
+            dist.barrier(group=self.ctrl)             # nobody maps anybody's buffers any more
+            torch.cuda.ipc_collect()
+            self._recv = None
