@@ -202,18 +202,19 @@ def main():
     achieved_gbs = ALGO_BYTES[args.workload] * n / avg_kernel_s / 1e9
     valu_tflops = ALGO_FLOPS[args.workload] * n / avg_kernel_s / 1e12
 
-    traffic = None
+    traffic_step = None
     tfile = next((f for f in (ROOT / "profiles" / r / "traffic.json" for r in ("r03", "r02", "r01")) if f.exists()), ROOT / "profiles" / "r03" / "traffic.json")
     if tfile.exists() and n == 4096:
         try:
             tj = json.loads(tfile.read_text()).get(args.workload)
             if tj:
-                traffic = (tj["fetch_kb"] + tj["write_kb"]) * 1024.0      # bytes per env-step batch (one step of all envs), committed PMC profile of this command
+                # bytes per step of all environments, committed PMC profile of this command; FETCH_SIZE with the guide's gfx950 x2 correction
+                traffic_step = (tj.get("fetch_kb_x2", 2 * tj["fetch_kb"]) + tj["write_kb"]) * 1024.0
         except Exception:
-            traffic = None
+            traffic_step = None
 
-    # the mapping usim_create picks (csrc/usim_api.hip): soft torso up to 4096 envs -> two waves per quad of environments (32 lanes per env)
-    lanes = int(extra.get("lanes_per_env", 0)) or (32 if (args.workload == "soft" and n <= 4096 and not extra.get("waves_per_simd")) else 16)
+    # the mapping usim_create picks (csrc/usim_api.hip): soft torso -> two waves per quad of environments (32 lanes per env)
+    lanes = int(extra.get("lanes_per_env", 0)) or (32 if (args.workload == "soft" and not extra.get("waves_per_simd")) else 16)
     spl = env.steps_per_launch if lanes in (16, 32) else 1        # consecutive steps per kernel launch (usim_set_steps_per_launch)
     spl = max(1, min(spl, T, args.steps))
     wl = "randomised" if (args.randomize and args.workload == "soft" and n == 8192) else args.workload
@@ -233,7 +234,11 @@ def main():
                        "lanes_per_env": lanes if not adaptive else "32, and 16 (two waves per SIMD) while the previous block is gathered",
                        "waves_per_simd": int(extra.get("waves_per_simd", 0)) or "auto"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": f"{tfile.relative_to(ROOT)} (rocprofv3 FETCH_SIZE + WRITE_SIZE, per step of all environments; multiply by steps_per_launch for a launch)" if traffic else None,
+                         # HBM bytes per launch from the committed PMC profile (FETCH_SIZE with the guide's gfx950 x2 correction + WRITE_SIZE).  Far below the
+                         # algorithmic bytes: inside a multi-step launch the state of the 4096 environments (7.8 MB) stays in the XCDs' L2 from one step
+                         # to the next, and what reaches the memory side is mostly the transition block
+                         "traffic": None if traffic_step is None else traffic_step * spl, "traffic_per_step": traffic_step,
+                         "traffic_source": f"{tfile.relative_to(ROOT)} (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE per step of all environments, times steps_per_launch)" if traffic_step else None,
                          # one launch advances all n environments by `steps_per_launch` steps; achieved = algorithmic bytes per launch / launch duration
                          "algorithmic_bytes_per_launch": ALGO_BYTES[args.workload] * n * spl, "algorithmic_bytes_per_env_step": ALGO_BYTES[args.workload],
                          "steps_per_launch": spl, "avg_launch_us": avg_kernel_s * 1e6 * spl,

@@ -71,7 +71,7 @@ typedef struct usim_config {
     int32_t ik_iters;                          /* reset inverse-kinematics iterations */
     int32_t env_offset;                        /* global index of env 0 of this handle (multi-GPU shard) */
     int32_t lanes_per_env;                     /* kernel mapping: 0 automatic; 16 lanes per environment (arm mathematics distributed over the group); 32 (soft torso: the
-                                                * same, arm side and lattice / contact side in two waves that share a SIMD; automatic up to 4096 envs);
+                                                * same, arm side and lattice / contact side in two waves that share a SIMD; the automatic choice for the soft torso);
                                                 * 8 (soft torso; arm mathematics replicated per lane) or 1 (rigid torso: one environment per lane) */
     int32_t torso_shape;                       /* use_box_torso (rl_config.yaml:57): 0 box (soft_box.xml), 1 cylinder (soft_human_torso.xml) */
     int32_t waves_per_simd;                    /* 16-lane step kernel: register budget for 1 or 2 waves per SIMD; 0 auto (1 up to 4096 envs, 2 beyond) */

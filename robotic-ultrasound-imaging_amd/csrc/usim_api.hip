@@ -293,6 +293,7 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
         const double cb = (cfg->probe_radius - cfg->probe_radius2) / cfg->probe_height, ca = std::sqrt(1.0 - cb * cb);
         C.probe_r2 = (float)cfg->probe_radius2; C.probe_h = (float)cfg->probe_height; C.probe_ca = (float)ca; C.probe_cb = (float)cb;
         C.probe_cah = C.probe_ca * C.probe_h;
+        { const double cr = cfg->probe_radius + cfg->probe_height + 0.025 + 0.0075 + 1e-4; C.probe_cull2 = (float)(cr * cr); }
         C.probe_deep0 = (float)(cfg->probe_radius * (2.0 / 3.0)); C.probe_inv_band = (float)(1.0 / (cfg->probe_radius * (0.96 - 2.0 / 3.0)));
     }
     {
@@ -312,9 +313,11 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
     HIPCHK(h, hipEventCreate(&h->ev1));
     // kernel mapping
     // Rigid torso: 16 lanes per environment (arm mathematics distributed over the group) or, with lanes_per_env = 1, one lane each.
-    // Soft torso, automatic choice: up to 4096 envs/GPU the split kernel (32 lanes = two waves per quad of environments, usim_step32_kernel)
-    // unless a register budget was asked for; beyond, 16 lanes per environment with the two-waves-per-SIMD budget.
-    h->lpe = h->n_el ? (cfg->lanes_per_env == 0 ? ((n_envs <= 4096 && cfg->waves_per_simd == 0) ? 32 : 16) : cfg->lanes_per_env)
+    // Soft torso, automatic choice: the split kernel (32 lanes = two waves per quad of environments, usim_step32_kernel) at every batch size
+    // unless a register budget was asked for.  (Round 2 switched to 16 lanes with the two-waves-per-SIMD budget beyond 4096 envs/GPU; with the
+    // capsule collision of round 3 that build spills, and two rounds of split-kernel workgroups are faster: 8192 envs 33.3 vs 40.4 us/step,
+    // 16384 envs 65.0 vs 78.8, profiles/r03/bench_matrix.txt.)
+    h->lpe = h->n_el ? (cfg->lanes_per_env == 0 ? (cfg->waves_per_simd == 0 ? 32 : 16) : cfg->lanes_per_env)
                      : (cfg->lanes_per_env == 0 ? 16 : cfg->lanes_per_env);
     if (h->n_el ? (h->lpe != 8 && h->lpe != 16 && h->lpe != 32) : (h->lpe != 1 && h->lpe != 16)) return USIM_ERR_INVALID;
     if (cfg->robot != USIM_ROBOT_PANDA && h->lpe != 16 && h->lpe != 32) {

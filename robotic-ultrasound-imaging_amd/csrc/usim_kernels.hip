@@ -154,9 +154,8 @@ DI float probe_sdf(const DevCfg& C, const f3 p, f3& g) {
 // eps settles the point near the cap when the shaft lies flat against a flank of the probe (every point equally close: the plain minimiser
 // would be ill-conditioned).
 template <int G>
-DI void collide_one(const float* lds, float* recs, const int i, const int gl, const int gbase, const DevModel& M, const DevCfg& C, const float se, const float dz,
-                    const f3 Kx, const f3 Ksx, const f3 Ksy, const f3 Ksz, int& nc) {
-    const int eraw = i * G + gl, e = eraw < N_TOP ? eraw : N_TOP - 1;
+DI void collide_elem(const float* lds, float* recs, const bool valid, const int e, const int gl, const int gbase, const DevModel& M, const DevCfg& C, const float se, const float dz,
+                     const f3 Kx, const f3 Ksx, const f3 Ksy, const f3 Ksz, int& nc) {
     const f3 ax = mk(lds[TB_AXIS + 3 * e], lds[TB_AXIS + 3 * e + 1], lds[TB_AXIS + 3 * e + 2]);
     const f3 tip = mk(M.torso[0] + lds[TB_POS + 3 * e], M.torso[1] + lds[TB_POS + 3 * e + 1], M.torso[2] + lds[TB_POS + 3 * e + 2] + dz) + ax * (se - ELEM_R);
     const f3 rel = tip - Kx;
@@ -168,7 +167,7 @@ DI void collide_one(const float* lds, float* recs, const int i, const int gl, co
     const float s0 = dot(g0, us), s1 = dot(g1, us);
     const float tt = clampf(-s0 * rcp_(fmaxf(s1 - s0, 0.f) + SHAFT_EPS), 0.f, 1.f);
     const float dist = probe_sdf(C, madd(p0, us, tt), gs) - ELEM_R;
-    const bool hit = (eraw < N_TOP) && (dist < 0.f);
+    const bool hit = valid && (dist < 0.f);
     const f3 nn = (Ksx * gs.x + Ksy * gs.y + Ksz * gs.z) * -1.f;                 // from the element towards the probe
     const f3 rr = madd(tip, ax, -2.f * ELEM_HL * tt) + nn * (ELEM_R + 0.5f * dist) - Kx;
     const unsigned long long bal = __ballot(hit);
@@ -179,6 +178,37 @@ DI void collide_one(const float* lds, float* recs, const int i, const int gl, co
     rec[0] = make_float4(nn.x, nn.y, nn.z, rr.x);
     rec[1] = make_float4(rr.y, rr.z, __int_as_float(e), dist);
     nc += __popc(gm);
+}
+
+// round form: element i G + gl of this lane's environment (the single-wave kernels walk all rounds)
+template <int G>
+DI void collide_one(const float* lds, float* recs, const int i, const int gl, const int gbase, const DevModel& M, const DevCfg& C, const float se, const float dz,
+                    const f3 Kx, const f3 Ksx, const f3 Ksy, const f3 Ksz, int& nc) {
+    const int eraw = i * G + gl;
+    collide_elem<G>(lds, recs, eraw < N_TOP, eraw < N_TOP ? eraw : N_TOP - 1, gl, gbase, M, C, se, dz, Kx, Ksx, Ksy, Ksz, nc);
+}
+
+// Broad phase (split kernel).  The probe -- convex hull of two parallel capsules whose axes are probe_h apart -- lies inside the capsule of
+// radius probe_r + probe_h around its UPPER axis; an element's capsule lies inside the ball of radius ELEM_HL + ELEM_R around the midpoint of its
+// axis segment.  An element whose ball misses that capsule cannot touch the probe: 80 % of the 99 elements, for 20 instructions each instead
+// of three distance evaluations.  The survivors go, in ascending element order, into a queue that the lanes of the group then walk together
+// (collide_queue): typically one pass of 16 instead of seven rounds.
+DI bool collide_cull(const float* lds, const int e, const DevModel& M, const DevCfg& C, const float se, const float dz, const f3 Kx, const f3 Ksx, const f3 Ksz) {
+    const f3 ax = mk(lds[TB_AXIS + 3 * e], lds[TB_AXIS + 3 * e + 1], lds[TB_AXIS + 3 * e + 2]);
+    const f3 mid = mk(M.torso[0] + lds[TB_POS + 3 * e], M.torso[1] + lds[TB_POS + 3 * e + 1], M.torso[2] + lds[TB_POS + 3 * e + 2] + dz) + ax * (se - ELEM_R - ELEM_HL);
+    const f3 d = mid - (Kx - Ksz * (C.probe_r + C.probe_h));                       // from the centre of the upper axis (site z points away from the probe body)
+    const f3 v = d - Ksx * clampf(dot(d, Ksx), -C.probe_hl, C.probe_hl);
+    return dot(v, v) < C.probe_cull2;
+}
+template <int G>
+DI void collide_queue(const float* lds, const float* queue, const int q0, const int q1, float* recs, const int gl, const int gbase, const DevModel& M, const DevCfg& C,
+                      const float* s_lds, const float dz, const f3 Kx, const f3 Ksx, const f3 Ksy, const f3 Ksz, int& nc) {
+    for (int j0 = q0; __any(j0 < q1); j0 += G) {
+        const int j = j0 + gl;
+        const bool valid = j < q1;
+        const int e = valid ? __float_as_int(queue[j]) : 0;
+        collide_elem<G>(lds, recs, valid, e, gl, gbase, M, C, s_lds[e], dz, Kx, Ksx, Ksy, Ksz, nc);
+    }
 }
 
 // More penetrating elements than contact slots (rare in a mixed batch, common right after a synchronous reset): keep the MAXC deepest of the
@@ -240,10 +270,10 @@ DI void contact_overflow(float* lds, const int eb, const int gl, const int gbase
 // the right-hand side of the soft-equality system, a~ = Linv rhs, collide the probe capsule with the 99 cap spheres and
 // leave the contact records (ascending shell id; the MAXC deepest when more were found) in LDS.  Returns the number found (may exceed MAXC).
 // PART 0: everything; 1: staging + right-hand side only (needs no arm quantity); 2: solve + collision only (after a PART 1 call).
-template <int G, int NE, bool MM, int PART = 0, int R0 = 0>
+template <int G, int NE, bool MM, int PART = 0, bool QM = false>
 DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, const DevModel& M, const DevCfg& C, const int tsim,
                      const float kst, const float kdmp, const bool live, const float* s_pre, const float* sd_pre,
-                     const f3 Kx, const f3 Ksy, const f3 Ksz, unsigned long long* dbg) {
+                     const f3 Kx, const f3 Ksy, const f3 Ksz, unsigned long long* dbg, const float* queue = nullptr, const int q0 = 0, const int q1 = 0) {
 #if !defined(USIM_TSTAMP) && !defined(USIM_TSTAMP_NOWAIT)
 #define LSTAMP(k) do { } while (0)
 #else
@@ -295,14 +325,15 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                     }
                     if constexpr (PART == 1) return 0;
                     LSTAMP(5);
-                                    // ---- collision rounds R0 .. NE - 1 (collide_one): scheduled between the pieces of the matrix-core solve below.  (The
-                    //      split kernel gives rounds 0 .. R0 - 1 to the arm wave, which has the site pose first and would otherwise wait for this
-                    //      wave at the barrier; the two lists are merged after it: merge_contact_lists.) ----
+                                    // ---- collision: seven rounds of one element per lane (collide_one), scheduled between the pieces of the matrix-core
+                    //      solve below -- or, in the split kernel (QM), this wave's share [q0, q1) of the broad phase's queue (collide_cull / collide_queue;
+                    //      the arm wave, which has the site pose first, builds the queue and takes the other share; the two hit lists are merged
+                    //      after hand-off (2)) ----
                     const f3 Ksx = cross(Ksy, Ksz);
                     int nc = 0;
                     auto collide_round = [&](const int i) {
-                        if (i < R0) return;
-                        collide_one<G>(lds, &EBF(GE_CG), i, gl, gbase, M, C, live ? s_pre[i] : 0.f, dz, Kx, Ksx, Ksy, Ksz, nc);
+                        if constexpr (QM) { if (i == 0) collide_queue<G>(lds, queue, q0, q1, &EBF(GE_CG), gl, gbase, M, C, &EBF(GE_S), dz, Kx, Ksx, Ksy, Ksz, nc); }
+                        else collide_one<G>(lds, &EBF(GE_CG), i, gl, gbase, M, C, live ? s_pre[i] : 0.f, dz, Kx, Ksx, Ksy, Ksz, nc);
                     };
                                     // ---- a~ = Linv * rhs ----
                     if constexpr (MM) {
@@ -388,7 +419,7 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
     #pragma unroll
                         for (int i = 0; i < NE; ++i) collide_round(i);
                     }
-                    if constexpr (R0 == 0) contact_overflow<G>(lds, eb, gl, gbase, nc);
+                    if constexpr (!QM) contact_overflow<G>(lds, eb, gl, gbase, nc);
     return nc;
 #undef EBF
 #undef LSTAMP

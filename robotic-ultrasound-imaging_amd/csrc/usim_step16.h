@@ -165,11 +165,14 @@ constexpr int X16_RIGID_STRIDE = 68;                  // rigid-torso launches: o
 // LDS mailboxes: site pose (1 -> 2), Lambda^-1 / alpha / vs (1 -> 2), contact wrench and contact list (2 -> 1).  ROLE 0 = one wave does both.
 constexpr int X2_BASE = TB_WORDS + 16 * GE_STRIDE;        // behind the sixteen per-environment blocks: arm scratch + mailboxes of the split kernel
 // 64 transpose scratch | 12 pose (+ the arm side's hit count in word 9) | 64 op-space (6 x 8 Lambda^-1, alpha 6, vs 6) | 16 wrench + contacts | the arm side's contact records
-constexpr int MB_POSE = 64, MB_OP = 76, MB_W = 140, MB_CA = 156, X2_STRIDE = MB_CA + (MAXCAND + 1) * CG_WORDS;
+constexpr int MB_POSE = 64, MB_OP = 76, MB_W = 140, MB_CA = 156, MB_Q = MB_CA + (MAXCAND + 1) * CG_WORDS, X2_STRIDE = MB_Q + 100;   // ... | broad-phase queue (element ids)
 static_assert(MB_W + 16 <= MB_CA && (MB_CA % 4) == 0 && (X2_STRIDE % 4) == 0, "mailbox block");
-// Collision rounds of the split kernel that the ARM side runs (elements 0 .. 16 ARM_ROUNDS - 1): it has the site pose first and would
-// otherwise wait at hand-off (2) for the lattice side, whose matrix-core solve + seven rounds are the longer path (profiles/r03/timeline_*)
-constexpr int ARM_ROUNDS = 7;
+// Collision in the split kernel: the ARM side, which has the site pose first, runs the broad phase over all 99 elements (collide_cull) while the
+// lattice side still stages its right-hand side, and leaves the survivors' ids (ascending) in the queue; after hand-off (1) the arm side takes
+// the first ARM_SHARE_NUM / ARM_SHARE_DEN of the queue, the lattice side the rest, each typically in one pass of its 16 lanes per environment.
+// (With the broad phase the narrow phase is short enough that the lattice side does best with all of it; the sharing machinery stays for
+// other probe shapes.)
+constexpr int ARM_SHARE_NUM = 0, ARM_SHARE_DEN = 1;     // measured (us/step, one box): 0 -> 15.48, 1/4 -> 15.80, 1/3 -> 15.61, 1/2 -> 15.77
 
 template <int TORSO, int MODE, int ROLE, int NT>
 DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __restrict__ st, const int n, const int npad, const DevIO& io, const int flags, const long long rstep,
@@ -242,7 +245,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         const int e = gl + i * G;
         s_pre[i] = 0.f; sd_pre[i] = 0.f;
         if (TORSO && MODE == 0 && ROLE != 1 && e < N_TOP) { s_pre[i] = LAT(LAT_S + e); sd_pre[i] = LAT(LAT_SD + e); }
-        if (TORSO && MODE == 0 && ROLE == 1 && i < ARM_ROUNDS && e < N_TOP) s_pre[i] = LAT(LAT_S + e);      // the arm side collides these elements
+        if (TORSO && MODE == 0 && ROLE == 1 && e < N_TOP) s_pre[i] = LAT(LAT_S + e);      // the arm side runs the broad phase of the collision
     }
     if (TORSO != 0 && item0 == item_first && first_pass) {
         // workgroup-resident copy of the lattice tables: 16-byte loads, all issued before the first LDS store (and behind the state loads
@@ -280,11 +283,12 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         RSTAMP(2);
         const f3 xs = mk(mb[MB_POSE], mb[MB_POSE + 1], mb[MB_POSE + 2]), sy = mk(mb[MB_POSE + 3], mb[MB_POSE + 4], mb[MB_POSE + 5]),
                  sz = mk(mb[MB_POSE + 6], mb[MB_POSE + 7], mb[MB_POSE + 8]);
-        const int ncl = lattice_front<G, NE, true, 2, ARM_ROUNDS>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, true, s_pre, sd_pre, xs, sy, sz, dbg);
+        const int nq = __float_as_int(mb[MB_POSE + 10]), na = (nq * ARM_SHARE_NUM + ARM_SHARE_DEN - 1) / ARM_SHARE_DEN;
+        const int ncl = lattice_front<G, NE, true, 2, true>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, true, s_pre, sd_pre, xs, sy, sz, dbg, mb + MB_Q, na, nq);
         RSTAMP(3);
         __syncthreads();                                                 // (2) ... and Lambda^-1, alpha = J qs, vs = J qd, and the arm side's contact records
         RSTAMP(4);
-        // one list in ascending shell id: the arm side's records (elements 0 .. 16 ARM_ROUNDS - 1) first, this side's behind them
+        // one list in ascending shell id: the arm side's records (first part of the queue) first, this side's behind them
         const int nca = __float_as_int(mb[MB_POSE + 9]);
         int nc = nca + ncl;
         if (__any(nca > 0)) {
@@ -446,6 +450,24 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
     const f3 sx = rbc3<7>(X), sy = rbc3<7>(Y), sz = rbc3<7>(Z), xs = rbc3<7>(P);
     const f3 hand = rbc3<NJ - 1>(P + X * M.hand7[0] + Y * M.hand7[1] + Z * M.hand7[2]);
     if constexpr (ROLE == 1) {
+        {
+            // broad phase of the collision (collide_cull): element ids that can touch the probe, ascending, into the queue; element positions
+            // into the environment's LDS block for whoever evaluates them
+            float dz_, vz_, az_;
+            torso_motion(C, t - 1, dz_, vz_, az_);
+            const f3 sxc = cross(sy, sz);
+            int nq = 0;
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const int eraw = i * G + gl, e = eraw < N_TOP ? eraw : N_TOP - 1;
+                if (eraw < N_TOP) EB(GE_S + eraw) = s_pre[i];
+                const bool cand = (eraw < N_TOP) && collide_cull(lds, e, M, C, s_pre[i], dz_, xs, sxc, sz);
+                const unsigned gm = (unsigned)(__ballot(cand) >> gbase) & 0xffffu;
+                if (cand) xl[MB_Q + nq + __popc(gm & ((1u << gl) - 1u))] = __int_as_float(e);
+                nq += __popc(gm);
+            }
+            if (gl == 0) xl[MB_POSE + 10] = __int_as_float(nq);
+        }
         if (gl == 7) {                                                   // the site frame is lane 7's own
             float* mbp = xl + MB_POSE;
             mbp[0] = P.x; mbp[1] = P.y; mbp[2] = P.z; mbp[3] = Y.x; mbp[4] = Y.y; mbp[5] = Y.z; mbp[6] = Z.x; mbp[7] = Z.y; mbp[8] = Z.z;
@@ -696,13 +718,13 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
     for (int k = 0; k < MAXC; ++k) con_shell[k] = -1;
     if constexpr (ROLE == 1) {
         {
-            // the arm side's share of the collision: elements 0 .. 16 ARM_ROUNDS - 1 against the site pose it computed itself
+            // the arm side's share of the narrow phase: the first part of the queue against the site pose it computed itself
             float dz_, vz_, az_;
             torso_motion(C, t - 1, dz_, vz_, az_);
             const f3 sxc = cross(sy, sz);
+            const int nq = __float_as_int(xl[MB_POSE + 10]), na = (nq * ARM_SHARE_NUM + ARM_SHARE_DEN - 1) / ARM_SHARE_DEN;
             int nca = 0;
-#pragma unroll
-            for (int i = 0; i < ARM_ROUNDS; ++i) collide_one<G>(lds, xl + MB_CA, i, gl, gbase, M, C, s_pre[i], dz_, xs, sxc, sy, sz, nca);
+            collide_queue<G>(lds, xl + MB_Q, 0, na, xl + MB_CA, gl, gbase, M, C, &EB(GE_S), dz_, xs, sxc, sy, sz, nca);
             if (gl == 0) xl[MB_POSE + 9] = __int_as_float(nca);
         }
         // hand Lambda^-1 (row a from task lane a), alpha = J qs and vs = J qd to the lattice side; take the contact wrench back

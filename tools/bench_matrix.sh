@@ -1,0 +1,19 @@
+#!/bin/bash
+# one-box comparison of the bench configurations (box-to-box variation is ~5 %: only numbers from one call are comparable)
+# usage: tools/bench_matrix.sh  ->  gpurun_out/bench_matrix.txt
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/bench_matrix.txt; : > "$OUT"
+run() { label=$1; shift; python3 "$ROOT/bench.py" --no-cpu-baseline "$@" 2>/dev/null | tail -1 | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print('%-34s %8.1f M env-steps/s  %7.2f us/step  kernel %7.2f us  frac %.4f  lanes %s  spl %s' % ('$label', d['value'] / 1e6, d['ms_per_step'] * 1e3, d['roofline']['avg_kernel_us'], d['roofline']['frac'], d['config']['lanes_per_env'], d['config']['steps_per_launch']))" | tee -a "$OUT"; }
+run "configs[2] soft 4096"            --steps 2000 --warmup 100
+run "configs[2] soft 4096 spl 1"      --steps 2000 --warmup 100 --steps-per-launch 1
+run "configs[2] driver-style 20/5"    --steps 20 --warmup 5
+run "configs[2] lanes 16"             --steps 2000 --warmup 100 --lanes-per-env 16
+run "configs[1] rigid 4096"           --steps 2000 --warmup 100 --workload rigid
+run "configs[4] 8192 randomised auto" --steps 1000 --warmup 100 --envs-per-gpu 8192 --randomize
+run "configs[4] 8192 randomised l32"  --steps 1000 --warmup 100 --envs-per-gpu 8192 --randomize --lanes-per-env 32
+run "configs[4] 8192 randomised l8"   --steps 1000 --warmup 100 --envs-per-gpu 8192 --randomize --lanes-per-env 8
+run "soft 16384 auto"                 --steps 500 --warmup 100 --envs-per-gpu 16384
+run "soft 16384 l32"                  --steps 500 --warmup 100 --envs-per-gpu 16384 --lanes-per-env 32
