@@ -172,6 +172,7 @@ static_assert(MB_W + 16 <= MB_CA && (MB_CA % 4) == 0 && (X2_STRIDE % 4) == 0, "m
 // the first ARM_SHARE_NUM / ARM_SHARE_DEN of the queue, the lattice side the rest, each typically in one pass of its 16 lanes per environment.
 // (With the broad phase the narrow phase is short enough that the lattice side does best with all of it; the sharing machinery stays for
 // other probe shapes.)
+constexpr int ARM_CULL_ROUNDS = 7;                   // broad-phase rounds the arm side runs before hand-off (1); the lattice side runs the rest after it.  Measured (us/step, one box): 0 -> 15.67, 2 -> 15.98, 4 -> 15.92, 7 (all) -> 15.48
 constexpr int ARM_SHARE_NUM = 0, ARM_SHARE_DEN = 1;     // measured (us/step, one box): 0 -> 15.48, 1/4 -> 15.80, 1/3 -> 15.61, 1/2 -> 15.77
 
 template <int TORSO, int MODE, int ROLE, int NT>
@@ -283,7 +284,21 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         RSTAMP(2);
         const f3 xs = mk(mb[MB_POSE], mb[MB_POSE + 1], mb[MB_POSE + 2]), sy = mk(mb[MB_POSE + 3], mb[MB_POSE + 4], mb[MB_POSE + 5]),
                  sz = mk(mb[MB_POSE + 6], mb[MB_POSE + 7], mb[MB_POSE + 8]);
-        const int nq = __float_as_int(mb[MB_POSE + 10]), na = (nq * ARM_SHARE_NUM + ARM_SHARE_DEN - 1) / ARM_SHARE_DEN;
+        int nq = __float_as_int(mb[MB_POSE + 10]);
+        {
+            // the rest of the broad phase (elements 16 ARM_CULL_ROUNDS ..): appended to the arm side's part of the queue
+            const f3 sxc = cross(sy, sz);
+#pragma unroll
+            for (int i = ARM_CULL_ROUNDS; i < NE; ++i) {
+                const int eraw = i * G + gl, e = eraw < N_TOP ? eraw : N_TOP - 1;
+                const bool cand = (eraw < N_TOP) && collide_cull(lds, e, M, C, s_pre[i], dz, xs, sxc, sz);
+                const unsigned gm = (unsigned)(__ballot(cand) >> gbase) & 0xffffu;
+                if (cand) mb[MB_Q + nq + __popc(gm & ((1u << gl) - 1u))] = __int_as_float(e);
+                nq += __popc(gm);
+            }
+            group_sync();
+        }
+        const int na = (__float_as_int(mb[MB_POSE + 10]) * ARM_SHARE_NUM + ARM_SHARE_DEN - 1) / ARM_SHARE_DEN;
         const int ncl = lattice_front<G, NE, true, 2, true>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, true, s_pre, sd_pre, xs, sy, sz, dbg, mb + MB_Q, na, nq);
         RSTAMP(3);
         __syncthreads();                                                 // (2) ... and Lambda^-1, alpha = J qs, vs = J qd, and the arm side's contact records
@@ -461,6 +476,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
             for (int i = 0; i < NE; ++i) {
                 const int eraw = i * G + gl, e = eraw < N_TOP ? eraw : N_TOP - 1;
                 if (eraw < N_TOP) EB(GE_S + eraw) = s_pre[i];
+                if (i >= ARM_CULL_ROUNDS) continue;
                 const bool cand = (eraw < N_TOP) && collide_cull(lds, e, M, C, s_pre[i], dz_, xs, sxc, sz);
                 const unsigned gm = (unsigned)(__ballot(cand) >> gbase) & 0xffffu;
                 if (cand) xl[MB_Q + nq + __popc(gm & ((1u << gl) - 1u))] = __int_as_float(e);
