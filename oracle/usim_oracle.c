@@ -135,7 +135,7 @@ static const double PROBE_POS[3] = {-0.004, -0.063, 0.128};   /* ultrasound_prob
 #define PROBE_MASS 1.0                                         /* ultrasound_probe_gripper.xml:8 */
 /* The probe mesh is missing from the reference snapshot (.MISSING_LARGE_BLOBS:1): stand-in geometry.  Collision shape = flared blade
  * (probe_sdf), long axis = site x (docs/images/frontview.png, sideview.png: the transducer is wide along world y at goal_quat), sizes
- * calibrated on the 192 decoded reset observations (tools/calib_probe.py; tests/test_oracle_env_formulas.py) */
+ * calibrated on the 192 decoded reset observations (tests/calib_probe.py; tests/test_oracle_env_formulas.py) */
 static const double PROBE_COM[3] = {0.0013, 0.021, -0.043};
 static const double PROBE_INERTIA[3] = {1.6e-3, 1.6e-3, 2.0e-4};
 #define PROBE_RADIUS 0.012

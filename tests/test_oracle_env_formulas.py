@@ -113,7 +113,7 @@ DEPTH_BINS = ((-0.030, -0.015), (-0.015, -0.005), (-0.005, 0.0), (0.0, 0.005), (
 def check_reset_rows_against_reference(obs, ref):
     """Shared by the oracle test below and its GPU twin (tests/test_gpu_properties.py): the six force / torque channels of a batch of
     reset observations against the 192 reset rows decoded from the reference checkpoints (calibration record
-    profiles/r03/calib_probe.txt, tools/calib_probe.py).  Bands: +-30 % on the spread of Fx, Fz, torque x, torque y, +-25 % + 2 N on
+    profiles/r03/calib_probe.txt, tests/calib_probe.py).  Bands: +-30 % on the spread of Fx, Fz, torque x, torque y, +-25 % + 2 N on
     the binned force-depth curve.  KNOWN GAP, asserted at its measured size so that it cannot grow silently: the spread of Fy (reference
     8.4 N, here 3.8 N) and of the torque about the probe axis (0.33 vs 0.09 N m) -- the reference's lateral forces act through
     fewer, stronger contacts than this lattice + primitive probe produces."""
