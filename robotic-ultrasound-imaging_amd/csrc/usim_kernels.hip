@@ -105,6 +105,13 @@ DI float group_bcast(float v, int k) {
 #define USIM_STAMP(dbg, k) do { if ((dbg) && blockIdx.x == 0 && threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); (dbg)[k] = __builtin_readcyclecounter(); } } while (0)
 #endif
 
+// contact-solve phases of the lattice wave of the split kernel (first lattice wave of workgroup 0): dbg[40..45]
+#if !defined(USIM_TSTAMP) && !defined(USIM_TSTAMP_NOWAIT)
+#define USIM_CSTAMP(dbg, k) do { } while (0)
+#else
+#define USIM_CSTAMP(dbg, k) do { if ((dbg) && blockIdx.x == 0 && threadIdx.x == 256) (dbg)[40 + (k)] = __builtin_readcyclecounter(); } while (0)
+#endif
+
 // prescribed torso base motion: free fall over the 4.7 mm spawn gap, then rest (ultrasound.py:313)
 DI void torso_motion(const DevCfg& C, int tsim, float& dz, float& vz, float& az) {
     dz = -C.drop; vz = 0.f; az = 0.f;
@@ -436,6 +443,7 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
 #define EB(off) lds[TB_WORDS + eb * GE_STRIDE + (off)]
     // ---- contact k lives in the registers of lane k of its group.  Set-up: row directions w, Lambda^-1 w, element
     //      coupling g, reference acceleration, regulariser; Km[c] = Linv[e_own][e_c] / m ----
+    USIM_CSTAMP(dbg, 0);
     const bool own = gl < nc;
     float w[3][6], Liw[3][6], g[3], invD[3], Rd[3], f[3] = {0.f, 0.f, 0.f}, cres[3] = {0.f, 0.f, 0.f}, Km[MAXC];
 #pragma unroll
@@ -487,6 +495,7 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
         }
     }
     USIM_STAMP(dbg, 9);
+    USIM_CSTAMP(dbg, 1);
     // ---- Delassus blocks: B[k][d][d'] = d(residual of row d of this lane's contact) / d(force on row d' of contact k)
     //      = w_d . Lambda^-1 w^k_d' + g_d Km[k] g^k_d' (+ the regulariser on the diagonal of the lane's own block); the sweeps below then
     //      need three broadcasts per visit.
@@ -534,6 +543,7 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
             }
         }
     }
+    USIM_CSTAMP(dbg, 2);
     // ---- projected Gauss-Seidel on the dual over the contact rows (fixed sweeps, cold start).  Contacts are visited in
     //      ascending order.  The owner relaxes its three rows in order (normal, t1, t2; the earlier rows' updates enter
     //      through its own block), projects on the cone and shares the three force increments; every lane then moves its
@@ -589,6 +599,7 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
         default: sweeps(std::integral_constant<int, 8>{}); break;
     }
     USIM_STAMP(dbg, 10);
+    USIM_CSTAMP(dbg, 3);
     // ---- contact wrench on the site and impulse along each element axis (lanes without a contact hold w = g = f = 0, i.e. contribute
     //      zeros) ----
     {
@@ -628,6 +639,7 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
             }
         }
     }
+    USIM_CSTAMP(dbg, 4);
 #undef EB
 }
 

@@ -175,9 +175,16 @@ static_assert(MB_W + 16 <= MB_CA && (MB_CA % 4) == 0 && (X2_STRIDE % 4) == 0, "m
 constexpr int ARM_CULL_ROUNDS = 7;                   // broad-phase rounds the arm side runs before hand-off (1); the lattice side runs the rest after it.  Measured (us/step, one box): 0 -> 15.67, 2 -> 15.98, 4 -> 15.92, 7 (all) -> 15.48
 constexpr int ARM_SHARE_NUM = 0, ARM_SHARE_DEN = 1;     // measured (us/step, one box): 0 -> 15.48, 1/4 -> 15.80, 1/3 -> 15.61, 1/2 -> 15.77
 
+// workgroup barrier of the step kernels; the profiling build counts them per role (BARRIER INVARIANT at usim_step32_kernel)
+#if defined(USIM_TSTAMP) || defined(USIM_TSTAMP_NOWAIT)
+#define USIM_BAR() do { __syncthreads(); ++nbar; } while (0)
+#else
+#define USIM_BAR() __syncthreads()
+#endif
+
 template <int TORSO, int MODE, int ROLE, int NT>
 DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __restrict__ st, const int n, const int npad, const DevIO& io, const int flags, const long long rstep,
-                   const bool first_pass) {
+                   const bool first_pass, int& nbar) {
     constexpr int G = 16, EPW = 4, EPB = 16;
     constexpr int NE = TORSO ? (N_TOP + G - 1) / G : 1;
     static_assert(ROLE == 0 || (TORSO == 1 && MODE == 0), "the split kernel is the soft-torso step");
@@ -259,7 +266,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         for (int i = 0; i < PER; ++i) { int idx = threadIdx.x + i * NT; tmp[i] = (idx < NV) ? src[idx] : make_float4(0, 0, 0, 0); }
 #pragma unroll
         for (int i = 0; i < PER; ++i) { int idx = threadIdx.x + i * NT; if (idx < NV) dst[idx] = tmp[i]; }
-        __syncthreads();
+        USIM_BAR();
     }
     USIM_STAMP(dbg, 1);
 
@@ -280,7 +287,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         torso_motion(C, tsim, dz, vz, az);
         lattice_front<G, NE, true, 1>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, true, s_pre, sd_pre, mk(0, 0, 0), mk(0, 0, 0), mk(0, 0, 0), dbg);
         RSTAMP(1);
-        __syncthreads();                                                 // (1) the arm side has published the site pose
+        USIM_BAR();                                                 // (1) the arm side has published the site pose
         RSTAMP(2);
         const f3 xs = mk(mb[MB_POSE], mb[MB_POSE + 1], mb[MB_POSE + 2]), sy = mk(mb[MB_POSE + 3], mb[MB_POSE + 4], mb[MB_POSE + 5]),
                  sz = mk(mb[MB_POSE + 6], mb[MB_POSE + 7], mb[MB_POSE + 8]);
@@ -301,7 +308,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         const int na = (__float_as_int(mb[MB_POSE + 10]) * ARM_SHARE_NUM + ARM_SHARE_DEN - 1) / ARM_SHARE_DEN;
         const int ncl = lattice_front<G, NE, true, 2, true>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, true, s_pre, sd_pre, xs, sy, sz, dbg, mb + MB_Q, na, nq);
         RSTAMP(3);
-        __syncthreads();                                                 // (2) ... and Lambda^-1, alpha = J qs, vs = J qd, and the arm side's contact records
+        USIM_BAR();                                                 // (2) ... and Lambda^-1, alpha = J qs, vs = J qd, and the arm side's contact records
         RSTAMP(4);
         // one list in ascending shell id: the arm side's records (first part of the queue) first, this side's behind them
         const int nca = __float_as_int(mb[MB_POSE + 9]);
@@ -342,7 +349,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
             for (int k = 0; k < MAXC; ++k) mb[MB_W + 8 + k] = __int_as_float((k < nc) ? tb_shell[cel[k]] : -1);
         }
         RSTAMP(5);
-        __syncthreads();                                                 // (3) contact wrench and contact list published
+        USIM_BAR();                                                 // (3) contact wrench and contact list published
         RSTAMP(6);
         {
             float acc_e[NE];
@@ -368,7 +375,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
             }
         }
         RSTAMP(7);
-        __syncthreads();                                                 // (4) lattice stored: the arm side may now zero it for an episode that ended
+        USIM_BAR();                                                 // (4) lattice stored: the arm side may now zero it for an episode that ended
         RSTAMP(8);
         return;
     }
@@ -489,7 +496,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
             mbp[0] = P.x; mbp[1] = P.y; mbp[2] = P.z; mbp[3] = Y.x; mbp[4] = Y.y; mbp[5] = Y.z; mbp[6] = Z.x; mbp[7] = Z.y; mbp[8] = Z.z;
         }
         if constexpr (ROLE == 1) RSTAMP(1);
-        __syncthreads();                                                 // (1)
+        USIM_BAR();                                                 // (1)
         if constexpr (ROLE == 1) RSTAMP(2);
     }
 
@@ -752,11 +759,11 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
             mbo[48 + arow] = alpha_t; mbo[54 + arow] = v6;
         }
         RSTAMP(3);
-        __syncthreads();                                                 // (2)
+        USIM_BAR();                                                 // (2)
         RSTAMP(4);
         precompute();                                                    // ... while the lattice side solves the contacts
         RSTAMP(5);
-        __syncthreads();                                                 // (3) the lattice side has solved the contacts
+        USIM_BAR();                                                 // (3) the lattice side has solved the contacts
         RSTAMP(6);
         const float4 w0 = *reinterpret_cast<const float4*>(&xl[MB_W]), w1 = *reinterpret_cast<const float4*>(&xl[MB_W + 4]);
         W[0] = w0.x; W[1] = w0.y; W[2] = w0.z; W[3] = w0.w; W[4] = w1.x; W[5] = w1.y;
@@ -960,7 +967,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         }
     }
 
-    if constexpr (ROLE == 1) { RSTAMP(7); __syncthreads(); RSTAMP(8); }   // (4) the lattice side has stored the integrated lattice
+    if constexpr (ROLE == 1) { RSTAMP(7); USIM_BAR(); RSTAMP(8); }   // (4) the lattice side has stored the integrated lattice
     if (MODE == 0 && need) {
         // ================= auto-reset: adopt the initial state prepared in the reset bank and queue the slot for refill =================
         episode += 1;
@@ -1024,13 +1031,14 @@ DI void step16_body(float* lds, const DevModel& M, const DevCfg& C, float* __res
     // straight-line kernel; the loop costs it 2 us per step)
     const int nsub = (MULTI && MODE == 0 && io0.nsub > 1) ? io0.nsub : 1;
     DevIO io = io0;
+    int nbar = 0;                                                        // barriers executed by this wave (read by the profiling build only)
     for (int ks = 0; ks < nsub; ++ks) {
-        step16_one<TORSO, MODE, ROLE, NT>(lds, M, C, st, n, npad, io, flags, rstep + ks, ks == 0);
+        step16_one<TORSO, MODE, ROLE, NT>(lds, M, C, st, n, npad, io, flags, rstep + ks, ks == 0, nbar);
         if (ks + 1 < nsub) {
             // the next step reads the state words this one stored -- some through other lanes of the group, the per-episode scalars through the
             // other wave of the pair (split kernel): order the stores, then meet.  (Both roles of the split kernel pass here once per step.)
             __threadfence_block();
-            __syncthreads();
+            USIM_BAR();
             if (io0.block) {
                 const size_t nn = (size_t)n;
                 io.obs += nn * OBS_DIM; io.rew += nn; io.done += nn;
@@ -1042,6 +1050,9 @@ DI void step16_body(float* lds, const DevModel& M, const DevCfg& C, float* __res
             }
         }
     }
+#if defined(USIM_TSTAMP) || defined(USIM_TSTAMP_NOWAIT)
+    if (ROLE != 0 && io0.dbg && blockIdx.x == 0 && (threadIdx.x & 255) == 0) io0.dbg[ROLE == 1 ? 46 : 47] = (unsigned long long)nbar;
+#endif
 }
 
 template <int TORSO, int OCC, int MODE, bool MULTI = false>
@@ -1057,7 +1068,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 // execute __syncthreads() at DIFFERENT program points, so both must execute exactly the same NUMBER of barriers on every path -- per step: the
 // table copy (first step of a launch), hand-offs (1)-(4) of step16_one, and the one between consecutive steps of a multi-step launch.  An
 // early return, a barrier under a branch that is not uniform over the whole workgroup, or a fifth hand-off on one side only would hang the
-// GPU instead of failing a test.  The profiling build counts the barriers of both roles (USIM_TSTAMP: dbg[29] / dbg[39]) and
+// GPU instead of failing a test.  The profiling build counts the barriers of both roles (USIM_BAR: ticks[46] / ticks[47] of usim_profile_step) and
 // tests/test_gpu_properties.py compares them; the split-vs-single-wave bit-exactness tests cover ragged workgroups and slot overflow.
 template <bool MULTI>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void usim_step32_kernel(const DevModel M, const DevCfg C, float* __restrict__ st, int n, int npad,

@@ -20,12 +20,12 @@ MARGIN = {"contact": 5e-6,   # m     : |capsule distance| below which the contac
           "joint": 1e-4}     # rad
 
 
-def _mk(usim, n, torso, mode, seed=3, omp=False, robot="Panda", precision="f64", **extra):
+def _mk(usim, n, torso, mode, seed=3, omp=False, robot="Panda", precision="f64", gpu_extra=None, **extra):
     kw = usim.default_robosuite_kwargs()
     kw["controller_configs"] = dict(kw["controller_configs"], impedance_mode=mode)
     kw["robots"] = robot
     kw.update(extra)                                   # options that exist on both sides under the same name
-    env = usim.UltrasoundVecEnv(n, device="cuda:0", seed=seed, torso=torso, **kw)
+    env = usim.UltrasoundVecEnv(n, device="cuda:0", seed=seed, torso=torso, **kw, **(gpu_extra or {}))      # gpu_extra: kernel mapping etc.
     ora = Oracle(n, precision=precision, omp=omp, mode=mode, torso="top" if torso == "soft" else "none", seed=seed, robot=robot, **extra)
     return env, ora
 
@@ -161,6 +161,15 @@ def test_full_size_parity_4096_envs(usim):
     import os
     os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 64)))
     _run_parity(usim, 4096, 200, "soft", "tracking", omp=True)
+
+
+@pytest.mark.parametrize("mapping", [{"lanes_per_env": 8}, {"lanes_per_env": 16, "waves_per_simd": 1}, {"lanes_per_env": 16, "waves_per_simd": 2}],
+                         ids=["8-lane", "16-lane-occ1", "16-lane-occ2"])
+def test_every_kernel_mapping_holds_the_full_parity_bars(usim, mapping):
+    """The non-default mappings -- the round-1 kernel with the arm mathematics replicated over 8 lanes, the single-wave 16-lane kernel in both
+    register budgets -- through the same check as the default split kernel: 200 steps, done flags and contact indices bit-exact, every
+    observation channel and the state within the oracle bars (they share the lattice / contact phases, not the arm mathematics)."""
+    _run_parity(usim, 256, 200, "soft", "tracking", gpu_extra=mapping)
 
 
 def test_residual_is_precision_not_logic(usim):

@@ -1,9 +1,13 @@
 """Size-independent properties of the HIP path at BASELINE's full size (4096 / 8192 envs per GPU) and the VecEnv protocol."""
+import os
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
 
 
 def _env(usim, n, torso="soft", **kw):
@@ -339,3 +343,31 @@ def test_mapping_can_change_in_the_middle_of_a_rollout(usim):
         rigid.set_mapping(32, 0)
     for e in (a, b, rigid):
         e.close()
+
+
+def test_split_kernel_roles_execute_the_same_number_of_barriers(usim, tmp_path):
+    """The two roles of usim_step32_kernel meet at workgroup barriers placed at different program points (outside the HIP programming model; the
+    invariant is stated at the kernel): the profiling build counts the barriers each role executes -- table copy + four hand-offs per step --
+    and they must agree, also for a ragged last workgroup and right after a reset that overflows the contact slots."""
+    import subprocess, sys, textwrap
+    csrc = ROOT / "robotic-ultrasound-imaging_amd" / "csrc"
+    prof = ROOT / "robotic-ultrasound-imaging_amd" / "lib" / "libusim_prof.so"
+    subprocess.run(["make", "-s", "-C", str(csrc), "prof"], check=True)
+    code = textwrap.dedent(f"""
+        import importlib, sys
+        sys.path.insert(0, {str(ROOT)!r})
+        usim = importlib.import_module("robotic-ultrasound-imaging_amd")
+        for n in (16, 1000, 37):
+            env = usim.UltrasoundVecEnv(n, device="cuda:0", seed=3, lanes_per_env=32, **usim.default_robosuite_kwargs())
+            env.reset_tensor()
+            for k in range(3):
+                t = env.profile_step_raw(k, n=48)
+                print(n, k, t[46], t[47])
+            env.close()
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, USIM_LIB=str(prof)))
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = [tuple(int(v) for v in line.split()) for line in r.stdout.splitlines() if line[:1].isdigit()]
+    assert len(rows) == 9
+    for n, k, arm, lat in rows:
+        assert arm == lat == 5, (n, k, arm, lat)                  # table copy + hand-offs (1)-(4)

@@ -21,3 +21,7 @@ for base, names, title in ((20, names_a, "arm wave"), (30, names_b, "lattice wav
     for i, nm in enumerate(names):
         v = rows[:, base + i] - t0[:, 0]
         print(f"   {nm:36s} {np.median(v):9.0f}")
+print("== contact solve of the lattice wave (ticks since its start)")
+c0 = rows[:, 40:41]
+for i, nm in enumerate(["start", "contact rows done", "Delassus blocks done", "sweeps done", "wrench done"]):
+    print(f"   {nm:36s} {np.median(rows[:, 40 + i] - c0[:, 0]):9.0f}")
