@@ -157,6 +157,12 @@ int usim_rollout_random(usim_handle* h, int64_t first_step, int nsteps, const us
  * step still reads and writes its state and its slice of the rollout block in HBM.  The results do not depend on the value (bit for bit). */
 int usim_set_steps_per_launch(usim_handle* h, int steps);
 
+/* Device time spent so far in the reset-bank refill launches of this handle (one every 64 steps with auto-reset: the initial-pose IK and
+ * zero-torque forward pass of the episodes that will start next), from HIP events around them on their stream.  Blocks
+ * until the refill launches issued so far have finished.  bench.py subtracts it from the event time of its step blocks to get the duration of
+ * the step kernel alone -- the number a rocprofv3 kernel trace reports. */
+int usim_refill_time(usim_handle* h, double* total_ms, long long* launches);
+
 /* Like usim_rollout_random, bracketed by HIP events on `stream`; blocks until done and returns the elapsed
  * device time in milliseconds (bench.py roofline leg). */
 int usim_time_steps(usim_handle* h, int64_t first_step, int nsteps, const usim_step_io* io, int block_advance, void* stream, float* elapsed_ms);

@@ -28,6 +28,13 @@ struct usim_handle {
     float* state = nullptr;
     float* d_tables = nullptr;        // lattice table block of this handle (DevModel::tables)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // device time of the reset-bank refill launches (usim_refill_time): a ring of event pairs, read lazily
+    static constexpr int RF_RING = 8;
+    hipEvent_t rf0[RF_RING] = {}, rf1[RF_RING] = {};
+    bool rf_live[RF_RING] = {};
+    int rf_next = 0;
+    double rf_total_ms = 0.0;
+    long long rf_count = 0;
     // reset bank machinery
     int2* d_items = nullptr;          // refill work list, capacity 2 * n * BANK_DEPTH
     int* d_count = nullptr;           // [0] items, [1] finished workgroups of the running refill
@@ -311,6 +318,7 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
     HIPCHK(h, hipMemset(h->d_count, 0, 2 * sizeof(int)));
     HIPCHK(h, hipEventCreate(&h->ev0));
     HIPCHK(h, hipEventCreate(&h->ev1));
+    for (int i = 0; i < usim_handle::RF_RING; ++i) { HIPCHK(h, hipEventCreate(&h->rf0[i])); HIPCHK(h, hipEventCreate(&h->rf1[i])); }
     // kernel mapping
     // Rigid torso: 16 lanes per environment (arm mathematics distributed over the group) or, with lanes_per_env = 1, one lane each.
     // Soft torso, automatic choice: the split kernel (32 lanes = two waves per quad of environments, usim_step32_kernel) at every batch size
@@ -356,6 +364,7 @@ void usim_destroy(usim_handle* h) {
 
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (int i = 0; i < usim_handle::RF_RING; ++i) { if (h->rf0[i]) (void)hipEventDestroy(h->rf0[i]); if (h->rf1[i]) (void)hipEventDestroy(h->rf1[i]); }
     delete h;
 }
 
@@ -372,15 +381,37 @@ int usim_set_steps_per_launch(usim_handle* h, int steps) {
     return USIM_OK;
 }
 
+static void refill_collect(usim_handle* h, int slot);
+
+int usim_refill_time(usim_handle* h, double* total_ms, long long* launches) {
+    if (!h || !total_ms || !launches) return USIM_ERR_INVALID;
+    DeviceGuard guard(h->device);
+    for (int i = 0; i < usim_handle::RF_RING; ++i) refill_collect(h, i);         // blocks until the recorded refill launches have finished
+    *total_ms = h->rf_total_ms; *launches = h->rf_count;
+    return USIM_OK;
+}
+
 int usim_num_envs(const usim_handle* h) { return h ? h->n : USIM_ERR_INVALID; }
 int usim_action_dim(const usim_handle* h) { return h ? h->adim : USIM_ERR_INVALID; }
 int usim_num_elements(const usim_handle* h) { return h ? h->n_el : USIM_ERR_INVALID; }
 
 // compute every episode on the refill work list into the reset bank (grid-stride over the list, one launch)
+static void refill_collect(usim_handle* h, int slot) {
+    if (!h->rf_live[slot]) return;
+    float ms = 0.f;
+    if (hipEventSynchronize(h->rf1[slot]) == hipSuccess && hipEventElapsedTime(&ms, h->rf0[slot], h->rf1[slot]) == hipSuccess) { h->rf_total_ms += ms; h->rf_count += 1; }
+    h->rf_live[slot] = false;
+}
 static int bank_refill(usim_handle* h, hipStream_t s) {
     DevIO b{}; b.items = h->d_items; b.count = h->d_count; b.refill = 1;
     h->steps_since_refill = 0;
-    return launch<1>(h, b, 0, 0, s);
+    const int slot = h->rf_next;
+    h->rf_next = (slot + 1) % usim_handle::RF_RING;
+    refill_collect(h, slot);                          // (a pair that is reused was recorded RF_RING refills = 512 steps ago: long finished)
+    const bool timed = h->rf0[slot] && h->rf1[slot] && hipEventRecord(h->rf0[slot], s) == hipSuccess;
+    const int rc = launch<1>(h, b, 0, 0, s);
+    if (timed && rc == USIM_OK && hipEventRecord(h->rf1[slot], s) == hipSuccess) h->rf_live[slot] = true;
+    return rc;
 }
 
 // order episodes +1..+BANK_DEPTH for the selected environments and compute them

@@ -147,6 +147,12 @@ class UltrasoundVecEnv:
         self._last_act = a           # keep the tensor alive until the kernel has run
         return self._obs, self._rew, self._done
 
+    def refill_time(self):
+        """(total device milliseconds, number) of the reset-bank refill launches issued so far (include/usim.h usim_refill_time)"""
+        ms, cnt = C.c_double(0.0), C.c_longlong(0)
+        self._check(self.lib.usim_refill_time(self._handle, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
     def set_steps_per_launch(self, steps):
         """rollout_random / time_steps: consecutive steps per kernel launch (1 .. 64, default 64; include/usim.h usim_set_steps_per_launch)"""
         self._check(self.lib.usim_set_steps_per_launch(self._handle, int(steps)))
