@@ -338,9 +338,30 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                     //      after hand-off (2)) ----
                     const f3 Ksx = cross(Ksy, Ksz);
                     int nc = 0;
+                    // single-wave kernels: broad phase and narrow phase in one go -- element positions into the environment's LDS block, the ids
+                    // that pass collide_cull (ascending) into a queue that overlays the a~ area (free until the solve stores its result), then the
+                    // queue G elements at a time.  Same per-element arithmetic and the same ballot slots as walking all rounds.
+                    auto collide_all = [&]() {
+                        float* const q = &EBF(GE_A);
+                        int nq = 0;
+#pragma unroll
+                        for (int i = 0; i < NE; ++i) {
+                            const int eraw = i * G + gl, e = eraw < N_TOP ? eraw : N_TOP - 1;
+                            const float se = live ? s_pre[i] : 0.f;
+                            if (eraw < N_TOP) EBF(GE_S + eraw) = se;
+                            const bool cand = (eraw < N_TOP) && collide_cull(lds, e, M, C, se, dz, Kx, Ksx, Ksz);
+                            const unsigned gm = (unsigned)(__ballot(cand) >> gbase) & ((1u << G) - 1u);
+                            if (cand) q[nq + __popc(gm & ((1u << gl) - 1u))] = __int_as_float(e);
+                            nq += __popc(gm);
+                        }
+                        group_sync();
+                        collide_queue<G>(lds, q, 0, nq, &EBF(GE_CG), gl, gbase, M, C, &EBF(GE_S), dz, Kx, Ksx, Ksy, Ksz, nc);
+                        group_sync();                                      // the queue area is rewritten by the solve's result
+                    };
                     auto collide_round = [&](const int i) {
-                        if constexpr (QM) { if (i == 0) collide_queue<G>(lds, queue, q0, q1, &EBF(GE_CG), gl, gbase, M, C, &EBF(GE_S), dz, Kx, Ksx, Ksy, Ksz, nc); }
-                        else collide_one<G>(lds, &EBF(GE_CG), i, gl, gbase, M, C, live ? s_pre[i] : 0.f, dz, Kx, Ksx, Ksy, Ksz, nc);
+                        if (i != 0) return;
+                        if constexpr (QM) collide_queue<G>(lds, queue, q0, q1, &EBF(GE_CG), gl, gbase, M, C, &EBF(GE_S), dz, Kx, Ksx, Ksy, Ksz, nc);
+                        else collide_all();
                     };
                                     // ---- a~ = Linv * rhs ----
                     if constexpr (MM) {
@@ -393,7 +414,8 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                         group_sync();
                     } else {
                         // VALU form for launches whose environments may be masked: lane gl computes rows gl, gl+G, ...; Linv rows and rhs
-                        // are read as 16-byte chunks
+                        // are read as 16-byte chunks.  (The collision runs first: its queue overlays the a~ area this product fills.)
+                        collide_round(0);
                         const float4* xv = reinterpret_cast<const float4*>(&EBF(GE_X));
                         constexpr int RB = 4;                              // rows per pass share one read of the rhs chunk
     #pragma unroll
@@ -423,8 +445,6 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                             }
                         }
                         LSTAMP(6);
-    #pragma unroll
-                        for (int i = 0; i < NE; ++i) collide_round(i);
                     }
                     if constexpr (!QM) contact_overflow<G>(lds, eb, gl, gbase, nc);
     return nc;
