@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--gather", choices=["rccl", "p2p"], default="rccl", help="N > 1: RCCL all-gather (resident workgroups on the CUs) or peer-to-peer copies "
                     "of the packed block (copy engines, no CUs; distributed.P2PRolloutGather)")
     ap.add_argument("--steps-per-launch", type=int, default=0, help="consecutive steps per kernel launch of the rollout (1 .. 64; default: the library's, 64)")
-    ap.add_argument("--lanes-per-env", type=int, default=0, choices=[0, 1, 8, 16, 32], help="kernel mapping: 16 lanes per environment (automatic), 8 (soft torso) or 1 (rigid torso)")
+    ap.add_argument("--lanes-per-env", type=int, default=0, choices=[0, 1, 8, 16, 32, 64], help="kernel mapping: 16 lanes per environment (automatic), 8 (soft torso) or 1 (rigid torso)")
     args = ap.parse_args()
 
     import torch
@@ -220,9 +220,9 @@ def main():
         except Exception:
             traffic_step = None
 
-    # the mapping usim_create picks (csrc/usim_api.hip): soft torso -> two waves per quad of environments (32 lanes per env)
-    lanes = int(extra.get("lanes_per_env", 0)) or (32 if (args.workload == "soft" and not extra.get("waves_per_simd")) else 16)
-    spl = env.steps_per_launch if lanes in (16, 32) else 1        # consecutive steps per kernel launch (usim_set_steps_per_launch)
+    # the mapping usim_create picks (csrc/usim_api.hip): soft torso -> the split kernel, 16-lane groups (32) up to 4096 envs, 8-lane groups (64) beyond
+    lanes = int(extra.get("lanes_per_env", 0)) or ((32 if n <= 4096 else 64) if (args.workload == "soft" and not extra.get("waves_per_simd")) else 16)
+    spl = env.steps_per_launch if lanes in (16, 32, 64) else 1        # consecutive steps per kernel launch (usim_set_steps_per_launch)
     spl = max(1, min(spl, T, args.steps))
     wl = "randomised" if (args.randomize and args.workload == "soft" and n == 8192) else args.workload
     if rank == 0:
@@ -250,7 +250,7 @@ def main():
                          "algorithmic_bytes_per_launch": ALGO_BYTES[args.workload] * n * spl, "algorithmic_bytes_per_env_step": ALGO_BYTES[args.workload],
                          "steps_per_launch": spl, "avg_launch_us": avg_kernel_s * 1e6 * spl,
                          "refill_launches": refill_n, "refill_us_per_step": refill_ms * 1e3 / args.steps, "block_us_per_step": block_ms * 1e3 / args.steps,
-                         "avg_kernel_us": avg_kernel_s * 1e6, "kernel": {32: "usim_step32_kernel", 16: "usim_step16_kernel"}.get(lanes, "usim_step_kernel") + ("<multi-step>" if spl > 1 else ""),
+                         "avg_kernel_us": avg_kernel_s * 1e6, "kernel": {32: "usim_step32_kernel", 64: "usim_step32_kernel (8-lane groups)", 16: "usim_step16_kernel"}.get(lanes, "usim_step_kernel") + ("<multi-step>" if spl > 1 else ""),
                          "valu_fp32_tflops": valu_tflops, "valu_frac": valu_tflops / FP32_VALU_PEAK_TFLOPS,
                          "note": "kernel is FP32-VALU/latency bound at 4096 envs (one or two waves per SIMD, serial per-environment chain), not HBM bound; see DESIGN.md section 5"},
         }

@@ -70,7 +70,8 @@ typedef struct usim_config {
     int32_t pgs_iters;                         /* full contact sweeps per forward pass (default 4), interleaved with normal-only sweeps: N N F F N F F */
     int32_t ik_iters;                          /* reset inverse-kinematics iterations */
     int32_t env_offset;                        /* global index of env 0 of this handle (multi-GPU shard) */
-    int32_t lanes_per_env;                     /* kernel mapping: 0 automatic; 16 lanes per environment (arm mathematics distributed over the group); 32 (soft torso: the
+    int32_t lanes_per_env;                     /* kernel mapping: 0 automatic; 16 lanes per environment (arm mathematics distributed over the group); 64 (soft torso: the split
+                                                * kernel with 8-lane groups, 32 environments per workgroup; automatic beyond 4096 envs); 32 (soft torso: the
                                                 * same, arm side and lattice / contact side in two waves that share a SIMD; the automatic choice for the soft torso);
                                                 * 8 (soft torso; arm mathematics replicated per lane) or 1 (rigid torso: one environment per lane) */
     int32_t torso_shape;                       /* use_box_torso (rl_config.yaml:57): 0 box (soft_box.xml), 1 cylinder (soft_human_torso.xml) */

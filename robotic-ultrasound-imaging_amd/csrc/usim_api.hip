@@ -41,7 +41,7 @@ struct usim_handle {
     long long steps_since_refill = 0;
     int steps_per_launch = 64;      // usim_rollout_random: consecutive steps per launch of the 16-lane kernels (USIM_STEPS_PER_LAUNCH overrides, 1 .. 64)
     int bank_row0 = 0;
-    size_t lds_bytes = 0, lds16_bytes = 0, lds32_bytes = 0;
+    size_t lds_bytes = 0, lds16_bytes = 0, lds32_bytes = 0, lds64_bytes = 0;
     std::string hip_err;
 };
 
@@ -239,12 +239,18 @@ static int launch(usim_handle* h, DevIO io, int flags, long long rstep, hipStrea
     hipError_t e;
     // 16 lanes per environment: the kernels with the distributed arm mathematics (usim_step16.h); the 8-lane / one-lane mappings run the
     // kernels of usim_kernels.hip
-    if (h->lpe == 32 && MODE == 0) {
-        dim3 grid((h->n + 15) / 16), block(512);
-        if (io.nsub > 1) hipLaunchKernelGGL(usim_step32_kernel<true>, grid, block, h->lds32_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
-        else hipLaunchKernelGGL(usim_step32_kernel<false>, grid, block, h->lds32_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
+    if (h->lpe == 64 && MODE == 0) {
+        // split kernel with 8-lane groups: 32 environments per workgroup
+        dim3 grid((h->n + 31) / 32), block(512);
+        if (io.nsub > 1) hipLaunchKernelGGL((usim_step32_kernel<true, 8>), grid, block, h->lds64_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
+        else hipLaunchKernelGGL((usim_step32_kernel<false, 8>), grid, block, h->lds64_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
         e = hipGetLastError();
-    } else if (h->lpe == 16 || h->lpe == 32) {
+    } else if (h->lpe == 32 && MODE == 0) {
+        dim3 grid((h->n + 15) / 16), block(512);
+        if (io.nsub > 1) hipLaunchKernelGGL((usim_step32_kernel<true, 16>), grid, block, h->lds32_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
+        else hipLaunchKernelGGL((usim_step32_kernel<false, 16>), grid, block, h->lds32_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
+        e = hipGetLastError();
+    } else if (h->lpe == 16 || h->lpe == 32 || h->lpe == 64) {
         // (reset computations are not register-critical: always the two-waves-per-SIMD build)
         if (!h->n_el) e = launch_step16<0, 2, MODE>(h, io, flags, rstep, s);
         else if constexpr (MODE == 0) e = (h->occ == 1) ? launch_step16<1, 1, 0>(h, io, flags, rstep, s) : launch_step16<1, 2, 0>(h, io, flags, rstep, s);
@@ -321,23 +327,25 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
     for (int i = 0; i < usim_handle::RF_RING; ++i) { HIPCHK(h, hipEventCreate(&h->rf0[i])); HIPCHK(h, hipEventCreate(&h->rf1[i])); }
     // kernel mapping
     // Rigid torso: 16 lanes per environment (arm mathematics distributed over the group) or, with lanes_per_env = 1, one lane each.
-    // Soft torso, automatic choice: the split kernel (32 lanes = two waves per quad of environments, usim_step32_kernel) at every batch size
-    // unless a register budget was asked for.  (Round 2 switched to 16 lanes with the two-waves-per-SIMD budget beyond 4096 envs/GPU; with the
-    // capsule collision of round 3 that build spills, and two rounds of split-kernel workgroups are faster: 8192 envs 33.3 vs 40.4 us/step,
-    // 16384 envs 65.0 vs 78.8, profiles/r03/bench_matrix.txt.)
-    h->lpe = h->n_el ? (cfg->lanes_per_env == 0 ? (cfg->waves_per_simd == 0 ? 32 : 16) : cfg->lanes_per_env)
+    // Soft torso, automatic choice (unless a register budget was asked for): the split kernel -- up to 4096 envs/GPU with 16-lane groups (32: two
+    // waves per quad of environments, 16 environments per workgroup = one workgroup per CU), beyond with 8-lane groups (64: two environments per
+    // DPP row, 32 environments per workgroup: 8192 envs still one workgroup per CU, 23.8 vs 29.3 us/step; profiles/r03/bench_matrix.txt).
+    h->lpe = h->n_el ? (cfg->lanes_per_env == 0 ? (cfg->waves_per_simd == 0 ? (n_envs <= 4096 ? 32 : 64) : 16) : cfg->lanes_per_env)
                      : (cfg->lanes_per_env == 0 ? 16 : cfg->lanes_per_env);
-    if (h->n_el ? (h->lpe != 8 && h->lpe != 16 && h->lpe != 32) : (h->lpe != 1 && h->lpe != 16)) return USIM_ERR_INVALID;
-    if (cfg->robot != USIM_ROBOT_PANDA && h->lpe != 16 && h->lpe != 32) {
+    if (h->n_el ? (h->lpe != 8 && h->lpe != 16 && h->lpe != 32 && h->lpe != 64) : (h->lpe != 1 && h->lpe != 16)) return USIM_ERR_INVALID;
+    if (cfg->robot != USIM_ROBOT_PANDA && h->lpe != 16 && h->lpe != 32 && h->lpe != 64) {
         h->hip_err = "the UR5e runs on the table-driven 16-lane kernels only (lanes_per_env 0 or 16)";
         return USIM_ERR_UNSUPPORTED;
     }
     h->occ = cfg->waves_per_simd ? cfg->waves_per_simd : (n_envs <= 4096 ? 1 : 2);
     h->lds16_bytes = h->n_el ? (size_t)GroupGeom<16>::LDS_WORDS * sizeof(float) : (size_t)16 * X16_RIGID_STRIDE * sizeof(float);
-    h->lds32_bytes = (size_t)(X2_BASE + 16 * X2_STRIDE) * sizeof(float);
+    h->lds32_bytes = (size_t)(x2_base<16>() + 16 * x2_stride<16>()) * sizeof(float);
+    h->lds64_bytes = (size_t)(x2_base<8>() + 32 * x2_stride<8>()) * sizeof(float);
     if (h->n_el) {
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds32_bytes));
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds32_bytes));
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step32_kernel<false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds32_bytes));
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step32_kernel<true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds32_bytes));
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step32_kernel<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds64_bytes));
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step32_kernel<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds64_bytes));
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step16_kernel<1, 1, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds16_bytes));
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step16_kernel<1, 1, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds16_bytes));
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step16_kernel<1, 2, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds16_bytes));
@@ -369,7 +377,7 @@ void usim_destroy(usim_handle* h) {
 }
 
 int usim_set_mapping(usim_handle* h, int lanes_per_env, int waves_per_simd) {
-    if (!h || !h->n_el || h->lpe == 8 || (lanes_per_env != 16 && lanes_per_env != 32) || waves_per_simd < 0 || waves_per_simd > 2) return USIM_ERR_INVALID;
+    if (!h || !h->n_el || h->lpe == 8 || (lanes_per_env != 16 && lanes_per_env != 32 && lanes_per_env != 64) || waves_per_simd < 0 || waves_per_simd > 2) return USIM_ERR_INVALID;
     h->lpe = lanes_per_env;
     h->occ = waves_per_simd ? waves_per_simd : (h->n <= 4096 ? 1 : 2);
     return USIM_OK;
@@ -490,7 +498,7 @@ int usim_rollout_random(usim_handle* h, int64_t first_step, int nsteps, const us
     const size_t n = (size_t)h->n;
     // the 16-lane kernels run up to h->steps_per_launch consecutive steps per launch (usim_step16.h step16_body); a launch never crosses the
     // refill period of the reset bank (an environment consumes at most one ring slot per step)
-    const int kmax = (h->lpe == 16 || h->lpe == 32) ? h->steps_per_launch : 1;
+    const int kmax = (h->lpe == 16 || h->lpe == 32 || h->lpe == 64) ? h->steps_per_launch : 1;
     for (int k = 0; k < nsteps;) {
         int kk = nsteps - k < kmax ? nsteps - k : kmax;
         if (kk > BANK_DEPTH - (int)h->steps_since_refill) kk = BANK_DEPTH - (int)h->steps_since_refill;

@@ -627,36 +627,26 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
                              w[0][2] * f[0] + w[1][2] * f[1] + w[2][2] * f[2], w[0][3] * f[0] + w[1][3] * f[1] + w[2][3] * f[2],
                              w[0][4] * f[0] + w[1][4] * f[1] + w[2][4] * f[2], w[0][5] * f[0] + w[1][5] * f[1] + w[2][5] * f[2]};
         const float gfo = (g[0] * f[0] + g[1] * f[1] + g[2] * f[2]) * (1.0f / ELEM_MASS);
-        if constexpr (G == 16) {
-            // sixteen lanes per environment = one DPP row: the sum over the eight contact lanes is a shifted-add reduction (lanes 8-15 carry
-            // zeros as well), the per-contact impulses are row broadcasts
+        {
+            // the sum over the eight contact lanes is a shifted-add reduction over the DPP row (16 lanes per environment: lanes 8-15 carry zeros;
+            // 8 lanes per environment: the shifts are fenced at the group boundary, same tree, same bits), the per-contact impulses are
+            // group broadcasts
+            auto shr_add = [&](float v, auto Dc) {
+                constexpr int D = decltype(Dc)::value;
+                float t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + D, 0xf, 0xf, true));      // row_shr:D
+                if constexpr (G == 8) t = (gl < D) ? 0.f : t;
+                return v + t;
+            };
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
                 float v = (gl < MAXC) ? Fw[a] : 0.f;
-                v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));      // row_shr:1
-                v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));      // row_shr:2
-                v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));      // row_shr:4
+                v = shr_add(v, std::integral_constant<int, 1>{});
+                v = shr_add(v, std::integral_constant<int, 2>{});
+                v = shr_add(v, std::integral_constant<int, 4>{});
                 W[a] += group_bcast<G>(v, 7);
             }
 #pragma unroll
             for (int k = 0; k < MAXC; ++k) if (k < ncmax) gf[k] = group_bcast<G>(gfo, k);
-        } else {
-            if (gl < MAXC) {
-                const int b = GE_WS + gl * 8;
-#pragma unroll
-                for (int a = 0; a < 6; ++a) EB(b + a) = Fw[a];
-                EB(b + 6) = gfo;
-            }
-            group_sync();
-#pragma unroll
-            for (int k = 0; k < MAXC; ++k) {
-                if (k < ncmax) {
-                    const int b = GE_WS + k * 8;
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) W[a] += EB(b + a);
-                    gf[k] = EB(b + 6);
-                }
-            }
         }
     }
     USIM_CSTAMP(dbg, 4);

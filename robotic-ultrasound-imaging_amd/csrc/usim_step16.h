@@ -30,30 +30,51 @@ DI void static_for(F&& f) {
     if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
 }
 
-// ---- DPP row primitives (a row = 16 lanes = the group of one environment) ----
+// ---- DPP row primitives.  A DPP row is 16 lanes.  G = 16: the row is the group of one environment.  G = 8 (split kernel beyond 4096 envs/GPU):
+// a row holds the groups of TWO environments, lanes 0-7 and 8-15 -- the arm mathematics only ever used lanes 0-7 of a group (seven links + the
+// site frame; task rows in lanes 0-2 / 4-6), so the second environment takes the lanes that idled.  A broadcast then needs one instruction per
+// half (bank_mask 0x3 / 0xc select lanes 0-7 / 8-15 of every row), a shift one select that keeps lane 8 .. from reading across the fence. ----
 template <int CTRL>
 DI float dpp0(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
-template <int K> DI float rbc(float v) { return dpp0<0x150 + K>(v); }                 // value of lane K of the row, in every lane
-template <int D> DI float rshr0(float v) { return dpp0<0x110 + D>(v); }               // value of lane l - D (0 for l < D)
-template <int D> DI float rshl0(float v) { return dpp0<0x100 + D>(v); }               // value of lane l + D (0 beyond the row)
-template <int D> DI float rshr(float v, float fill) {                                  // value of lane l - D (`fill` for l < D)
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x110 + D, 0xf, 0xf, false));
+template <int G> DI int glane() { return (int)(threadIdx.x & (G - 1)); }
+template <int G, int K> DI float rbc(float v) {                                        // value of lane K of the group, in every lane of the group
+    if constexpr (G == 16) return dpp0<0x150 + K>(v);
+    else {
+        const int iv = __float_as_int(v);
+        const int t = __builtin_amdgcn_update_dpp(iv, iv, 0x150 + K, 0xf, 0x3, false);
+        return __int_as_float(__builtin_amdgcn_update_dpp(t, iv, 0x150 + 8 + K, 0xf, 0xc, false));
+    }
+}
+template <int G, int D> DI float rshr0(float v) {                                      // value of lane l - D of the group (0 for l < D)
+    const float t = dpp0<0x110 + D>(v);
+    if constexpr (G == 16) return t; else return (glane<G>() < D) ? 0.f : t;
+}
+template <int G, int D> DI float rshl0(float v) {                                      // value of lane l + D of the group (0 beyond it)
+    const float t = dpp0<0x100 + D>(v);
+    if constexpr (G == 16) return t; else return (glane<G>() >= G - D) ? 0.f : t;
+}
+template <int G, int D> DI float rshr(float v, float fill) {                           // value of lane l - D of the group (`fill` for l < D)
+    const float t = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x110 + D, 0xf, 0xf, false));
+    if constexpr (G == 16) return t; else return (glane<G>() < D) ? fill : t;
 }
 template <int K> DI float qbc(float v) { return dpp0<K * 0x55>(v); }                  // value of lane K of the quad
-template <int K> DI f3 rbc3(f3 v) { return mk(rbc<K>(v.x), rbc<K>(v.y), rbc<K>(v.z)); }
-DI float prefix_sum(float v) { v += rshr0<1>(v); v += rshr0<2>(v); v += rshr0<4>(v); return v; }     // inclusive, over lanes l-7 .. l
-DI float suffix_sum(float v) { v += rshl0<1>(v); v += rshl0<2>(v); v += rshl0<4>(v); return v; }     // inclusive, over lanes l .. l+7
-DI f3 prefix_sum(f3 v) { return mk(prefix_sum(v.x), prefix_sum(v.y), prefix_sum(v.z)); }
-DI f3 suffix_sum(f3 v) { return mk(suffix_sum(v.x), suffix_sum(v.y), suffix_sum(v.z)); }
+template <int G, int K> DI f3 rbc3(f3 v) { return mk(rbc<G, K>(v.x), rbc<G, K>(v.y), rbc<G, K>(v.z)); }
+template <int G> DI float prefix_sum(float v) { v += rshr0<G, 1>(v); v += rshr0<G, 2>(v); v += rshr0<G, 4>(v); return v; }     // inclusive, over lanes l-7 .. l of the group
+template <int G> DI float suffix_sum(float v) { v += rshl0<G, 1>(v); v += rshl0<G, 2>(v); v += rshl0<G, 4>(v); return v; }     // inclusive, over lanes l .. l+7
+template <int G> DI f3 prefix_sum(f3 v) { return mk(prefix_sum<G>(v.x), prefix_sum<G>(v.y), prefix_sum<G>(v.z)); }
+template <int G> DI f3 suffix_sum(f3 v) { return mk(suffix_sum<G>(v.x), suffix_sum<G>(v.y), suffix_sum<G>(v.z)); }
 DI f3 symmul6(const float* I, f3 v) { return symmul(I, v); }
 
 constexpr int TASK_LANE[6] = {0, 1, 2, 4, 5, 6};      // lane that owns task-space row a: position rows in quad 0, orientation rows in quad 1
 
 // ---- fused DPP arithmetic.  The compiler folds a row shift into v_add_f32_dpp by itself but keeps a broadcast feeding a multiply-add as
 // v_mov_b32_dpp + v_fmac_f32 (the accumulator of v_fmac is tied to the destination, which its DPP combiner does not model), so the
-// "own row times broadcast vector" products are written out: one v_fmac_f32_dpp per term.  A DPP source written by the VALU instruction
-// right before needs two wait states, and the hazard recogniser does not look inside inline assembly: every block opens with s_nop 1. ----
+// "own row times broadcast vector" products are written out: one v_fmac_f32_dpp per term (G = 8: one per term and half of the row).  A DPP
+// source written by the VALU instruction right before needs two wait states, and the hazard recogniser does not look inside inline assembly:
+// every block opens with s_nop 1. ----
 #define USIM_DPP_BC(K) " row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
+#define USIM_DPP_LO(K) " row_newbcast:" #K " row_mask:0xf bank_mask:0x3\n\t"
+// (the second environment of a row reads lane K + 8: the operand is spelled out per call site)
 // sum_j A[j] * (value of v in lane j), j = 0 .. 6: own row times a vector that lives one component per joint lane
 DI float row_times_joint7(const float* A, float v) {
     float s;
@@ -64,44 +85,96 @@ DI float row_times_joint7(const float* A, float v) {
         : "=&v"(s) : "v"(v), "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(A[5]), "v"(A[6]));
     return s;
 }
-template <int NJ_>
-DI float row_times_joint(const float* A, float v) {
-    static_assert(NJ_ == 7, "seven joint lanes");
-    return row_times_joint7(A, v);
-}
-// sum_a A[a] * (value of t in task lane a), task lanes 0 1 2 4 5 6
-DI float col_times_task(const float* A, float t) {
+// the same for the two 8-lane groups of a row: lanes 0-7 read lanes 0-6, lanes 8-15 read lanes 8-14
+DI float row_times_joint7_g8(const float* A, float v) {
     float s;
     asm("s_nop 1\n\t"
-        "v_mul_f32_dpp %0, %1, %2" USIM_DPP_BC(0) "v_fmac_f32_dpp %0, %1, %3" USIM_DPP_BC(1) "v_fmac_f32_dpp %0, %1, %4" USIM_DPP_BC(2)
-        "v_fmac_f32_dpp %0, %1, %5" USIM_DPP_BC(4) "v_fmac_f32_dpp %0, %1, %6" USIM_DPP_BC(5) "v_fmac_f32_dpp %0, %1, %7" USIM_DPP_BC(6)
-        : "=&v"(s) : "v"(t), "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(A[5]));
+        "v_mul_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0x3\n\t"  "v_mul_f32_dpp %0, %1, %2 row_newbcast:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0x3\n\t" "v_fmac_f32_dpp %0, %1, %3 row_newbcast:9 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0x3\n\t" "v_fmac_f32_dpp %0, %1, %4 row_newbcast:10 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0x3\n\t" "v_fmac_f32_dpp %0, %1, %5 row_newbcast:11 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0x3\n\t" "v_fmac_f32_dpp %0, %1, %6 row_newbcast:12 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0x3\n\t" "v_fmac_f32_dpp %0, %1, %7 row_newbcast:13 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f32_dpp %0, %1, %8 row_newbcast:6 row_mask:0xf bank_mask:0x3\n\t" "v_fmac_f32_dpp %0, %1, %8 row_newbcast:14 row_mask:0xf bank_mask:0xc"
+        : "=&v"(s) : "v"(v), "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(A[5]), "v"(A[6]));
+    return s;
+}
+template <int G, int NJ_>
+DI float row_times_joint(const float* A, float v) {
+    static_assert(NJ_ == 7, "seven joint lanes");
+    if constexpr (G == 16) return row_times_joint7(A, v); else return row_times_joint7_g8(A, v);
+}
+// sum_a A[a] * (value of t in task lane a), task lanes 0 1 2 4 5 6
+template <int G>
+DI float col_times_task(const float* A, float t) {
+    float s;
+    if constexpr (G == 16) {
+        asm("s_nop 1\n\t"
+            "v_mul_f32_dpp %0, %1, %2" USIM_DPP_BC(0) "v_fmac_f32_dpp %0, %1, %3" USIM_DPP_BC(1) "v_fmac_f32_dpp %0, %1, %4" USIM_DPP_BC(2)
+            "v_fmac_f32_dpp %0, %1, %5" USIM_DPP_BC(4) "v_fmac_f32_dpp %0, %1, %6" USIM_DPP_BC(5) "v_fmac_f32_dpp %0, %1, %7" USIM_DPP_BC(6)
+            : "=&v"(s) : "v"(t), "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(A[5]));
+    } else {
+        asm("s_nop 1\n\t"
+            "v_mul_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0x3\n\t"  "v_mul_f32_dpp %0, %1, %2 row_newbcast:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_fmac_f32_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0x3\n\t" "v_fmac_f32_dpp %0, %1, %3 row_newbcast:9 row_mask:0xf bank_mask:0xc\n\t"
+            "v_fmac_f32_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0x3\n\t" "v_fmac_f32_dpp %0, %1, %4 row_newbcast:10 row_mask:0xf bank_mask:0xc\n\t"
+            "v_fmac_f32_dpp %0, %1, %5 row_newbcast:4 row_mask:0xf bank_mask:0x3\n\t" "v_fmac_f32_dpp %0, %1, %5 row_newbcast:12 row_mask:0xf bank_mask:0xc\n\t"
+            "v_fmac_f32_dpp %0, %1, %6 row_newbcast:5 row_mask:0xf bank_mask:0x3\n\t" "v_fmac_f32_dpp %0, %1, %6 row_newbcast:13 row_mask:0xf bank_mask:0xc\n\t"
+            "v_fmac_f32_dpp %0, %1, %7 row_newbcast:6 row_mask:0xf bank_mask:0x3\n\t" "v_fmac_f32_dpp %0, %1, %7 row_newbcast:14 row_mask:0xf bank_mask:0xc"
+            : "=&v"(s) : "v"(t), "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(A[5]));
+    }
     return s;
 }
 // A[c] += (value of A[c] in lane K) * f  for the seven entries of a row (Gauss-Jordan row update: the pivot row is lane K's)
-template <int K>
+template <int G, int K>
 DI void row_axpy_bc7(float* A, float f) {
-    asm("s_nop 1\n\t"
-        "v_fmac_f32_dpp %0, %0, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %1, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %2, %2, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %3, %3, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %4, %4, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %5, %5, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %6, %6, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf"
-        : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]) : "v"(f), "n"(K));
+    if constexpr (G == 16) {
+        asm("s_nop 1\n\t"
+            "v_fmac_f32_dpp %0, %0, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %1, %1, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %2, %2, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %3, %3, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %4, %4, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %5, %5, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %6, %6, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf"
+            : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]) : "v"(f), "n"(K));
+    } else {
+        // the pivot row's own entries must be read before they are overwritten: lanes 0-7 and 8-15 are updated by separate instructions, and the
+        // pivot lanes K / K + 8 update themselves with f = (1 - pivot) / pivot - ... exactly as in the 16-lane form (same arithmetic per lane)
+        asm("s_nop 1\n\t"
+            "v_fmac_f32_dpp %0, %0, %7 row_newbcast:%8 row_mask:0xf bank_mask:0x3\n\t" "v_fmac_f32_dpp %0, %0, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xc\n\t"
+            "v_fmac_f32_dpp %1, %1, %7 row_newbcast:%8 row_mask:0xf bank_mask:0x3\n\t" "v_fmac_f32_dpp %1, %1, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xc\n\t"
+            "v_fmac_f32_dpp %2, %2, %7 row_newbcast:%8 row_mask:0xf bank_mask:0x3\n\t" "v_fmac_f32_dpp %2, %2, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xc\n\t"
+            "v_fmac_f32_dpp %3, %3, %7 row_newbcast:%8 row_mask:0xf bank_mask:0x3\n\t" "v_fmac_f32_dpp %3, %3, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xc\n\t"
+            "v_fmac_f32_dpp %4, %4, %7 row_newbcast:%8 row_mask:0xf bank_mask:0x3\n\t" "v_fmac_f32_dpp %4, %4, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xc\n\t"
+            "v_fmac_f32_dpp %5, %5, %7 row_newbcast:%8 row_mask:0xf bank_mask:0x3\n\t" "v_fmac_f32_dpp %5, %5, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xc\n\t"
+            "v_fmac_f32_dpp %6, %6, %7 row_newbcast:%8 row_mask:0xf bank_mask:0x3\n\t" "v_fmac_f32_dpp %6, %6, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xc"
+            : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]) : "v"(f), "n"(K), "n"(K + 8));
+    }
 }
 // z . n + vo . f with (z, vo) taken from lane K: entry K of this lane's row of the mass matrix
-template <int K>
+template <int G, int K>
 DI float spatial_dot_bc(f3 z, f3 vo, f3 n, f3 f) {
     float s;
-    asm("s_nop 1\n\t"
-        "v_mul_f32_dpp %0, %1, %7 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %8 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %0, %3, %9 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %4, %10 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %0, %5, %11 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %6, %12 row_newbcast:%13 row_mask:0xf bank_mask:0xf"
-        : "=&v"(s) : "v"(z.x), "v"(z.y), "v"(z.z), "v"(vo.x), "v"(vo.y), "v"(vo.z), "v"(n.x), "v"(n.y), "v"(n.z), "v"(f.x), "v"(f.y), "v"(f.z), "n"(K));
+    if constexpr (G == 16) {
+        asm("s_nop 1\n\t"
+            "v_mul_f32_dpp %0, %1, %7 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %2, %8 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %3, %9 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %4, %10 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %5, %11 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f32_dpp %0, %6, %12 row_newbcast:%13 row_mask:0xf bank_mask:0xf"
+            : "=&v"(s) : "v"(z.x), "v"(z.y), "v"(z.z), "v"(vo.x), "v"(vo.y), "v"(vo.z), "v"(n.x), "v"(n.y), "v"(n.z), "v"(f.x), "v"(f.y), "v"(f.z), "n"(K));
+    } else {
+        asm("s_nop 1\n\t"
+            "v_mul_f32_dpp %0, %1, %7 row_newbcast:%13 row_mask:0xf bank_mask:0x3\n\t"   "v_mul_f32_dpp %0, %1, %7 row_newbcast:%14 row_mask:0xf bank_mask:0xc\n\t"
+            "v_fmac_f32_dpp %0, %2, %8 row_newbcast:%13 row_mask:0xf bank_mask:0x3\n\t"  "v_fmac_f32_dpp %0, %2, %8 row_newbcast:%14 row_mask:0xf bank_mask:0xc\n\t"
+            "v_fmac_f32_dpp %0, %3, %9 row_newbcast:%13 row_mask:0xf bank_mask:0x3\n\t"  "v_fmac_f32_dpp %0, %3, %9 row_newbcast:%14 row_mask:0xf bank_mask:0xc\n\t"
+            "v_fmac_f32_dpp %0, %4, %10 row_newbcast:%13 row_mask:0xf bank_mask:0x3\n\t" "v_fmac_f32_dpp %0, %4, %10 row_newbcast:%14 row_mask:0xf bank_mask:0xc\n\t"
+            "v_fmac_f32_dpp %0, %5, %11 row_newbcast:%13 row_mask:0xf bank_mask:0x3\n\t" "v_fmac_f32_dpp %0, %5, %11 row_newbcast:%14 row_mask:0xf bank_mask:0xc\n\t"
+            "v_fmac_f32_dpp %0, %6, %12 row_newbcast:%13 row_mask:0xf bank_mask:0x3\n\t" "v_fmac_f32_dpp %0, %6, %12 row_newbcast:%14 row_mask:0xf bank_mask:0xc"
+            : "=&v"(s) : "v"(z.x), "v"(z.y), "v"(z.z), "v"(vo.x), "v"(vo.y), "v"(vo.z), "v"(n.x), "v"(n.y), "v"(n.z), "v"(f.x), "v"(f.y), "v"(f.z), "n"(K), "n"(K + 8));
+    }
     return s;
 }
 
 // world frame of every link: local transform of this lane's link (fixed rotation, joint about the local z axis), then the scan
 // T_l <- T_(l-d) o T_l for d = 1, 2, 4.  X, Y, Z: rotation columns, P: origin.  Lanes without a joint carry q = 0 (sin 0 = 0, cos 0 = 1 exactly).
+template <int G>
 DI void fk16(const float* at, const float q, f3& X, f3& Y, f3& Z, f3& P) {
     float s, c;
     sincos_(q, s, c);
@@ -111,10 +184,10 @@ DI void fk16(const float* at, const float q, f3& X, f3& Y, f3& Z, f3& P) {
     static_for<3>([&](auto Dc) {
         constexpr int D = 1 << decltype(Dc)::value;
         // lanes l < D read the identity (fill values of the shift): their frame is already complete
-        const f3 LX = mk(rshr<D>(X.x, 1.f), rshr<D>(X.y, 0.f), rshr<D>(X.z, 0.f));
-        const f3 LY = mk(rshr<D>(Y.x, 0.f), rshr<D>(Y.y, 1.f), rshr<D>(Y.z, 0.f));
-        const f3 LZ = mk(rshr<D>(Z.x, 0.f), rshr<D>(Z.y, 0.f), rshr<D>(Z.z, 1.f));
-        const f3 LP = mk(rshr0<D>(P.x), rshr0<D>(P.y), rshr0<D>(P.z));
+        const f3 LX = mk(rshr<G, D>(X.x, 1.f), rshr<G, D>(X.y, 0.f), rshr<G, D>(X.z, 0.f));
+        const f3 LY = mk(rshr<G, D>(Y.x, 0.f), rshr<G, D>(Y.y, 1.f), rshr<G, D>(Y.z, 0.f));
+        const f3 LZ = mk(rshr<G, D>(Z.x, 0.f), rshr<G, D>(Z.y, 0.f), rshr<G, D>(Z.z, 1.f));
+        const f3 LP = mk(rshr0<G, D>(P.x), rshr0<G, D>(P.y), rshr0<G, D>(P.z));
         const f3 nX = LX * X.x + LY * X.y + LZ * X.z, nY = LX * Y.x + LY * Y.y + LZ * Y.z, nZ = LX * Z.x + LY * Z.y + LZ * Z.z;
         P = LP + LX * P.x + LY * P.y + LZ * P.z;
         X = nX; Y = nY; Z = nZ;
@@ -136,14 +209,15 @@ DI void jacobian_rows(float* xl, const int gl, const float* Jc, float* Jr) {
 
 // solution of the 6 x 6 system whose row a (A[0..5] | b) lives in task lane a: Gauss-Jordan across the six task lanes, no pivoting (the
 // matrices are symmetric positive definite).  Lanes without a task row must pass zero rows: they are never pivots.
+template <int G>
 DI float solve6_task(float* A, float b, const int gl) {
     static_for<6>([&](auto Kc) {
         constexpr int k = decltype(Kc)::value;
         constexpr int lk = TASK_LANE[k];
-        const float g = (A[k] - (gl == lk ? 1.f : 0.f)) * rcp_(rbc<lk>(A[k]));
+        const float g = (A[k] - (gl == lk ? 1.f : 0.f)) * rcp_(rbc<G, lk>(A[k]));
 #pragma unroll
-        for (int c = k + 1; c < 6; ++c) A[c] = fmaf(-g, rbc<lk>(A[c]), A[c]);
-        b = fmaf(-g, rbc<lk>(b), b);
+        for (int c = k + 1; c < 6; ++c) A[c] = fmaf(-g, rbc<G, lk>(A[c]), A[c]);
+        b = fmaf(-g, rbc<G, lk>(b), b);
     });
     return b;
 }
@@ -163,10 +237,15 @@ constexpr int X16_RIGID_STRIDE = 68;                  // rigid-torso launches: o
 // (kinematics ... controller, then acceleration, sensors, reward, bookkeeping), ROLE 2 the lattice / contact side (staging, right-hand side,
 // matrix-core solve, collision, contact solve, element integration).  They meet at workgroup barriers and hand over through per-environment
 // LDS mailboxes: site pose (1 -> 2), Lambda^-1 / alpha / vs (1 -> 2), contact wrench and contact list (2 -> 1).  ROLE 0 = one wave does both.
-constexpr int X2_BASE = TB_WORDS + 16 * GE_STRIDE;        // behind the sixteen per-environment blocks: arm scratch + mailboxes of the split kernel
+// behind the per-environment blocks (16 with 16-lane groups, 32 with 8-lane groups): arm scratch + mailboxes of the split kernel
+template <int G> constexpr int x2_base() { return TB_WORDS + (256 / G) * GE_STRIDE; }
 // 64 transpose scratch | 12 pose (+ the arm side's hit count in word 9) | 64 op-space (6 x 8 Lambda^-1, alpha 6, vs 6) | 16 wrench + contacts | the arm side's contact records
-constexpr int MB_POSE = 64, MB_OP = 76, MB_W = 140, MB_CA = 156, MB_Q = MB_CA + (MAXCAND + 1) * CG_WORDS, X2_STRIDE = MB_Q + 100;   // ... | broad-phase queue (element ids)
-static_assert(MB_W + 16 <= MB_CA && (MB_CA % 4) == 0 && (X2_STRIDE % 4) == 0, "mailbox block");
+constexpr int MB_POSE = 64, MB_OP = 76, MB_W = 140, MB_CA = 156;
+// (8-lane groups: no record area for an arm-side share of the narrow phase -- 32 environments per workgroup have to fit the CU's 160 KB of LDS)
+template <int G> constexpr int mb_q() { return G == 16 ? MB_CA + (MAXCAND + 1) * CG_WORDS : MB_CA; }                // ... | broad-phase queue (element ids)
+template <int G> constexpr int x2_stride() { return mb_q<G>() + 100; }
+static_assert(MB_W + 16 <= MB_CA && (MB_CA % 4) == 0 && (x2_stride<16>() % 4) == 0 && (x2_stride<8>() % 4) == 0, "mailbox block");
+static_assert((x2_base<8>() + 32 * x2_stride<8>()) * 4 <= 160 * 1024, "split kernel with 8-lane groups: LDS of a CU");
 // Collision in the split kernel: the ARM side, which has the site pose first, runs the broad phase over all 99 elements (collide_cull) while the
 // lattice side still stages its right-hand side, and leaves the survivors' ids (ascending) in the queue; after hand-off (1) the arm side takes
 // the first ARM_SHARE_NUM / ARM_SHARE_DEN of the queue, the lattice side the rest, each typically in one pass of its 16 lanes per environment.
@@ -182,14 +261,17 @@ constexpr int ARM_SHARE_NUM = 0, ARM_SHARE_DEN = 1;     // measured (us/step, on
 #define USIM_BAR() __syncthreads()
 #endif
 
-template <int TORSO, int MODE, int ROLE, int NT>
+template <int TORSO, int MODE, int ROLE, int NT, int G = 16>
 DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __restrict__ st, const int n, const int npad, const DevIO& io, const int flags, const long long rstep,
                    const bool first_pass, int& nbar) {
-    constexpr int G = 16, EPW = 4, EPB = 16;
+    constexpr int EPW = 64 / G, EPB = 4 * EPW;                          // environments per wave / per workgroup (four waves per role)
+    constexpr int X2_BASE = x2_base<G>(), X2_STRIDE = x2_stride<G>(), MB_Q = mb_q<G>();
+    constexpr unsigned GMASK = (G == 16) ? 0xffffu : 0xffu;
+    static_assert(G == 16 || (TORSO == 1 && MODE == 0 && ROLE != 0), "8-lane groups: the split soft-torso step only");
     constexpr int NE = TORSO ? (N_TOP + G - 1) / G : 1;
     static_assert(ROLE == 0 || (TORSO == 1 && MODE == 0), "the split kernel is the soft-torso step");
     const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;      // wave within its role = quad of environments
-    const int gl = lane & 15, ge = lane >> 4;
+    const int gl = lane & (G - 1), ge = lane / G;
     const int gbase = lane - gl;
     const int eb = wave * EPW + ge;
     const bool auto_reset = (flags & LF_AUTO_RESET) != 0;
@@ -299,21 +381,21 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
             for (int i = ARM_CULL_ROUNDS; i < NE; ++i) {
                 const int eraw = i * G + gl, e = eraw < N_TOP ? eraw : N_TOP - 1;
                 const bool cand = (eraw < N_TOP) && collide_cull(lds, e, M, C, s_pre[i], dz, xs, sxc, sz);
-                const unsigned gm = (unsigned)(__ballot(cand) >> gbase) & 0xffffu;
+                const unsigned gm = (unsigned)(__ballot(cand) >> gbase) & GMASK;
                 if (cand) mb[MB_Q + nq + __popc(gm & ((1u << gl) - 1u))] = __int_as_float(e);
                 nq += __popc(gm);
             }
             group_sync();
         }
-        const int na = (__float_as_int(mb[MB_POSE + 10]) * ARM_SHARE_NUM + ARM_SHARE_DEN - 1) / ARM_SHARE_DEN;
+        const int na = (G == 16) ? (__float_as_int(mb[MB_POSE + 10]) * ARM_SHARE_NUM + ARM_SHARE_DEN - 1) / ARM_SHARE_DEN : 0;
         const int ncl = lattice_front<G, NE, true, 2, true>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, true, s_pre, sd_pre, xs, sy, sz, dbg, mb + MB_Q, na, nq);
         RSTAMP(3);
         USIM_BAR();                                                 // (2) ... and Lambda^-1, alpha = J qs, vs = J qd, and the arm side's contact records
         RSTAMP(4);
         // one list in ascending shell id: the arm side's records (first part of the queue) first, this side's behind them
-        const int nca = __float_as_int(mb[MB_POSE + 9]);
+        const int nca = (G == 16) ? __float_as_int(mb[MB_POSE + 9]) : 0;
         int nc = nca + ncl;
-        if (__any(nca > 0)) {
+        if (G == 16 && __any(nca > 0)) {
             const int na = nca < MAXCAND ? nca : MAXCAND, li = gl - na;
             const float4* src = reinterpret_cast<const float4*>(gl < na ? &mb[MB_CA + gl * CG_WORDS] : &EB(GE_CG + (li > 0 ? li : 0) * CG_WORDS));
             const float4 r0 = src[0], r1 = src[1];
@@ -396,9 +478,9 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         const u4 r = philox(gid, (uint32_t)ep_t, (uint32_t)(gl < 3 ? gl : 2), 0u, C.key0, C.key1);
         const float ra = __uint_as_float(r.a), rb = __uint_as_float(r.b), rc = __uint_as_float(r.c), rd = __uint_as_float(r.d);
         u4 A, B, Cc;
-        A.a = __float_as_uint(rbc<0>(ra)); A.b = __float_as_uint(rbc<0>(rb)); A.c = __float_as_uint(rbc<0>(rc)); A.d = __float_as_uint(rbc<0>(rd));
-        B.a = __float_as_uint(rbc<1>(ra)); B.b = __float_as_uint(rbc<1>(rb)); B.c = __float_as_uint(rbc<1>(rc)); B.d = __float_as_uint(rbc<1>(rd));
-        Cc.a = __float_as_uint(rbc<2>(ra)); Cc.b = __float_as_uint(rbc<2>(rb)); Cc.c = __float_as_uint(rbc<2>(rc)); Cc.d = __float_as_uint(rbc<2>(rd));
+        A.a = __float_as_uint(rbc<G, 0>(ra)); A.b = __float_as_uint(rbc<G, 0>(rb)); A.c = __float_as_uint(rbc<G, 0>(rc)); A.d = __float_as_uint(rbc<G, 0>(rd));
+        B.a = __float_as_uint(rbc<G, 1>(ra)); B.b = __float_as_uint(rbc<G, 1>(rb)); B.c = __float_as_uint(rbc<G, 1>(rc)); B.d = __float_as_uint(rbc<G, 1>(rd));
+        Cc.a = __float_as_uint(rbc<G, 2>(ra)); Cc.b = __float_as_uint(rbc<G, 2>(rb)); Cc.c = __float_as_uint(rbc<G, 2>(rc)); Cc.d = __float_as_uint(rbc<G, 2>(rd));
         const float tz = M.torso[2] + M.base[2] + C.top_off;             // ultrasound.py:184,807
         f3 noise = mk(0, 0, 0);
         kst = C.stiffness; kdmp = C.damping;
@@ -435,8 +517,8 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         qj = jlane ? at[AT_INITQ] : 0.f;
         for (int it = 0; it < C.ik_iters; ++it) {
             f3 X, Y, Z, P;
-            fk16(at, qj, X, Y, Z, P);
-            const f3 sx = rbc3<7>(X), sy = rbc3<7>(Y), sz = rbc3<7>(Z), xs = rbc3<7>(P);
+            fk16<G>(at, qj, X, Y, Z, P);
+            const f3 sx = rbc3<G, 7>(X), sy = rbc3<G, 7>(Y), sz = rbc3<G, 7>(Z), xs = rbc3<G, 7>(P);
             const f3 eo = (cross(sx, gx) + cross(sy, gy) + cross(sz, gz)) * 0.5f;
             const f3 ep = target - xs;
             const float e = is_task ? (blk ? pick(eo) : pick(ep)) : 0.f;
@@ -449,11 +531,11 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
             static_for<6>([&](auto Bc) {
                 constexpr int b = decltype(Bc)::value;
                 float sacc = 0.f;
-                static_for<NJ>([&](auto Jn) { constexpr int j = decltype(Jn)::value; sacc = fmaf(Jr[j], rbc<TASK_LANE[b]>(Jr[j]), sacc); });
+                static_for<NJ>([&](auto Jn) { constexpr int j = decltype(Jn)::value; sacc = fmaf(Jr[j], rbc<G, TASK_LANE[b]>(Jr[j]), sacc); });
                 A6[b] = is_task ? sacc + ((gl == TASK_LANE[b]) ? 1e-6f : 0.f) : 0.f;
             });
-            const float y = solve6_task(A6, e, gl);
-            const float dq = col_times_task(Jc, y);
+            const float y = solve6_task<G>(A6, e, gl);
+            const float dq = col_times_task<G>(Jc, y);
             qj = jlane ? qj + dq : 0.f;
             group_sync();                                                // the scratch is rewritten by the next iteration / the forward pass
         }
@@ -465,12 +547,12 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
     // kinematics: local transform of this lane's link, then the scan  T_l <- T_(l-d) o T_l  for d = 1, 2, 4
     // =================================================================================================================
     f3 X, Y, Z, P;                                                       // world rotation columns and origin of this lane's frame
-    fk16(at, qj, X, Y, Z, P);
+    fk16<G>(at, qj, X, Y, Z, P);
     const f3 rcm = X * at[AT_LCOM] + Y * at[AT_LCOM + 1] + Z * at[AT_LCOM + 2];      // link COM relative to the link origin
     const f3 cm_ = P + rcm;
     // site frame = lane 7's; hand origin = a fixed point of the last link
-    const f3 sx = rbc3<7>(X), sy = rbc3<7>(Y), sz = rbc3<7>(Z), xs = rbc3<7>(P);
-    const f3 hand = rbc3<NJ - 1>(P + X * M.hand7[0] + Y * M.hand7[1] + Z * M.hand7[2]);
+    const f3 sx = rbc3<G, 7>(X), sy = rbc3<G, 7>(Y), sz = rbc3<G, 7>(Z), xs = rbc3<G, 7>(P);
+    const f3 hand = rbc3<G, NJ - 1>(P + X * M.hand7[0] + Y * M.hand7[1] + Z * M.hand7[2]);
     if constexpr (ROLE == 1) {
         {
             // broad phase of the collision (collide_cull): element ids that can touch the probe, ascending, into the queue; element positions
@@ -485,7 +567,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
                 if (eraw < N_TOP) EB(GE_S + eraw) = s_pre[i];
                 if (i >= ARM_CULL_ROUNDS) continue;
                 const bool cand = (eraw < N_TOP) && collide_cull(lds, e, M, C, s_pre[i], dz_, xs, sxc, sz);
-                const unsigned gm = (unsigned)(__ballot(cand) >> gbase) & 0xffffu;
+                const unsigned gm = (unsigned)(__ballot(cand) >> gbase) & GMASK;
                 if (cand) xl[MB_Q + nq + __popc(gm & ((1u << gl) - 1u))] = __int_as_float(e);
                 nq += __popc(gm);
             }
@@ -510,8 +592,8 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         const u4 r = philox(gid, (uint32_t)rstep, (uint32_t)((unsigned long long)rstep >> 32), 1u + (uint32_t)(gl & 1), C.key0, C.key1);
         const float ra = __uint_as_float(r.a), rb = __uint_as_float(r.b), rc = __uint_as_float(r.c), rd = __uint_as_float(r.d);
         uint32_t rr[7];
-        rr[0] = __float_as_uint(rbc<0>(ra)); rr[1] = __float_as_uint(rbc<0>(rb)); rr[2] = __float_as_uint(rbc<0>(rc)); rr[3] = __float_as_uint(rbc<0>(rd));
-        rr[4] = __float_as_uint(rbc<1>(ra)); rr[5] = __float_as_uint(rbc<1>(rb)); rr[6] = __float_as_uint(rbc<1>(rc));
+        rr[0] = __float_as_uint(rbc<G, 0>(ra)); rr[1] = __float_as_uint(rbc<G, 0>(rb)); rr[2] = __float_as_uint(rbc<G, 0>(rc)); rr[3] = __float_as_uint(rbc<G, 0>(rd));
+        rr[4] = __float_as_uint(rbc<G, 1>(ra)); rr[5] = __float_as_uint(rbc<G, 1>(rb)); rr[6] = __float_as_uint(rbc<G, 1>(rc));
 #pragma unroll
         for (int a = 0; a < 7; ++a) {
             const float u = u01(rr[a]);
@@ -536,15 +618,15 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
     f3 w, al, ao;                                                        // link angular velocity, bias angular acceleration, bias acceleration of the origin
     {
         const f3 zq = Z * qdj;
-        w = prefix_sum(zq);
+        w = prefix_sum<G>(zq);
         const f3 wp = w - zq;                                            // parent link
         const f3 dal = cross(wp, zq);
-        al = prefix_sum(dal);
+        al = prefix_sum<G>(dal);
         const f3 alp = al - dal;
-        const f3 r = mk(P.x - rshr0<1>(P.x), P.y - rshr0<1>(P.y), P.z - rshr0<1>(P.z));
+        const f3 r = mk(P.x - rshr0<G, 1>(P.x), P.y - rshr0<G, 1>(P.y), P.z - rshr0<G, 1>(P.z));
         f3 da = cross(alp, r) + cross(wp, cross(wp, r));
         da.z += (gl == 0) ? GRAV : 0.f;                                  // gravity enters as the base acceleration
-        ao = prefix_sum(da);
+        ao = prefix_sum<G>(da);
         const f3 ac = ao + cross(al, rcm) + cross(w, cross(w, rcm));
         const float mass = at[AT_MASS];
         const f3 F = ac * mass;
@@ -557,16 +639,16 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         Iw[0] = RI0.x * X.x + RI0.y * Y.x + RI0.z * Z.x; Iw[1] = RI0.x * X.y + RI0.y * Y.y + RI0.z * Z.y; Iw[2] = RI0.x * X.z + RI0.y * Y.z + RI0.z * Z.z;
         Iw[3] = RI1.x * X.y + RI1.y * Y.y + RI1.z * Z.y; Iw[4] = RI1.x * X.z + RI1.y * Y.z + RI1.z * Z.z; Iw[5] = RI2.x * X.z + RI2.y * Y.z + RI2.z * Z.z;
         const f3 Nc = symmul(Iw, al) + cross(w, symmul(Iw, w)) + cross(cm_, F);      // moment about the base origin
-        const f3 fa = suffix_sum(F), na = suffix_sum(Nc);
+        const f3 fa = suffix_sum<G>(F), na = suffix_sum<G>(Nc);
         bias = dot(Z, na - cross(P, fa));
         // composite inertia about the base origin: mass, first moment, second moment
         const float cc = dot(cm_, cm_);
         float Io[6] = {fmaf(mass, cc - cm_.x * cm_.x, Iw[0]), fmaf(-mass, cm_.x * cm_.y, Iw[1]), fmaf(-mass, cm_.x * cm_.z, Iw[2]),
                        fmaf(mass, cc - cm_.y * cm_.y, Iw[3]), fmaf(-mass, cm_.y * cm_.z, Iw[4]), fmaf(mass, cc - cm_.z * cm_.z, Iw[5])};
-        const float cmass = suffix_sum(mass);
-        const f3 ch = suffix_sum(cm_ * mass);
+        const float cmass = suffix_sum<G>(mass);
+        const f3 ch = suffix_sum<G>(cm_ * mass);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) Io[k] = suffix_sum(Io[k]);
+        for (int k = 0; k < 6; ++k) Io[k] = suffix_sum<G>(Io[k]);
         const f3 vo = cross(P, Z);
         const f3 nn = symmul(Io, Z) + cross(ch, vo);
         const f3 ff = vo * cmass + cross(Z, ch);
@@ -574,7 +656,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         float Ml[8];
         static_for<NJ>([&](auto Jc) {
             constexpr int j = decltype(Jc)::value;
-            Ml[j] = spatial_dot_bc<j>(Z, vo, nn, ff);
+            Ml[j] = spatial_dot_bc<G, j>(Z, vo, nn, ff);
         });
         Ml[7] = 0.f;
         // upper triangle through LDS: every lane parks its row, then reads its column
@@ -597,9 +679,9 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
     static_for<NJ>([&](auto Kc) {
         constexpr int k = decltype(Kc)::value;
         const float mk_ = (gl == k) ? 1.f : 0.f;
-        const float g = (mk_ - Mi[k]) * rcp_(rbc<k>(Mi[k]));           // minus the elimination factor
+        const float g = (mk_ - Mi[k]) * rcp_(rbc<G, k>(Mi[k]));           // minus the elimination factor
         Mi[k] = mk_;
-        row_axpy_bc7<k>(Mi, g);
+        row_axpy_bc7<G, k>(Mi, g);
     });
 
     // ---------------- operational space: Jacobian column per joint lane, row per task lane, Lambda^-1 row per task lane ----------------
@@ -610,12 +692,12 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
 #pragma unroll
         for (int a = 0; a < 6; ++a) Jc[a] = jlane ? Jc[a] : 0.f;         // no column for padding / site / idle lanes
 #pragma unroll
-        for (int a = 0; a < 6; ++a) Xm[a] = row_times_joint<NJ>(Mi, Jc[a]);
+        for (int a = 0; a < 6; ++a) Xm[a] = row_times_joint<G, NJ>(Mi, Jc[a]);
         jacobian_rows(xl, gl, Jc, Jr);
 #pragma unroll
-        for (int b = 0; b < 6; ++b) Li[b] = row_times_joint<NJ>(Jr, Xm[b]);
+        for (int b = 0; b < 6; ++b) Li[b] = row_times_joint<G, NJ>(Jr, Xm[b]);
     }
-    const float v6 = row_times_joint<NJ>(Jr, qdj);                       // site twist component of this task lane
+    const float v6 = row_times_joint<G, NJ>(Jr, qdj);                       // site twist component of this task lane
     USIM_STAMP(dbg, 3);
 
     // ---------------- OSC_POSE torque (robosuite osc.py run_controller; rl_config.yaml:33-51) ----------------
@@ -674,12 +756,12 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         // nullspace torque N^T M (10 (q0 - q) - 2 sqrt(10) qd) = M pt - J^T Lambda (J pt)
         const float pt = 10.f * (q0j - qj) - 6.3245553203367586f * qdj;
         float y = 0.f, jb = 0.f;
-        y = row_times_joint<NJ>(Mr, pt); jb = row_times_joint<NJ>(Jr, pt);
+        y = row_times_joint<G, NJ>(Mr, pt); jb = row_times_joint<G, NJ>(Jr, pt);
         float A[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) A[c] = is_task ? Li[c] : 0.f;       // lanes without a task row: zero rows, never pivots
-        jb = solve6_task(A, is_task ? jb : 0.f, gl);
-        const float tq_ = bias + y + col_times_task(Jc, wr - jb);
+        jb = solve6_task<G>(A, is_task ? jb : 0.f, gl);
+        const float tq_ = bias + y + col_times_task<G>(Jc, wr - jb);
         tau = clampf(tq_, -at[AT_TAUMAX], at[AT_TAUMAX]);
     }
     if (MODE == 0 && io.log && valid) {
@@ -693,8 +775,8 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
     USIM_STAMP(dbg, 4);
 
     // ---------------- smooth acceleration, site-space acceleration of the unconstrained arm ----------------
-    const float qs = row_times_joint<NJ>(Mi, tau - bias - JOINT_DAMP * qdj);
-    const float alpha_t = row_times_joint<NJ>(Jr, qs);                   // site acceleration of the unconstrained arm, component of this task lane
+    const float qs = row_times_joint<G, NJ>(Mi, tau - bias - JOINT_DAMP * qdj);
+    const float alpha_t = row_times_joint<G, NJ>(Jr, qs);                   // site acceleration of the unconstrained arm, component of this task lane
     // ---- everything of the sensor / observation / reward that does not depend on the contact forces.  The split kernel evaluates it while
     //      the lattice side solves the contacts; the single-wave kernels evaluate it at the same place in the arithmetic, so all variants
     //      compute the same numbers ----
@@ -745,9 +827,9 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
             float dz_, vz_, az_;
             torso_motion(C, t - 1, dz_, vz_, az_);
             const f3 sxc = cross(sy, sz);
-            const int nq = __float_as_int(xl[MB_POSE + 10]), na = (nq * ARM_SHARE_NUM + ARM_SHARE_DEN - 1) / ARM_SHARE_DEN;
+            const int nq = __float_as_int(xl[MB_POSE + 10]), na = (G == 16) ? (nq * ARM_SHARE_NUM + ARM_SHARE_DEN - 1) / ARM_SHARE_DEN : 0;
             int nca = 0;
-            collide_queue<G>(lds, xl + MB_Q, 0, na, xl + MB_CA, gl, gbase, M, C, &EB(GE_S), dz_, xs, sxc, sy, sz, nca);
+            if constexpr (G == 16) collide_queue<G>(lds, xl + MB_Q, 0, na, xl + MB_CA, gl, gbase, M, C, &EB(GE_S), dz_, xs, sxc, sy, sz, nca);
             if (gl == 0) xl[MB_POSE + 9] = __int_as_float(nca);
         }
         // hand Lambda^-1 (row a from task lane a), alpha = J qs and vs = J qd to the lattice side; take the contact wrench back
@@ -792,9 +874,9 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
             float alpha[6], vs[6], Lp[21];
             static_for<6>([&](auto Ac) {
                 constexpr int a = decltype(Ac)::value;
-                alpha[a] = rbc<TASK_LANE[a]>(alpha_t); vs[a] = rbc<TASK_LANE[a]>(v6);
+                alpha[a] = rbc<G, TASK_LANE[a]>(alpha_t); vs[a] = rbc<G, TASK_LANE[a]>(v6);
 #pragma unroll
-                for (int b = 0; b <= a; ++b) Lp[PK(a, b)] = rbc<TASK_LANE[a]>(Li[b]);
+                for (int b = 0; b <= a; ++b) Lp[PK(a, b)] = rbc<G, TASK_LANE[a]>(Li[b]);
             });
             USIM_STAMP(dbg, 8);
             contact_solve<G>(lds, eb, gl, M, C, nc, ncmax, cel, Lp, alpha, vs, mu, vz, W, gf, dbg);
@@ -845,7 +927,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         // link accelerations from the site Jacobian: alpha = alpha_bias + Jw qacc, a(o) = a_bias + Jv qacc - (Jw qacc) x (x - o).  Every lane
         // evaluates the sensor on its own link's registers; the last link's lane holds the probe's.
         float aq[6];
-        static_for<6>([&](auto Ac) { constexpr int a = decltype(Ac)::value; aq[a] = rbc<TASK_LANE[a]>(aq_t); });
+        static_for<6>([&](auto Ac) { constexpr int a = decltype(Ac)::value; aq[a] = rbc<G, TASK_LANE[a]>(aq_t); });
         const f3 alq = mk(aq[3], aq[4], aq[5]);
         const f3 alt = al + alq;
         const f3 a7 = ao + mk(aq[0], aq[1], aq[2]) - cross(alq, s_xso);
@@ -853,20 +935,20 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         const f3 N = rot_inertia(alt) + s_nw;
         const f3 Fp = ac * PROBE_MASS;
         const f3 tw = N + cross(s_arm, Fp) - mk(W[3], W[4], W[5]);
-        tq[0] = rbc<NJ - 1>(dot(sx, tw)); tq[1] = rbc<NJ - 1>(dot(sy, tw)); tq[2] = rbc<NJ - 1>(dot(sz, tw));
+        tq[0] = rbc<G, NJ - 1>(dot(sx, tw)); tq[1] = rbc<G, NJ - 1>(dot(sy, tw)); tq[2] = rbc<G, NJ - 1>(dot(sz, tw));
         USIM_STAMP(dbg, 13);
         hv = mk(0, 0, 0);
         if constexpr (MODE == 0) {
             // mj_Euler with implicit joint damping: (M + h D) x = M qacc, one fixed-point step on M^-1
-            const float xk = row_times_joint<NJ>(Mi, qacc);
+            const float xk = row_times_joint<G, NJ>(Mi, qacc);
             const float rhs = fmaf(-dt * JOINT_DAMP, xk, qacc);
             qdj = fmaf(dt, rhs, qdj); dqj = fmaf(dt, qdj, dqj);
             if (!jlane) { qdj = 0.f; dqj = 0.f; }
             qj = q0j + dqj;
             // hand velocity: Jacobian from before the integration, qvel from after (mj_step data semantics)
-            const float v2_t = row_times_joint<NJ>(Jr, qdj);
+            const float v2_t = row_times_joint<G, NJ>(Jr, qdj);
             float v2[6];
-            static_for<6>([&](auto Ac) { constexpr int a = decltype(Ac)::value; v2[a] = rbc<TASK_LANE[a]>(v2_t); });
+            static_for<6>([&](auto Ac) { constexpr int a = decltype(Ac)::value; v2[a] = rbc<G, TASK_LANE[a]>(v2_t); });
             hv = mk(v2[0], v2[1], v2[2]) + cross(mk(v2[3], v2[4], v2[5]), hand - xs);
         }
     }
@@ -913,7 +995,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         fzbar = 0.1f * fz + 0.9f * fzbar;
         // joint-limit margin and run-away guard are per-joint quantities: one ballot / one prefix sum over the group
         const bool jviol = (qj < at[AT_QMIN] + 0.1f) || (qj > at[AT_QMAX] - 0.1f);
-        const unsigned jany = (unsigned)(__ballot(jviol) >> gbase) & 0xffffu;
+        const unsigned jany = (unsigned)(__ballot(jviol) >> gbase) & GMASK;
         if (C.early_term) {
             const bool term = (jany != 0u) || (pos_err_norm > 1.0f) || (contact && ori_err > 0.10f) || (touched && !contact);
             done = done || term;
@@ -938,7 +1020,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         if (overflow) status |= 1;
         {
             // numerical fault guard: a non-finite or run-away state ends the episode and is flagged
-            const float chk = rbc<7>(prefix_sum(fabsf(qj) + 1e-3f * fabsf(qdj)));
+            const float chk = rbc<G, 7>(prefix_sum<G>(fabsf(qj) + 1e-3f * fabsf(qdj)));
             if (!(chk < 1.0e3f)) { status |= 4; done = true; epret -= reward; reward = 0.f; if (!(epret == epret)) epret = 0.f; }
         }
         if (store) {
@@ -1025,7 +1107,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
 // One launch = io.nsub consecutive steps (usim_rollout_random: the actions are drawn in-kernel, so step k + 1 needs nothing from the host).
 // The lattice tables stay in LDS, launch latency and the kernel-argument / first-load round trip are paid once; every step still reads its
 // state from HBM and writes it back together with its slice of the transition block, so the algorithmic traffic per step is unchanged.
-template <int TORSO, int MODE, int ROLE, int NT, bool MULTI = false>
+template <int TORSO, int MODE, int ROLE, int NT, bool MULTI = false, int G = 16>
 DI void step16_body(float* lds, const DevModel& M, const DevCfg& C, float* __restrict__ st, const int n, const int npad, const DevIO& io0, const int flags, const long long rstep) {
     // (MULTI is a template parameter: the single-step instantiation -- usim_step, a policy in the loop -- keeps the register allocation of a
     // straight-line kernel; the loop costs it 2 us per step)
@@ -1033,7 +1115,7 @@ DI void step16_body(float* lds, const DevModel& M, const DevCfg& C, float* __res
     DevIO io = io0;
     int nbar = 0;                                                        // barriers executed by this wave (read by the profiling build only)
     for (int ks = 0; ks < nsub; ++ks) {
-        step16_one<TORSO, MODE, ROLE, NT>(lds, M, C, st, n, npad, io, flags, rstep + ks, ks == 0, nbar);
+        step16_one<TORSO, MODE, ROLE, NT, G>(lds, M, C, st, n, npad, io, flags, rstep + ks, ks == 0, nbar);
         if (ks + 1 < nsub) {
             // the next step reads the state words this one stored -- some through other lanes of the group, the per-episode scalars through the
             // other wave of the pair (split kernel): order the stores, then meet.  (Both roles of the split kernel pass here once per step.)
@@ -1070,12 +1152,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 // early return, a barrier under a branch that is not uniform over the whole workgroup, or a fifth hand-off on one side only would hang the
 // GPU instead of failing a test.  The profiling build counts the barriers of both roles (USIM_BAR: ticks[46] / ticks[47] of usim_profile_step) and
 // tests/test_gpu_properties.py compares them; the split-vs-single-wave bit-exactness tests cover ragged workgroups and slot overflow.
-template <bool MULTI>
+// G = 16: 16 environments per workgroup (a quad per wave pair).  G = 8: 32 environments per workgroup (eight per wave pair; two per DPP row) -- the
+// mapping for more than 4096 envs/GPU, where 16-lane groups would need a second round of workgroups.
+template <bool MULTI, int G = 16>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void usim_step32_kernel(const DevModel M, const DevCfg C, float* __restrict__ st, int n, int npad,
                                                                                                        const DevIO io, int flags, long long rstep) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    if (threadIdx.x < 256) step16_body<1, 0, 1, 512, MULTI>(lds, M, C, st, n, npad, io, flags, rstep);
-    else step16_body<1, 0, 2, 512, MULTI>(lds, M, C, st, n, npad, io, flags, rstep);
+    if (threadIdx.x < 256) step16_body<1, 0, 1, 512, MULTI, G>(lds, M, C, st, n, npad, io, flags, rstep);
+    else step16_body<1, 0, 2, 512, MULTI, G>(lds, M, C, st, n, npad, io, flags, rstep);
 }
 
 }  // namespace usim

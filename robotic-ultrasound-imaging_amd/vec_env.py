@@ -159,7 +159,7 @@ class UltrasoundVecEnv:
         self.steps_per_launch = int(steps)
 
     def set_mapping(self, lanes_per_env, waves_per_simd=0):
-        """Switch a live soft-torso env between the split kernel (lanes_per_env 32) and the single-wave 16-lane kernel (waves_per_simd
+        """Switch a live soft-torso env between the split kernel (lanes_per_env 32: 16-lane groups, 64: 8-lane groups) and the single-wave 16-lane kernel (waves_per_simd
         0 / 1 / 2).  The mappings compute the same bits; the choice only matters for speed (include/usim.h usim_set_mapping)."""
         self._check(self.lib.usim_set_mapping(self._handle, int(lanes_per_env), int(waves_per_simd)))
 

@@ -163,11 +163,12 @@ def test_full_size_parity_4096_envs(usim):
     _run_parity(usim, 4096, 200, "soft", "tracking", omp=True)
 
 
-@pytest.mark.parametrize("mapping", [{"lanes_per_env": 8}, {"lanes_per_env": 16, "waves_per_simd": 1}, {"lanes_per_env": 16, "waves_per_simd": 2}],
-                         ids=["8-lane", "16-lane-occ1", "16-lane-occ2"])
+@pytest.mark.parametrize("mapping", [{"lanes_per_env": 8}, {"lanes_per_env": 16, "waves_per_simd": 1}, {"lanes_per_env": 16, "waves_per_simd": 2}, {"lanes_per_env": 64}],
+                         ids=["8-lane", "16-lane-occ1", "16-lane-occ2", "split-8-lane-groups"])
 def test_every_kernel_mapping_holds_the_full_parity_bars(usim, mapping):
-    """The non-default mappings -- the round-1 kernel with the arm mathematics replicated over 8 lanes, the single-wave 16-lane kernel in both
-    register budgets -- through the same check as the default split kernel: 200 steps, done flags and contact indices bit-exact, every
+    """The mappings that are not the default at this size -- the round-1 kernel with the arm mathematics replicated over 8 lanes, the single-wave
+    16-lane kernel in both register budgets, the split kernel with 8-lane groups (two environments per DPP row; automatic beyond 4096
+    envs/GPU) -- through the same check as the default split kernel: 200 steps, done flags and contact indices bit-exact, every
     observation channel and the state within the oracle bars (they share the lattice / contact phases, not the arm mathematics)."""
     _run_parity(usim, 256, 200, "soft", "tracking", gpu_extra=mapping)
 

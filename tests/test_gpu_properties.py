@@ -303,9 +303,10 @@ def test_split_kernel_equals_the_single_wave_kernel_bit_for_bit(usim):
     """lanes_per_env = 32 (arm side and lattice / contact side of a quad of environments in two waves, mailboxes in LDS; the automatic choice
     up to 4096 envs) and lanes_per_env = 16 (one wave does both) are the same arithmetic: identical bits over 300 steps with auto-resets,
     both register budgets of the 16-lane kernel included"""
-    envs = [_env(usim, 1000, lanes_per_env=32), _env(usim, 1000, lanes_per_env=16, waves_per_simd=1), _env(usim, 1000, lanes_per_env=16, waves_per_simd=2)]
+    envs = [_env(usim, 1000, lanes_per_env=32), _env(usim, 1000, lanes_per_env=16, waves_per_simd=1), _env(usim, 1000, lanes_per_env=16, waves_per_simd=2),
+            _env(usim, 1000, lanes_per_env=64)]        # 64: the split kernel with 8-lane groups (two environments per DPP row)
     obs0 = [e.reset_tensor().clone() for e in envs]
-    assert torch.equal(obs0[0], obs0[1]) and torch.equal(obs0[0], obs0[2])
+    assert all(torch.equal(obs0[0], o) for o in obs0[1:])
     ended = 0
     for k in range(300):
         act = envs[0].random_actions_tensor(k).clone()

@@ -14,6 +14,9 @@ run "configs[2] lanes 16"             --steps 2000 --warmup 100 --lanes-per-env 
 run "configs[1] rigid 4096"           --steps 2000 --warmup 100 --workload rigid
 run "configs[4] 8192 randomised auto" --steps 1000 --warmup 100 --envs-per-gpu 8192 --randomize
 run "configs[4] 8192 randomised l32"  --steps 1000 --warmup 100 --envs-per-gpu 8192 --randomize --lanes-per-env 32
+run "configs[4] 8192 randomised l64"  --steps 1000 --warmup 100 --envs-per-gpu 8192 --randomize --lanes-per-env 64
 run "configs[4] 8192 randomised l8"   --steps 1000 --warmup 100 --envs-per-gpu 8192 --randomize --lanes-per-env 8
 run "soft 16384 auto"                 --steps 500 --warmup 100 --envs-per-gpu 16384
+run "soft 16384 l64"                  --steps 500 --warmup 100 --envs-per-gpu 16384 --lanes-per-env 64
+run "configs[2] soft 4096 l64"        --steps 2000 --warmup 100 --lanes-per-env 64
 run "soft 16384 l32"                  --steps 500 --warmup 100 --envs-per-gpu 16384 --lanes-per-env 32
