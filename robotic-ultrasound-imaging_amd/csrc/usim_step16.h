@@ -240,19 +240,26 @@ constexpr int X16_RIGID_STRIDE = 68;                  // rigid-torso launches: o
 // behind the per-environment blocks (16 with 16-lane groups, 32 with 8-lane groups): arm scratch + mailboxes of the split kernel
 template <int G> constexpr int x2_base() { return TB_WORDS + (256 / G) * GE_STRIDE; }
 // 64 transpose scratch | 12 pose (+ the arm side's hit count in word 9) | 64 op-space (6 x 8 Lambda^-1, alpha 6, vs 6) | 16 wrench + contacts | the arm side's contact records
-constexpr int MB_POSE = 64, MB_OP = 76, MB_W = 140, MB_CA = 156;
-// (8-lane groups: no record area for an arm-side share of the narrow phase -- 32 environments per workgroup have to fit the CU's 160 KB of LDS)
-template <int G> constexpr int mb_q() { return G == 16 ? MB_CA + (MAXCAND + 1) * CG_WORDS : MB_CA; }                // ... | broad-phase queue (element ids)
+// 16-lane groups: 64 transpose scratch | 12 pose | 64 op-space | 16 wrench + contacts | 17 x 8 arm-side contact records | 100 queue.
+// 8-lane groups (32 environments per workgroup have to fit the CU's 160 KB): the arm side's contact records overlay the transpose scratch, which
+// is idle from the arm side's narrow-phase share until the next step, plus 72 words behind it; the mailboxes follow.
+template <int G> constexpr int mb_pose() { return G == 16 ? 64 : (MAXCAND + 1) * CG_WORDS; }
+template <int G> constexpr int mb_op() { return mb_pose<G>() + 12; }
+template <int G> constexpr int mb_w() { return mb_op<G>() + 64; }
+template <int G> constexpr int mb_ca() { return G == 16 ? mb_w<G>() + 16 : 0; }                                       // arm-side contact records
+template <int G> constexpr int mb_q() { return G == 16 ? mb_ca<G>() + (MAXCAND + 1) * CG_WORDS : mb_w<G>() + 16; }    // broad-phase queue (element ids)
 template <int G> constexpr int x2_stride() { return mb_q<G>() + 100; }
-static_assert(MB_W + 16 <= MB_CA && (MB_CA % 4) == 0 && (x2_stride<16>() % 4) == 0 && (x2_stride<8>() % 4) == 0, "mailbox block");
+static_assert((mb_ca<16>() % 4) == 0 && (mb_pose<8>() % 4) == 0 && (x2_stride<16>() % 4) == 0 && (x2_stride<8>() % 4) == 0, "mailbox block");
 static_assert((x2_base<8>() + 32 * x2_stride<8>()) * 4 <= 160 * 1024, "split kernel with 8-lane groups: LDS of a CU");
 // Collision in the split kernel: the ARM side, which has the site pose first, runs the broad phase over all 99 elements (collide_cull) while the
 // lattice side still stages its right-hand side, and leaves the survivors' ids (ascending) in the queue; after hand-off (1) the arm side takes
 // the first ARM_SHARE_NUM / ARM_SHARE_DEN of the queue, the lattice side the rest, each typically in one pass of its 16 lanes per environment.
 // (With the broad phase the narrow phase is short enough that the lattice side does best with all of it; the sharing machinery stays for
 // other probe shapes.)
-constexpr int ARM_CULL_ROUNDS = 7;                   // broad-phase rounds the arm side runs before hand-off (1); the lattice side runs the rest after it.  Measured (us/step, one box): 0 -> 15.67, 2 -> 15.98, 4 -> 15.92, 7 (all) -> 15.48
-constexpr int ARM_SHARE_NUM = 0, ARM_SHARE_DEN = 1;     // measured (us/step, one box): 0 -> 15.48, 1/4 -> 15.80, 1/3 -> 15.61, 1/2 -> 15.77
+template <int G> constexpr int arm_cull_rounds() { return 7; }   // broad-phase rounds the arm side runs before hand-off (1); the lattice side runs the rest after it.  16-lane groups, measured (us/step, one box): 0 -> 15.67, 2 -> 15.98, 4 -> 15.92, 7 (all) -> 15.48
+constexpr int ARM_SHARE_DEN = 4;
+template <int G> constexpr int arm_share_num() { return 0; }     // quarters of the queue the arm side evaluates.  Measured (us/step, one box): 16-lane groups 0 -> 15.48, 1 -> 15.80, 2 -> 15.77; 8-lane groups at 8192 envs 0 -> 23.06, 2 -> 23.93, 3 -> 24.06 (the two waves share a SIMD: what the arm wave does while it would wait costs the lattice wave issue slots)
+// 16-lane groups     // measured (us/step, one box): 0 -> 15.48, 1/4 -> 15.80, 1/3 -> 15.61, 1/2 -> 15.77
 
 // workgroup barrier of the step kernels; the profiling build counts them per role (BARRIER INVARIANT at usim_step32_kernel)
 #if defined(USIM_TSTAMP) || defined(USIM_TSTAMP_NOWAIT)
@@ -265,7 +272,7 @@ template <int TORSO, int MODE, int ROLE, int NT, int G = 16>
 DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __restrict__ st, const int n, const int npad, const DevIO& io, const int flags, const long long rstep,
                    const bool first_pass, int& nbar) {
     constexpr int EPW = 64 / G, EPB = 4 * EPW;                          // environments per wave / per workgroup (four waves per role)
-    constexpr int X2_BASE = x2_base<G>(), X2_STRIDE = x2_stride<G>(), MB_Q = mb_q<G>();
+    constexpr int X2_BASE = x2_base<G>(), X2_STRIDE = x2_stride<G>(), MB_Q = mb_q<G>(), MB_POSE = mb_pose<G>(), MB_OP = mb_op<G>(), MB_W = mb_w<G>(), MB_CA = mb_ca<G>();
     constexpr unsigned GMASK = (G == 16) ? 0xffffu : 0xffu;
     static_assert(G == 16 || (TORSO == 1 && MODE == 0 && ROLE != 0), "8-lane groups: the split soft-torso step only");
     constexpr int NE = TORSO ? (N_TOP + G - 1) / G : 1;
@@ -375,10 +382,10 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
                  sz = mk(mb[MB_POSE + 6], mb[MB_POSE + 7], mb[MB_POSE + 8]);
         int nq = __float_as_int(mb[MB_POSE + 10]);
         {
-            // the rest of the broad phase (elements 16 ARM_CULL_ROUNDS ..): appended to the arm side's part of the queue
+            // the rest of the broad phase (elements 16 arm_cull_rounds<G>() ..): appended to the arm side's part of the queue
             const f3 sxc = cross(sy, sz);
 #pragma unroll
-            for (int i = ARM_CULL_ROUNDS; i < NE; ++i) {
+            for (int i = arm_cull_rounds<G>(); i < NE; ++i) {
                 const int eraw = i * G + gl, e = eraw < N_TOP ? eraw : N_TOP - 1;
                 const bool cand = (eraw < N_TOP) && collide_cull(lds, e, M, C, s_pre[i], dz, xs, sxc, sz);
                 const unsigned gm = (unsigned)(__ballot(cand) >> gbase) & GMASK;
@@ -387,21 +394,30 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
             }
             group_sync();
         }
-        const int na = (G == 16) ? (__float_as_int(mb[MB_POSE + 10]) * ARM_SHARE_NUM + ARM_SHARE_DEN - 1) / ARM_SHARE_DEN : 0;
+        const int na = (__float_as_int(mb[MB_POSE + 10]) * arm_share_num<G>() + ARM_SHARE_DEN - 1) / ARM_SHARE_DEN;
         const int ncl = lattice_front<G, NE, true, 2, true>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, true, s_pre, sd_pre, xs, sy, sz, dbg, mb + MB_Q, na, nq);
         RSTAMP(3);
         USIM_BAR();                                                 // (2) ... and Lambda^-1, alpha = J qs, vs = J qd, and the arm side's contact records
         RSTAMP(4);
         // one list in ascending shell id: the arm side's records (first part of the queue) first, this side's behind them
-        const int nca = (G == 16) ? __float_as_int(mb[MB_POSE + 9]) : 0;
+        const int nca = __float_as_int(mb[MB_POSE + 9]);
         int nc = nca + ncl;
-        if (G == 16 && __any(nca > 0)) {
-            const int na = nca < MAXCAND ? nca : MAXCAND, li = gl - na;
-            const float4* src = reinterpret_cast<const float4*>(gl < na ? &mb[MB_CA + gl * CG_WORDS] : &EB(GE_CG + (li > 0 ? li : 0) * CG_WORDS));
-            const float4 r0 = src[0], r1 = src[1];
+        if (__any(nca > 0)) {
+            constexpr int RPL = MAXCAND / G;                             // records per lane of the group
+            const int na = nca < MAXCAND ? nca : MAXCAND;
+            float4 r0[RPL], r1[RPL];
+#pragma unroll
+            for (int hh = 0; hh < RPL; ++hh) {
+                const int gg = gl + hh * G, li = gg - na;
+                const float4* src = reinterpret_cast<const float4*>(gg < na ? &mb[MB_CA + gg * CG_WORDS] : &EB(GE_CG + (li > 0 ? li : 0) * CG_WORDS));
+                r0[hh] = src[0]; r1[hh] = src[1];
+            }
             group_sync();                                                // every record is in registers before any slot is overwritten
-            float4* dst = reinterpret_cast<float4*>(&EB(GE_CG + gl * CG_WORDS));
-            dst[0] = r0; dst[1] = r1;
+#pragma unroll
+            for (int hh = 0; hh < RPL; ++hh) {
+                float4* dst = reinterpret_cast<float4*>(&EB(GE_CG + (gl + hh * G) * CG_WORDS));
+                dst[0] = r0[hh]; dst[1] = r1[hh];
+            }
         }
         contact_overflow<G>(lds, eb, gl, gbase, nc);
         int overflow = 0;
@@ -565,7 +581,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
             for (int i = 0; i < NE; ++i) {
                 const int eraw = i * G + gl, e = eraw < N_TOP ? eraw : N_TOP - 1;
                 if (eraw < N_TOP) EB(GE_S + eraw) = s_pre[i];
-                if (i >= ARM_CULL_ROUNDS) continue;
+                if (i >= arm_cull_rounds<G>()) continue;
                 const bool cand = (eraw < N_TOP) && collide_cull(lds, e, M, C, s_pre[i], dz_, xs, sxc, sz);
                 const unsigned gm = (unsigned)(__ballot(cand) >> gbase) & GMASK;
                 if (cand) xl[MB_Q + nq + __popc(gm & ((1u << gl) - 1u))] = __int_as_float(e);
@@ -827,9 +843,9 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
             float dz_, vz_, az_;
             torso_motion(C, t - 1, dz_, vz_, az_);
             const f3 sxc = cross(sy, sz);
-            const int nq = __float_as_int(xl[MB_POSE + 10]), na = (G == 16) ? (nq * ARM_SHARE_NUM + ARM_SHARE_DEN - 1) / ARM_SHARE_DEN : 0;
+            const int nq = __float_as_int(xl[MB_POSE + 10]), na = (nq * arm_share_num<G>() + ARM_SHARE_DEN - 1) / ARM_SHARE_DEN;
             int nca = 0;
-            if constexpr (G == 16) collide_queue<G>(lds, xl + MB_Q, 0, na, xl + MB_CA, gl, gbase, M, C, &EB(GE_S), dz_, xs, sxc, sy, sz, nca);
+            collide_queue<G>(lds, xl + MB_Q, 0, na, xl + MB_CA, gl, gbase, M, C, &EB(GE_S), dz_, xs, sxc, sy, sz, nca);
             if (gl == 0) xl[MB_POSE + 9] = __int_as_float(nca);
         }
         // hand Lambda^-1 (row a from task lane a), alpha = J qs and vs = J qd to the lattice side; take the contact wrench back

@@ -8,8 +8,10 @@ os.environ["USIM_LIB"] = str(PROF)
 sys.path.insert(0, str(ROOT))
 import numpy as np, torch
 usim = importlib.import_module("robotic-ultrasound-imaging_amd")
-env = usim.UltrasoundVecEnv(4096, torso="soft", lanes_per_env=32, **usim.default_robosuite_kwargs())
 pre = int(sys.argv[1]) if len(sys.argv) > 1 else 200          # steps since the synchronous reset at which the stamps are taken
+nenv = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+lanes = int(sys.argv[3]) if len(sys.argv) > 3 else 32          # 32: 16-lane groups, 64: 8-lane groups
+env = usim.UltrasoundVecEnv(nenv, torso="soft", lanes_per_env=lanes, **usim.default_robosuite_kwargs())
 env.reset_tensor(); env.rollout_random(0, pre); torch.cuda.synchronize()
 rows = np.array([env.profile_step_raw(pre + k) for k in range(20 if pre < 100 else 50)], dtype=np.float64)
 print(f"stamps of steps {pre} .. {pre + len(rows) - 1} after the reset")
