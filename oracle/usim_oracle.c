@@ -756,10 +756,9 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
                 v3set(uw, -m->el_axis[e][0] * (real)(2 * ELEM_COLL_HALFLEN), -m->el_axis[e][1] * (real)(2 * ELEM_COLL_HALFLEN), -m->el_axis[e][2] * (real)(2 * ELEM_COLL_HALFLEN));
                 m3tmulv(us, k->Rs, uw);
                 v3add(ps, p0, us);
-                real s0 = v3dot(g0, us);   /* (set below) */
-                (void)probe_sdf(S, p0, g0); s0 = v3dot(g0, us);
+                (void)probe_sdf(S, p0, g0);
                 (void)probe_sdf(S, ps, g1);
-                real s1 = v3dot(g1, us), curv = s1 - s0; if (curv < 0) curv = 0;
+                real s0 = v3dot(g0, us), s1 = v3dot(g1, us), curv = s1 - s0; if (curv < 0) curv = 0;
                 tt = -s0 / (curv + (real)SHAFT_EPS); if (tt < 0) tt = 0; if (tt > 1) tt = 1;
                 v3addscl(ps, p0, us, tt); best = probe_sdf(S, ps, gs);
                 m3mulv(gw, k->Rs, gs); v3addscl(c2, tip, uw, tt); v3set(nrm, -gw[0], -gw[1], -gw[2]);
