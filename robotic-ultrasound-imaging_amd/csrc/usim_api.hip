@@ -338,9 +338,10 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
         return USIM_ERR_UNSUPPORTED;
     }
     h->occ = cfg->waves_per_simd ? cfg->waves_per_simd : (n_envs <= 4096 ? 1 : 2);
-    h->lds16_bytes = h->n_el ? (size_t)GroupGeom<16>::LDS_WORDS * sizeof(float) : (size_t)16 * X16_RIGID_STRIDE * sizeof(float);
-    h->lds32_bytes = (size_t)(x2_base<16>() + 16 * x2_stride<16>()) * sizeof(float);
-    h->lds64_bytes = (size_t)(x2_base<8>() + 32 * x2_stride<8>()) * sizeof(float);
+    // (every 16-lane kernel: + the arm table, parked behind everything else by multi-step launches)
+    h->lds16_bytes = (size_t)((h->n_el ? arm_lds_base<1, 0, 16>() : arm_lds_base<0, 0, 16>()) + ARM_LDS_WORDS) * sizeof(float);
+    h->lds32_bytes = (size_t)(arm_lds_base<1, 1, 16>() + ARM_LDS_WORDS) * sizeof(float);
+    h->lds64_bytes = (size_t)(arm_lds_base<1, 1, 8>() + ARM_LDS_WORDS) * sizeof(float);
     if (h->n_el) {
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step32_kernel<false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds32_bytes));
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&usim_step32_kernel<true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds32_bytes));
@@ -601,6 +602,8 @@ int usim_profile_step(usim_handle* h, const usim_step_io* s, int64_t step, uint6
     HIPCHK(h, hipMalloc(&d, 64 * sizeof(unsigned long long)));
     HIPCHK(h, hipMemset(d, 0, 64 * sizeof(unsigned long long)));
     io.dbg = d; io.items = h->d_items; io.count = h->d_count;
+    // USIM_PROFILE_NSUB = k: the stamps of the LAST of k consecutive steps of one launch (multi-step kernels; never across a refill period)
+    if (const char* ns = std::getenv("USIM_PROFILE_NSUB")) { const int v = std::atoi(ns); if (v > 1 && v <= BANK_DEPTH - h->steps_since_refill) { io.nsub = v; h->steps_since_refill += v - 1; } }
     rc = launch<0>(h, io, LF_AUTO_RESET | LF_RANDOM_ACT, (long long)step, nullptr);
     if (rc == USIM_OK && ++h->steps_since_refill >= BANK_DEPTH) rc = bank_refill(h, nullptr);
     HIPCHK(h, hipDeviceSynchronize());

@@ -268,16 +268,44 @@ template <int G> constexpr int arm_share_num() { return 0; }     // quarters of 
 #define USIM_BAR() __syncthreads()
 #endif
 
-template <int TORSO, int MODE, int ROLE, int NT, int G = 16>
+
+// State of an environment that stays in the registers of its lanes from one step of a multi-step launch to the next (RES): its joint words, the
+// scalar words (held by every lane of the group) and its elements of the lattice.  Every step still STORES the state (and its slice of the
+// transition block); what a resident launch saves is waiting for the words it stored itself to come back.  The arm table (28 words per lane,
+// needed at the top of every step) is parked in LDS behind everything else during the first step and read from there afterwards: kept in
+// registers it would be live across the whole step (the split kernel spills at 256 registers).
+constexpr int ARM_LDS_WORDS = A16_LANES * AT_STRIDE;
+template <int TORSO, int ROLE, int G> constexpr int arm_lds_base();
+template <int NE>
+struct Carry {
+    float dqj, qdj, q0j;
+    f3 ts, te;
+    float u0, vbar, fzbar, fzprev, dfz, kst, kdmp, mu, epret;
+    int t, touched, episode, status;
+    float s[NE], sd[NE];
+};
+
+template <int TORSO, int ROLE, int G> constexpr int arm_lds_base() {
+    return ROLE != 0 ? x2_base<G>() + (256 / G) * x2_stride<G>() : (TORSO ? GroupGeom<16>::LDS_WORDS : 16 * X16_RIGID_STRIDE);
+}
+static_assert((arm_lds_base<1, 1, 8>() + ARM_LDS_WORDS) * 4 <= 160 * 1024 && arm_lds_base<1, 1, 8>() % 4 == 0 && arm_lds_base<1, 1, 16>() % 4 == 0 && arm_lds_base<1, 0, 16>() % 4 == 0
+              && arm_lds_base<0, 0, 16>() % 4 == 0, "arm table behind the LDS blocks of every 16-lane kernel");
+
+template <int TORSO, int MODE, int ROLE, int NT, int G = 16, bool RES = false>
 DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __restrict__ st, const int n, const int npad, const DevIO& io, const int flags, const long long rstep,
-                   const bool first_pass, int& nbar) {
+                   const bool first_pass, int& nbar, Carry<TORSO ? (N_TOP + G - 1) / G : 1>& cy) {
     constexpr int EPW = 64 / G, EPB = 4 * EPW;                          // environments per wave / per workgroup (four waves per role)
+    static_assert(!RES || MODE == 0, "resident state: step launches only");
     constexpr int X2_BASE = x2_base<G>(), X2_STRIDE = x2_stride<G>(), MB_Q = mb_q<G>(), MB_POSE = mb_pose<G>(), MB_OP = mb_op<G>(), MB_W = mb_w<G>(), MB_CA = mb_ca<G>();
     constexpr unsigned GMASK = (G == 16) ? 0xffffu : 0xffu;
     static_assert(G == 16 || (TORSO == 1 && MODE == 0 && ROLE != 0), "8-lane groups: the split soft-torso step only");
     constexpr int NE = TORSO ? (N_TOP + G - 1) / G : 1;
     static_assert(ROLE == 0 || (TORSO == 1 && MODE == 0), "the split kernel is the soft-torso step");
     const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;      // wave within its role = quad of environments
+    // resident state (see Carry): everywhere but on the lattice side of the split kernel with 16-lane groups, where it measured slower (one box,
+    // us/step at 4096 envs: neither side 15.00, arm side only 14.78, both 15.28, lattice side only 15.60; 8-lane groups at 8192 envs: 23.10 / 22.73 / 22.67)
+    constexpr bool RES_HERE = RES && !(ROLE == 2 && G == 16);
+    const bool fresh = !RES_HERE || first_pass;                         // the state comes from HBM (first step of a launch; every single-step launch)
     const int gl = lane & (G - 1), ge = lane / G;
     const int gbase = lane - gl;
     const int eb = wave * EPW + ge;
@@ -312,38 +340,71 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
     // ---------------- load: this lane's link record, its joint state, the environment's scalars ----------------
     float at[AT_STRIDE];
     {
-        const float4* ap = reinterpret_cast<const float4*>(M.tables + TB_ARM + gl * AT_STRIDE);
+        constexpr int ARM_LDS = arm_lds_base<TORSO, ROLE, G>();
+        const float4* ap = fresh ? reinterpret_cast<const float4*>(M.tables + TB_ARM + gl * AT_STRIDE) : reinterpret_cast<const float4*>(lds + ARM_LDS + gl * AT_STRIDE);
+        if (fresh) {
 #pragma unroll
-        for (int v = 0; v < AT_STRIDE / 4; ++v) { const float4 x = ap[v]; at[4 * v] = x.x; at[4 * v + 1] = x.y; at[4 * v + 2] = x.z; at[4 * v + 3] = x.w; }
+            for (int v = 0; v < AT_STRIDE / 4; ++v) { const float4 x = ap[v]; at[4 * v] = x.x; at[4 * v + 1] = x.y; at[4 * v + 2] = x.z; at[4 * v + 3] = x.w; }
+            if constexpr (RES && ROLE != 2) {
+                // (every wave writes the same words and reads them back itself: no hand-off involved)
+                if (lane < G) {
+#pragma unroll
+                    for (int v = 0; v < AT_STRIDE / 4; ++v) reinterpret_cast<float4*>(lds + ARM_LDS + gl * AT_STRIDE)[v] = make_float4(at[4 * v], at[4 * v + 1], at[4 * v + 2], at[4 * v + 3]);
+                }
+            }
+        } else {
+            const float4* lp = reinterpret_cast<const float4*>(lds + ARM_LDS + gl * AT_STRIDE);
+#pragma unroll
+            for (int v = 0; v < AT_STRIDE / 4; ++v) { const float4 x = lp[v]; at[4 * v] = x.x; at[4 * v + 1] = x.y; at[4 * v + 2] = x.z; at[4 * v + 3] = x.w; }
+        }
     }
     const float* const sp = st + scalar_index(0, (size_t)ei);
     const bool jlane = at[AT_JOINT] != 0.f;                       // lanes that own a joint (a chain of fewer than seven joints pads with locked ones)
     const int jl = jlane ? gl : NJ - 1;
     // the joint words of the state hold dq = q - q0 (usim_device.h): the per-step increment dt qd is then rounded at the magnitude of the
     // excursion (~0.05 rad), not of the angle (~3 rad) -- the rounding of q would otherwise accumulate to micrometres at the probe over 200 steps
-    float dqj = sp[F_Q + jl], qdj = sp[F_QD + jl], q0j = sp[F_Q0 + jl];
+    float &dqj = cy.dqj, &qdj = cy.qdj, &q0j = cy.q0j;
+    f3 &ts = cy.ts, &te = cy.te;
+    float &u0 = cy.u0, &vbar = cy.vbar, &fzbar = cy.fzbar, &fzprev = cy.fzprev, &dfz = cy.dfz, &kst = cy.kst, &kdmp = cy.kdmp, &mu = cy.mu, &epret = cy.epret;
+    int &t = cy.t, &touched = cy.touched, &episode = cy.episode, &status = cy.status;
+    float (&s_pre)[NE] = cy.s, (&sd_pre)[NE] = cy.sd;
+    if (fresh) {
+        dqj = sp[F_Q + jl]; qdj = sp[F_QD + jl]; q0j = sp[F_Q0 + jl];
+        float sv[20];                                              // scalar words 20 .. 39
+        {
+            const float4* s4 = reinterpret_cast<const float4*>(sp + 20);
+#pragma unroll
+            for (int v = 0; v < 5; ++v) { const float4 x = s4[v]; sv[4 * v] = x.x; sv[4 * v + 1] = x.y; sv[4 * v + 2] = x.z; sv[4 * v + 3] = x.w; }
+        }
+#define SV(f) sv[(f) - 20]
+        ts = mk(SV(F_TS), SV(F_TS + 1), SV(F_TS + 2)); te = mk(SV(F_TE), SV(F_TE + 1), SV(F_TE + 2));
+        u0 = SV(F_U0); vbar = SV(F_VBAR); fzbar = SV(F_FZBAR); fzprev = SV(F_FZPREV); dfz = SV(F_DFZ);
+        kst = SV(F_KST); kdmp = SV(F_KDMP); mu = SV(F_MU); epret = SV(F_EPRET);
+        t = __float_as_int(SV(F_T)); touched = __float_as_int(SV(F_TOUCH)); episode = __float_as_int(SV(F_EPISODE)); status = __float_as_int(SV(F_STATUS));
+#undef SV
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = gl + i * G;
+            s_pre[i] = 0.f; sd_pre[i] = 0.f;
+            if (TORSO && MODE == 0 && ROLE != 1 && e < N_TOP) { s_pre[i] = LAT(LAT_S + e); sd_pre[i] = LAT(LAT_SD + e); }
+            if (TORSO && MODE == 0 && ROLE == 1 && e < N_TOP) s_pre[i] = LAT(LAT_S + e);      // the arm side runs the broad phase of the collision
+        }
+    } else if constexpr (RES && ROLE == 1) {
+        // resident launch, arm side: the element positions the lattice side integrated (or the zeros this side left for a new episode) are in
+        // the environment's LDS block
+#pragma unroll
+        for (int i = 0; i < NE; ++i) { const int e = gl + i * G; s_pre[i] = (e < N_TOP) ? EB(GE_S + e) : 0.f; }
+    } else if constexpr (RES && ROLE == 2) {
+        // resident launch, lattice side: the arm side reports a new episode (lattice at rest, its parameters, t = 0) through the mailbox
+        const float4 nx = *reinterpret_cast<const float4*>(&lds[X2_BASE + eb * X2_STRIDE + MB_W]);
+        if (nx.w != 0.f) {
+            kst = nx.x; kdmp = nx.y; mu = nx.z; t = 0;
+#pragma unroll
+            for (int i = 0; i < NE; ++i) { s_pre[i] = 0.f; sd_pre[i] = 0.f; }
+        }
+    }
     if (!jlane) { dqj = 0.f; qdj = 0.f; q0j = 0.f; }
     float qj = q0j + dqj;
-    float sv[20];                                                  // scalar words 20 .. 39
-    {
-        const float4* s4 = reinterpret_cast<const float4*>(sp + 20);
-#pragma unroll
-        for (int v = 0; v < 5; ++v) { const float4 x = s4[v]; sv[4 * v] = x.x; sv[4 * v + 1] = x.y; sv[4 * v + 2] = x.z; sv[4 * v + 3] = x.w; }
-    }
-#define SV(f) sv[(f) - 20]
-    f3 ts = mk(SV(F_TS), SV(F_TS + 1), SV(F_TS + 2)), te = mk(SV(F_TE), SV(F_TE + 1), SV(F_TE + 2));
-    float u0 = SV(F_U0), vbar = SV(F_VBAR), fzbar = SV(F_FZBAR), fzprev = SV(F_FZPREV), dfz = SV(F_DFZ);
-    float kst = SV(F_KST), kdmp = SV(F_KDMP), mu = SV(F_MU), epret = SV(F_EPRET);
-    int t = __float_as_int(SV(F_T)), touched = __float_as_int(SV(F_TOUCH)), episode = __float_as_int(SV(F_EPISODE)), status = __float_as_int(SV(F_STATUS));
-#undef SV
-    float s_pre[NE], sd_pre[NE];
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const int e = gl + i * G;
-        s_pre[i] = 0.f; sd_pre[i] = 0.f;
-        if (TORSO && MODE == 0 && ROLE != 1 && e < N_TOP) { s_pre[i] = LAT(LAT_S + e); sd_pre[i] = LAT(LAT_SD + e); }
-        if (TORSO && MODE == 0 && ROLE == 1 && e < N_TOP) s_pre[i] = LAT(LAT_S + e);      // the arm side runs the broad phase of the collision
-    }
     if (TORSO != 0 && item0 == item_first && first_pass) {
         // workgroup-resident copy of the lattice tables: 16-byte loads, all issued before the first LDS store (and behind the state loads
         // above, whose HBM latency the copy then covers)
@@ -470,6 +531,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
                 const float sdn = sd_pre[i] + dt * acc_e[i];
                 const float sn = s_pre[i] + dt * sdn;
                 if (valid) { LAT(LAT_SD + e) = sdn; LAT(LAT_S + e) = sn; }
+                if constexpr (RES) { sd_pre[i] = sdn; s_pre[i] = sn; EB(GE_S + e) = sn; }     // resident launch: the next step's state; positions for the arm side's broad phase
             }
         }
         RSTAMP(7);
@@ -922,6 +984,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
                 const float sdn = sd_pre[i] + dt * acc_e[i];
                 const float sn = s_pre[i] + dt * sdn;
                 if (valid) { LAT(LAT_SD + e) = sdn; LAT(LAT_S + e) = sn; }
+                if constexpr (RES) { sd_pre[i] = sdn; s_pre[i] = sn; }
             }
         }
 #pragma unroll
@@ -1079,7 +1142,20 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
             for (int a = 0; a < OBS_DIM; ++a) io.obs[(size_t)ei * OBS_DIM + a] = BK(sl, BOBS + a);
         }
         if (TORSO && valid) for (int e = gl; e < N_TOP; e += G) { LAT(LAT_S + e) = 0.f; LAT(LAT_SD + e) = 0.f; }
+        if constexpr (RES && TORSO != 0) {
+            // resident launch: the lattice of the new episode is at rest in the registers too (single wave) / in the LDS copy of the element
+            // positions this side reads back at the next step (split kernel; the lattice side learns of it through the mailbox below)
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                s_pre[i] = 0.f; sd_pre[i] = 0.f;
+                if (ROLE == 1 && gl + i * G < N_TOP) EB(GE_S + gl + i * G) = 0.f;
+            }
+        }
         if (store) { const int idx = atomicAdd(io.count, 1); io.items[idx] = make_int2(env, episode + BANK_DEPTH); }
+    }
+    if constexpr (RES && ROLE == 1) {
+        // (the wrench mailbox is free between hand-off (4) and the lattice side's next contact solve)
+        if (gl == 0) *reinterpret_cast<float4*>(&xl[MB_W]) = make_float4(kst, kdmp, mu, (MODE == 0 && need) ? 1.f : 0.f);
     }
     USIM_STAMP(dbg, 15);
 
@@ -1130,13 +1206,19 @@ DI void step16_body(float* lds, const DevModel& M, const DevCfg& C, float* __res
     const int nsub = (MULTI && MODE == 0 && io0.nsub > 1) ? io0.nsub : 1;
     DevIO io = io0;
     int nbar = 0;                                                        // barriers executed by this wave (read by the profiling build only)
+    Carry<TORSO ? (N_TOP + G - 1) / G : 1> cy;                           // multi-step launches: the state stays in registers between the steps
     for (int ks = 0; ks < nsub; ++ks) {
-        step16_one<TORSO, MODE, ROLE, NT, G>(lds, M, C, st, n, npad, io, flags, rstep + ks, ks == 0, nbar);
+        step16_one<TORSO, MODE, ROLE, NT, G, MULTI && MODE == 0>(lds, M, C, st, n, npad, io, flags, rstep + ks, ks == 0, nbar, cy);
         if (ks + 1 < nsub) {
-            // the next step reads the state words this one stored -- some through other lanes of the group, the per-episode scalars through the
-            // other wave of the pair (split kernel): order the stores, then meet.  (Both roles of the split kernel pass here once per step.)
+            // Split kernel: the next step reads words this one stored through the other wave of the pair (the lattice side of 16-lane groups
+            // reloads the per-episode scalars; the LDS blocks are reused): order the stores, then meet.  (Both roles pass here once per step.)
+            // A single-wave kernel keeps its state in registers and its LDS blocks to itself: its waves never meet after the table copy
+            // (lanes 16 kernel 17.05 -> 16.76 us/step, rigid torso 5.12 -> 5.03).
+            // Tried for the split kernel and dropped: hand-offs between the two waves of a pair only (LDS counters, s_sleep + s_wakeup) instead of
+            // workgroup barriers, so that a pair with few contacts runs ahead of its neighbours over the 64 steps of a launch -- 15.4 us/step
+            // against 14.8 with the barriers, whatever the sleep length (8192 envs, 8-lane groups: 23.4 against 22.7).
             __threadfence_block();
-            USIM_BAR();
+            if constexpr (ROLE != 0) USIM_BAR();
             if (io0.block) {
                 const size_t nn = (size_t)n;
                 io.obs += nn * OBS_DIM; io.rew += nn; io.done += nn;

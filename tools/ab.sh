@@ -1,0 +1,17 @@
+#!/bin/bash
+# A/B on one box: tools/ab.sh <libA.so> <libB.so> [...]  ->  gpurun_out/ab.txt   (paths relative to robotic-ultrasound-imaging_amd/lib)
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/ab.txt; : > "$OUT"
+run() { lib=$1; label=$2; shift 2; USIM_LIB=$ROOT/robotic-ultrasound-imaging_amd/lib/$lib python3 "$ROOT/bench.py" --no-cpu-baseline "$@" 2>/dev/null | tail -1 | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print('%-18s %-30s %8.1f M env-steps/s  %7.2f us/step  kernel %7.2f us' % ('$lib', '$label', d['value'] / 1e6, d['ms_per_step'] * 1e3, d['roofline']['avg_kernel_us']))" | tee -a "$OUT"; }
+for rep in 1 2; do
+for lib in "$@"; do
+run $lib "soft 4096"            --steps 2000 --warmup 100
+run $lib "config5 8192"         --steps 1000 --warmup 100 --envs-per-gpu 8192 --randomize
+[ -n "$QUICK" ] && continue
+run $lib "soft 4096 20/5"       --steps 20 --warmup 5
+run $lib "rigid 4096"           --steps 2000 --warmup 100 --workload rigid
+run $lib "soft 4096 lanes16"    --steps 2000 --warmup 100 --lanes-per-env 16
+done; done
