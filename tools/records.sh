@@ -1,0 +1,21 @@
+#!/bin/bash
+# Every record of profiles/<round>/ from ONE box and one gpurun call: tools/records.sh <round tag, e.g. r03>   (then tools/records_collect.sh <tag> here)
+TAG=${1:-r03}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+G=$ROOT/gpurun_out; mkdir -p "$G"
+cd "$ROOT"
+python3 -m pytest tests -m gpu -x -q 2>&1 | tail -3 > "$G/${TAG}_gputests.txt"
+tools/bench_matrix.sh > /dev/null
+python3 bench.py > "$G/${TAG}_bench_soft.json" 2> /dev/null
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$G/${TAG}_bench_driver.json" 2> /dev/null
+python3 bench.py --workload rigid --no-cpu-baseline > "$G/${TAG}_bench_rigid.json" 2> /dev/null
+python3 bench.py --envs-per-gpu 8192 --randomize --steps 1000 --warmup 100 --no-cpu-baseline > "$G/${TAG}_bench_config5.json" 2> /dev/null
+tools/profile.sh ${TAG}_soft > /dev/null 2>&1
+tools/profile.sh ${TAG}_rigid --workload rigid > /dev/null 2>&1
+tools/stats_only.sh ${TAG}_config5 --envs-per-gpu 8192 --randomize > /dev/null 2>&1
+tools/stats_only.sh ${TAG}_soft_spl1 --steps-per-launch 1 > /dev/null 2>&1
+python3 tools/split_timeline.py 200 4096 32 > "$G/${TAG}_timeline.txt" 2>&1
+USIM_PROFILE_NSUB=16 python3 tools/split_timeline.py 200 4096 32 > "$G/${TAG}_timeline_multi.txt" 2>&1
+USIM_PROFILE_NSUB=16 python3 tools/split_timeline.py 200 8192 64 > "$G/${TAG}_timeline_g8.txt" 2>&1
+python3 tests/gpu_parity_fullsize.py > "$G/${TAG}_parity_fullsize.txt" 2>&1
+cat "$G/${TAG}_gputests.txt" "$G/bench_matrix.txt"; tail -4 "$G/${TAG}_parity_fullsize.txt"
