@@ -274,6 +274,8 @@ typedef struct {
     real vbar, fzbar, fzprev, dfz;
     real kt_stiff, kt_damp, mu;                     /* per-env torso stiffness/damping, contact friction */
     int t, has_touched, episode;
+    int sub;                    /* physics substep of the running env.step() (0 .. substeps-1) */
+    real goal_pos[3], goal_rot[9];   /* 'fixed' mode: the goal set_goal() anchored at the policy step (first substep), held for the others */
     real ep_return;
     real s[N_TOP], sd[N_TOP];
     int ncon, con_el[USO_MAXC];
@@ -665,7 +667,7 @@ static real torso_dz(const Sim* S, int t, real* vz, real* az) {
     *vz = 0; *az = 0;
     const double TORSO_DROP = S->m.drop;
     if (!S->cfg.torso_drop) return (real)(-TORSO_DROP);
-    double tt = t * S->cfg.control_dt, z = -0.5 * GRAV * tt * tt;
+    double tt = t * (S->cfg.control_dt / (S->cfg.substeps > 1 ? S->cfg.substeps : 1)), z = -0.5 * GRAV * tt * tt;   /* t counts PHYSICS steps */
     if (z <= -TORSO_DROP) return (real)(-TORSO_DROP);
     *vz = (real)(-GRAV * tt); *az = (real)(-GRAV);
     return (real)z;
@@ -714,7 +716,8 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
     for (int i = 0; i < NJ; i++) qs[i] = tau[i] - k->bias[i] - (real)JOINT_DAMPING * E->qd[i];
     chol_solve(k->Lm, NJ, qs);
     int n = m->n_el;
-    real vz, az, dz = torso_dz(S, E->t > 0 ? E->t - 1 : 0, &vz, &az);   /* mj_step's forward runs at the pre-step time */
+    const int nsub_ = S->cfg.substeps > 1 ? S->cfg.substeps : 1;
+    real vz, az, dz = torso_dz(S, E->t > 0 ? (E->t - 1) * nsub_ + E->sub : 0, &vz, &az);   /* mj_step's forward runs at the pre-step time */
     if (n == 0) {
         memcpy(out->qacc, qs, sizeof qs);
     } else {
@@ -992,14 +995,18 @@ static void forward_pass(const Sim* S, const Env* E, const real* act, int zero_t
             /* robosuite OSC set_goal, impedance_mode "fixed", control_delta: goal = current pose + scaled delta */
             real d[6];
             for (int a = 0; a < 6; a++) { real v = act[a]; if (v > 1) v = 1; if (v < -1) v = -1; d[a] = v * (real)(a < 3 ? c->out_max_pos : c->out_max_ori); }
-            for (int a = 0; a < 3; a++) gpos[a] = P->k.x[a] + d[a];
-            real ang = (real)sqrt((double)(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]));
-            if (ang < (real)1e-12) memcpy(grot, P->k.Rs, sizeof grot);
-            else {
-                double h = 0.5 * (double)ang, sh = sin(h) / (double)ang;
-                double qq[4] = {cos(h), d[3] * sh, d[4] * sh, d[5] * sh};
-                real Re[9]; quat_wxyz_to_mat(Re, qq); m3mul(grot, Re, P->k.Rs);
-            }
+            if (E->sub == 0) {
+                /* SingleArm.control: `if policy_step: controller.set_goal(arm_action)` -- only the first physics substep anchors the goal */
+                for (int a = 0; a < 3; a++) gpos[a] = P->k.x[a] + d[a];
+                real ang = (real)sqrt((double)(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]));
+                if (ang < (real)1e-12) memcpy(grot, P->k.Rs, sizeof grot);
+                else {
+                    double h = 0.5 * (double)ang, sh = sin(h) / (double)ang;
+                    double qq[4] = {cos(h), d[3] * sh, d[4] * sh, d[5] * sh};
+                    real Re[9]; quat_wxyz_to_mat(Re, qq); m3mul(grot, Re, P->k.Rs);
+                }
+                memcpy(((Env*)E)->goal_pos, gpos, sizeof gpos); memcpy(((Env*)E)->goal_rot, grot, sizeof grot);
+            } else { memcpy(gpos, E->goal_pos, sizeof gpos); memcpy(grot, E->goal_rot, sizeof grot); }
             for (int a = 0; a < 6; a++) { kp[a] = (real)c->kp_fixed; kd[a] = (real)(2.0 * sqrt(c->kp_fixed) * c->damping_ratio); }
         } else {
             /* fork-only "tracking"/"variable_z" (SURVEY C.3): action -> kp in kp_limits, kd = 2 sqrt(kp), goal = trajectory */
@@ -1108,19 +1115,27 @@ static void step_env(Sim* S, int i, const double* act_d, double* obs, double* re
     Env* E = &S->env[i];
     const uso_config* c = &S->cfg;
     const Model* m = &S->m;
-    const real dt = (real)c->control_dt;
+    const int nsub = c->substeps > 1 ? c->substeps : 1;    /* MujocoEnv.step: range(int(control_timestep / model_timestep)) [RESTATED, SURVEY C.1] */
+    const real dt_ctrl = (real)c->control_dt, dt = (real)(c->control_dt / nsub);
     real act[8];
     for (int a = 0; a < S->adim; a++) { double v = act_d[a]; act[a] = (v == v && fabs(v) <= 3.0e38) ? (real)v : 0; }   /* non-finite action -> 0 */
     E->t += 1;                                             /* MujocoEnv.step: timestep += 1 [RESTATED, SURVEY C.1] */
-    Pass P; forward_pass(S, E, act, 0, &P);
-    /* mj_Euler with implicit joint damping [RESTATED]: qd += dt (M + dt D)^-1 M qacc ; q += dt qd */
-    real Md[NJ * NJ], rhs[NJ];
-    for (int a = 0; a < NJ; a++) { real s = 0; for (int b = 0; b < NJ; b++) s += P.k.M[a * NJ + b] * P.f.qacc[b]; rhs[a] = s; }
-    memcpy(Md, P.k.M, sizeof Md);
-    for (int a = 0; a < NJ; a++) Md[a * NJ + a] += dt * (real)JOINT_DAMPING;
-    chol(Md, NJ); chol_solve(Md, NJ, rhs);
-    for (int a = 0; a < NJ; a++) { E->qd[a] += dt * rhs[a]; E->dq[a] += dt * E->qd[a]; E->q[a] = E->q0[a] + E->dq[a]; }
-    for (int e = 0; e < m->n_el; e++) { E->sd[e] += dt * P.f.ael[e]; E->s[e] += dt * E->sd[e]; }
+    Pass P;
+    for (int sub = 0; sub < nsub; sub++) {
+        /* per physics substep: sim.forward(), controller torque from the current state (goal and gains of the policy step), sim.step() */
+        E->sub = sub;
+        forward_pass(S, E, act, 0, &P);
+        /* mj_Euler with implicit joint damping [RESTATED]: qd += dt (M + dt D)^-1 M qacc ; q += dt qd */
+        real Md[NJ * NJ], rhs[NJ];
+        for (int a = 0; a < NJ; a++) { real s = 0; for (int b = 0; b < NJ; b++) s += P.k.M[a * NJ + b] * P.f.qacc[b]; rhs[a] = s; }
+        memcpy(Md, P.k.M, sizeof Md);
+        for (int a = 0; a < NJ; a++) Md[a * NJ + a] += dt * (real)JOINT_DAMPING;
+        chol(Md, NJ); chol_solve(Md, NJ, rhs);
+        for (int a = 0; a < NJ; a++) { E->qd[a] += dt * rhs[a]; E->dq[a] += dt * E->qd[a]; E->q[a] = E->q0[a] + E->dq[a]; }
+        for (int e = 0; e < m->n_el; e++) { E->sd[e] += dt * P.f.ael[e]; E->s[e] += dt * E->sd[e]; }
+        if (P.f.overflow) E->status |= 1;
+    }
+    E->sub = 0;
     /* sensors read mj_step's data: kinematics/contacts from before the integration, qvel from after
      * (SURVEY C.4 "after mj_step, cfrc_ext/contacts describe the pre-integration state") */
     real hv[3], vs[6];
@@ -1154,7 +1169,7 @@ static void step_env(Sim* S, int i, const double* act_d, double* obs, double* re
     real hvn = v3norm(hv);
     E->vbar += (hvn - E->vbar) / (real)E->t;               /* :538 */
     real fz = P.f.fc[2];
-    E->dfz = (fz - E->fzprev) / dt;                        /* :542 */
+    E->dfz = (fz - E->fzprev) / dt_ctrl;                   /* :542 (self.control_timestep) */
     E->fzprev = fz;                                        /* :543 */
     E->fzbar = (real)FORCE_EMA_ALPHA * fz + (1 - (real)FORCE_EMA_ALPHA) * E->fzbar;   /* :546 */
     int cause = done ? 1 : 0;
@@ -1195,7 +1210,7 @@ void uso_default_config(uso_config* c) {
     c->mode = USO_MODE_TRACKING; c->torso = USO_TORSO_TOP; c->horizon = 1000; c->early_termination = 1;
     c->deterministic_trajectory = 0; c->torso_solref_randomization = 1; c->initial_probe_pos_randomization = 1;
     c->friction_randomization = 0; c->torso_drop = 1; c->pgs_iters = 4; c->ik_iters = 5; c->env_offset = 0; c->robot = 0;
-    c->seed = 3; c->control_dt = 0.002; c->kp_fixed = 300; c->damping_ratio = 1; c->kp_min = 0; c->kp_max = 500;
+    c->substeps = 1; c->seed = 3; c->control_dt = 0.002; c->kp_fixed = 300; c->damping_ratio = 1; c->kp_min = 0; c->kp_max = 500;
     c->out_max_pos = 0.05; c->out_max_ori = 0.5; c->stiffness = 1324.17; c->damping = 17.59;
     c->elem_friction = 0.01; c->probe_friction = 1e-4;
     c->probe_radius = PROBE_RADIUS; c->probe_halflen = PROBE_HALFLEN; c->probe_radius2 = PROBE_RADIUS2; c->probe_height = PROBE_HEIGHT; c->torso_shape = 0;

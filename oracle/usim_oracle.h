@@ -62,6 +62,9 @@ typedef struct uso_config {
     double probe_friction;        /* ultrasound_probe_gripper.xml:8 (1e-4) */
     double probe_radius, probe_halflen;   /* stand-in for the missing probe mesh (.MISSING_LARGE_BLOBS:1): tip radius, half-length */
     double probe_radius2, probe_height;   /* ... radius of the upper edge of the flared blade and its height above the tip axis */
+    int32_t substeps;             /* physics steps per env.step(): int(control_timestep / model_timestep) of robosuite MujocoEnv.step [RESTATED, SURVEY C.1];
+                                   * control_dt is the CONTROL timestep (ultrasound.py:542), the physics step is control_dt / substeps (0 or 1: one) */
+    int32_t reserved_;
 } uso_config;
 
 void  uso_default_config(uso_config* c);

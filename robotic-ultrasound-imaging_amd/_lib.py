@@ -29,7 +29,8 @@ class UsimConfig(C.Structure):
         "lanes_per_env", "torso_shape", "waves_per_simd", "robot")] + \
         [("seed", C.c_uint64)] + [(n, C.c_double) for n in (
             "control_dt", "kp_fixed", "damping_ratio", "kp_min", "kp_max", "out_max_pos", "out_max_ori", "stiffness", "damping",
-            "elem_friction", "probe_friction", "probe_radius", "probe_halflen", "probe_radius2", "probe_height")]
+            "elem_friction", "probe_friction", "probe_radius", "probe_halflen", "probe_radius2", "probe_height")] + \
+        [("substeps", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class UsimStepIO(C.Structure):

@@ -4,6 +4,8 @@ import ctypes as C
 
 from . import _lib
 
+MODEL_TIMESTEP = 0.002       # robosuite macros.SIMULATION_TIMESTEP [RESTATED]: the MuJoCo step of every robosuite environment
+
 # kwargs of the reference env that only concern rendering / bookkeeping and have no effect on step()/reset()
 _IGNORED = {
     "env_id", "env_configuration", "use_camera_obs", "has_renderer", "has_offscreen_renderer", "render_camera",
@@ -78,10 +80,16 @@ def make_config(seed=3, env_offset=0, **kw):
     omax = [omax] * 6 if not isinstance(omax, (list, tuple)) else list(omax)
     c.out_max_pos, c.out_max_ori = float(omax[0]), float(omax[3])
     control_freq = float(kw.pop("control_freq", 500))
-    if abs(control_freq - 500.0) > 1e-9:
-        # robosuite runs control_timestep / model_timestep (2 ms) physics substeps per env.step(); only the shipped setting
-        # (rl_config.yaml:26, main.py: control_freq 500 = one substep) is implemented
-        raise ValueError("only control_freq=500 (one 2 ms physics substep per control step) is implemented")
+    # robosuite MujocoEnv: control_timestep = 1 / control_freq, model_timestep = 2 ms (macros.SIMULATION_TIMESTEP); env.step() runs
+    # int(control_timestep / model_timestep) physics substeps [RESTATED, SURVEY C.1].  The shipped setting (rl_config.yaml:26, main.py:45,92) is 500 =
+    # one substep; the env's own default is 20 (ultrasound.py:119) = 25 substeps.
+    if control_freq <= 0 or control_freq > 500.0 + 1e-9:
+        raise ValueError("control_freq must lie in (0, 500]: the model timestep is 2 ms")
+    substeps = int((1.0 / control_freq) / MODEL_TIMESTEP + 1e-9)
+    if abs(substeps * MODEL_TIMESTEP * control_freq - 1.0) > 1e-6:
+        # (robosuite would silently run a control step of substeps * 2 ms while differentiating the force over 1 / control_freq)
+        raise ValueError("1 / control_freq must be a whole number of 2 ms model timesteps (control_freq 500, 250, 125, 100, 50, 25, 20, 10 ...)")
+    c.substeps = substeps
     c.control_dt = 1.0 / control_freq
     c.horizon = int(kw.pop("horizon", 1000))
     c.early_termination = int(bool(kw.pop("early_termination", False)))

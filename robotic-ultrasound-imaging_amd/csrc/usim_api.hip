@@ -228,7 +228,7 @@ static hipError_t launch_step(usim_handle* h, const DevIO& io, int flags, long l
 template <int TORSO, int OCC, int MODE>
 static hipError_t launch_step16(usim_handle* h, const DevIO& io, int flags, long long rstep, hipStream_t s) {
     dim3 grid((h->n + 15) / 16), block(256);
-    if (MODE == 0 && io.nsub > 1) hipLaunchKernelGGL((usim_step16_kernel<TORSO, OCC, MODE, MODE == 0>), grid, block, h->lds16_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
+    if (MODE == 0 && (io.nsub > 1 || h->C.substeps > 1)) hipLaunchKernelGGL((usim_step16_kernel<TORSO, OCC, MODE, MODE == 0>), grid, block, h->lds16_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
     else hipLaunchKernelGGL((usim_step16_kernel<TORSO, OCC, MODE, false>), grid, block, h->lds16_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
     return hipGetLastError();
 }
@@ -242,12 +242,12 @@ static int launch(usim_handle* h, DevIO io, int flags, long long rstep, hipStrea
     if (h->lpe == 64 && MODE == 0) {
         // split kernel with 8-lane groups: 32 environments per workgroup
         dim3 grid((h->n + 31) / 32), block(512);
-        if (io.nsub > 1) hipLaunchKernelGGL((usim_step32_kernel<true, 8>), grid, block, h->lds64_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
+        if (io.nsub > 1 || h->C.substeps > 1) hipLaunchKernelGGL((usim_step32_kernel<true, 8>), grid, block, h->lds64_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
         else hipLaunchKernelGGL((usim_step32_kernel<false, 8>), grid, block, h->lds64_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
         e = hipGetLastError();
     } else if (h->lpe == 32 && MODE == 0) {
         dim3 grid((h->n + 15) / 16), block(512);
-        if (io.nsub > 1) hipLaunchKernelGGL((usim_step32_kernel<true, 16>), grid, block, h->lds32_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
+        if (io.nsub > 1 || h->C.substeps > 1) hipLaunchKernelGGL((usim_step32_kernel<true, 16>), grid, block, h->lds32_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
         else hipLaunchKernelGGL((usim_step32_kernel<false, 16>), grid, block, h->lds32_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
         e = hipGetLastError();
     } else if (h->lpe == 16 || h->lpe == 32 || h->lpe == 64) {
@@ -270,7 +270,7 @@ int usim_default_config(usim_config* c) {
     c->mode = USIM_MODE_TRACKING; c->torso = USIM_TORSO_TOP; c->horizon = 1000; c->early_termination = 1;
     c->deterministic_trajectory = 0; c->torso_solref_randomization = 1; c->initial_probe_pos_randomization = 1;
     c->friction_randomization = 0; c->torso_drop = 1; c->pgs_iters = 4; c->ik_iters = 5; c->env_offset = 0; c->lanes_per_env = 0; c->torso_shape = 0; c->waves_per_simd = 0; c->robot = 0; c->seed = 3;
-    c->control_dt = 0.002; c->kp_fixed = 300; c->damping_ratio = 1; c->kp_min = 0; c->kp_max = 500; c->out_max_pos = 0.05; c->out_max_ori = 0.5;
+    c->control_dt = 0.002; c->substeps = 1; c->kp_fixed = 300; c->damping_ratio = 1; c->kp_min = 0; c->kp_max = 500; c->out_max_pos = 0.05; c->out_max_ori = 0.5;
     c->stiffness = 1324.17; c->damping = 17.59; c->elem_friction = 0.01; c->probe_friction = 1e-4; c->probe_radius = 0.012; c->probe_halflen = 0.03;
     c->probe_radius2 = 0.05; c->probe_height = 0.047; c->struct_size = (int32_t)sizeof(usim_config);
     return USIM_OK;
@@ -298,7 +298,8 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
     C.rand_solref = cfg->torso_solref_randomization; C.rand_pos = cfg->initial_probe_pos_randomization; C.rand_fric = cfg->friction_randomization;
     C.torso_drop = cfg->torso_drop; C.pgs_iters = cfg->pgs_iters; C.ik_iters = cfg->ik_iters; C.env_offset = cfg->env_offset; C.adim = h->adim;
     C.key0 = (uint32_t)cfg->seed; C.key1 = (uint32_t)(cfg->seed >> 32);
-    C.dt = (float)cfg->control_dt; C.kp_fixed = (float)cfg->kp_fixed; C.damping_ratio = (float)cfg->damping_ratio; C.kp_min = (float)cfg->kp_min;
+    C.substeps = cfg->substeps > 1 ? cfg->substeps : 1;
+    C.dt_ctrl = (float)cfg->control_dt; C.dt = (float)(cfg->control_dt / C.substeps); C.kp_fixed = (float)cfg->kp_fixed; C.damping_ratio = (float)cfg->damping_ratio; C.kp_min = (float)cfg->kp_min;
     C.kp_max = (float)cfg->kp_max; C.out_pos = (float)cfg->out_max_pos; C.out_ori = (float)cfg->out_max_ori; C.stiffness = (float)cfg->stiffness;
     C.damping = (float)cfg->damping; C.elem_fric = (float)cfg->elem_friction; C.probe_fric = (float)cfg->probe_friction;
     C.probe_r = (float)cfg->probe_radius; C.probe_hl = (float)cfg->probe_halflen;
@@ -335,6 +336,12 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
     if (h->n_el ? (h->lpe != 8 && h->lpe != 16 && h->lpe != 32 && h->lpe != 64) : (h->lpe != 1 && h->lpe != 16)) return USIM_ERR_INVALID;
     if (cfg->robot != USIM_ROBOT_PANDA && h->lpe != 16 && h->lpe != 32 && h->lpe != 64) {
         h->hip_err = "the UR5e runs on the table-driven 16-lane kernels only (lanes_per_env 0 or 16)";
+        return USIM_ERR_UNSUPPORTED;
+    }
+    if (C.substeps > 1 && ((h->lpe != 16 && h->lpe != 32 && h->lpe != 64) || cfg->mode == USIM_MODE_FIXED)) {
+        // several physics substeps per control step run inside the multi-step kernels; in `fixed` mode the goal anchored at the policy step would have
+        // to be held across the substeps (no state words for it): main.py, the one caller of that mode, uses control_freq 500
+        h->hip_err = "substeps > 1 (control_freq below 500) needs the 16-lane kernels (lanes_per_env 0, 16, 32, 64) and an impedance_mode other than 'fixed'";
         return USIM_ERR_UNSUPPORTED;
     }
     h->occ = cfg->waves_per_simd ? cfg->waves_per_simd : (n_envs <= 4096 ? 1 : 2);

@@ -293,7 +293,7 @@ static_assert((arm_lds_base<1, 1, 8>() + ARM_LDS_WORDS) * 4 <= 160 * 1024 && arm
 
 template <int TORSO, int MODE, int ROLE, int NT, int G = 16, bool RES = false>
 DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __restrict__ st, const int n, const int npad, const DevIO& io, const int flags, const long long rstep,
-                   const bool first_pass, int& nbar, Carry<TORSO ? (N_TOP + G - 1) / G : 1>& cy) {
+                   const bool first_pass, const int sub, int& nbar, Carry<TORSO ? (N_TOP + G - 1) / G : 1>& cy) {
     constexpr int EPW = 64 / G, EPB = 4 * EPW;                          // environments per wave / per workgroup (four waves per role)
     static_assert(!RES || MODE == 0, "resident state: step launches only");
     constexpr int X2_BASE = x2_base<G>(), X2_STRIDE = x2_stride<G>(), MB_Q = mb_q<G>(), MB_POSE = mb_pose<G>(), MB_OP = mb_op<G>(), MB_W = mb_w<G>(), MB_CA = mb_ca<G>();
@@ -420,7 +420,13 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
     }
     USIM_STAMP(dbg, 1);
 
-    if constexpr (MODE == 0) t += 1;                                     // MujocoEnv.step: timestep += 1
+    // robosuite MujocoEnv.step [RESTATED, SURVEY C.1]: timestep += 1 once, then int(control_timestep / model_timestep) physics substeps (controller
+    // torque from the current state with the policy step's goal and gains, mj_step), then _post_action once.  `sub` is the substep of this pass
+    // (multi-step kernels only; C.substeps = 1 with the shipped control_freq 500): every pass integrates and stores the state, the last one of a
+    // control step evaluates reward / bookkeeping / termination and writes the transition.
+    if (MODE == 0 && sub == 0) t += 1;
+    const bool last_sub = sub == C.substeps - 1;
+    const int tphys = (MODE == 0) ? (t - 1) * C.substeps + sub : 0;     // physics steps since the episode began (prescribed torso drop)
     const float dt = C.dt, inv_h = rcp_((float)C.horizon);
 #if defined(USIM_TSTAMP) || defined(USIM_TSTAMP_NOWAIT)
 #define RSTAMP(k) do { if (dbg && blockIdx.x == 0 && (threadIdx.x & 255) == 0) dbg[(ROLE == 2 ? 30 : 20) + (k)] = __builtin_readcyclecounter(); } while (0)
@@ -432,7 +438,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         RSTAMP(0);
         float* const mb = &lds[X2_BASE + eb * X2_STRIDE];
         const int* tb_shell = reinterpret_cast<const int*>(lds + TB_SHELL);
-        const int tsim = t - 1;
+        const int tsim = tphys;
         float dz, vz, az;
         torso_motion(C, tsim, dz, vz, az);
         lattice_front<G, NE, true, 1>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, true, s_pre, sd_pre, mk(0, 0, 0), mk(0, 0, 0), mk(0, 0, 0), dbg);
@@ -636,7 +642,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
             // broad phase of the collision (collide_cull): element ids that can touch the probe, ascending, into the queue; element positions
             // into the environment's LDS block for whoever evaluates them
             float dz_, vz_, az_;
-            torso_motion(C, t - 1, dz_, vz_, az_);
+            torso_motion(C, tphys, dz_, vz_, az_);
             const f3 sxc = cross(sy, sz);
             int nq = 0;
 #pragma unroll
@@ -903,7 +909,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         {
             // the arm side's share of the narrow phase: the first part of the queue against the site pose it computed itself
             float dz_, vz_, az_;
-            torso_motion(C, t - 1, dz_, vz_, az_);
+            torso_motion(C, tphys, dz_, vz_, az_);
             const f3 sxc = cross(sy, sz);
             const int nq = __float_as_int(xl[MB_POSE + 10]), na = (nq * arm_share_num<G>() + ARM_SHARE_DEN - 1) / ARM_SHARE_DEN;
             int nca = 0;
@@ -932,7 +938,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         for (int k = 0; k < MAXC; ++k) con_shell[k] = __float_as_int(xl[MB_W + 8 + k]);
     } else if constexpr (TORSO != 0) {
         const int* tb_shell = reinterpret_cast<const int*>(lds + TB_SHELL);
-        const int tsim = (t > 0) ? t - 1 : 0;
+        const int tsim = tphys;
         float dz, vz, az;
         torso_motion(C, tsim, dz, vz, az);
         int nc = lattice_front<G, NE, true>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, MODE == 0, s_pre, sd_pre, xs, sy, sz, dbg);
@@ -1060,7 +1066,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
 #pragma unroll
                 for (int a = 0; a < OBS_DIM; ++a) io.obs[(size_t)ei * OBS_DIM + a] = obs[a];
             }
-        } else {
+        } else if (last_sub) {
         const bool contact = ncon > 0;
         if (contact) touched = 1;
         const float force_rew = contact ? force_e : 0.f, dforce_rew = contact ? dforce_e : 0.f;
@@ -1069,7 +1075,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         const float hvn = sqrt_(dot(hv, hv));
         vbar += (hvn - vbar) * rcp_((float)t);
         const float fz = W[2];
-        dfz = (fz - fzprev) * rcp_(dt);
+        dfz = (fz - fzprev) * rcp_(C.dt_ctrl);                             // ultrasound.py:542: self.control_timestep
         fzprev = fz;
         fzbar = 0.1f * fz + 0.9f * fzbar;
         // joint-limit margin and run-away guard are per-joint quantities: one ballot / one prefix sum over the group
@@ -1203,12 +1209,18 @@ template <int TORSO, int MODE, int ROLE, int NT, bool MULTI = false, int G = 16>
 DI void step16_body(float* lds, const DevModel& M, const DevCfg& C, float* __restrict__ st, const int n, const int npad, const DevIO& io0, const int flags, const long long rstep) {
     // (MULTI is a template parameter: the single-step instantiation -- usim_step, a policy in the loop -- keeps the register allocation of a
     // straight-line kernel; the loop costs it 2 us per step)
-    const int nsub = (MULTI && MODE == 0 && io0.nsub > 1) ? io0.nsub : 1;
+    // io0.nsub counts CONTROL steps; each is C.substeps physics passes (1 with the shipped control_freq)
+    const int S = (MULTI && MODE == 0 && C.substeps > 1) ? C.substeps : 1;
+    const int nsub = (MULTI && MODE == 0) ? (io0.nsub > 1 ? io0.nsub : 1) * S : 1;
     DevIO io = io0;
     int nbar = 0;                                                        // barriers executed by this wave (read by the profiling build only)
     Carry<TORSO ? (N_TOP + G - 1) / G : 1> cy;                           // multi-step launches: the state stays in registers between the steps
+    int sub = 0;
+    long long cstep = rstep;                                             // control step: keys the in-kernel action draw
     for (int ks = 0; ks < nsub; ++ks) {
-        step16_one<TORSO, MODE, ROLE, NT, G, MULTI && MODE == 0>(lds, M, C, st, n, npad, io, flags, rstep + ks, ks == 0, nbar, cy);
+        step16_one<TORSO, MODE, ROLE, NT, G, MULTI && MODE == 0>(lds, M, C, st, n, npad, io, flags, cstep, ks == 0, sub, nbar, cy);
+        const bool ctrl_done = sub == S - 1;                             // this pass completed a control step
+        if (ctrl_done) { sub = 0; ++cstep; } else ++sub;
         if (ks + 1 < nsub) {
             // Split kernel: the next step reads words this one stored through the other wave of the pair (the lattice side of 16-lane groups
             // reloads the per-episode scalars; the LDS blocks are reused): order the stores, then meet.  (Both roles pass here once per step.)
@@ -1219,7 +1231,7 @@ DI void step16_body(float* lds, const DevModel& M, const DevCfg& C, float* __res
             // against 14.8 with the barriers, whatever the sleep length (8192 envs, 8-lane groups: 23.4 against 22.7).
             __threadfence_block();
             if constexpr (ROLE != 0) USIM_BAR();
-            if (io0.block) {
+            if (io0.block && ctrl_done) {
                 const size_t nn = (size_t)n;
                 io.obs += nn * OBS_DIM; io.rew += nn; io.done += nn;
                 if (io.term_obs) io.term_obs += nn * OBS_DIM;

@@ -27,7 +27,8 @@ class OracleConfig(C.Structure):
         "initial_probe_pos_randomization", "friction_randomization", "torso_drop", "pgs_iters", "ik_iters", "env_offset", "torso_shape", "robot")] + \
         [("seed", C.c_uint64)] + [(n, C.c_double) for n in (
             "control_dt", "kp_fixed", "damping_ratio", "kp_min", "kp_max", "out_max_pos", "out_max_ori", "stiffness",
-            "damping", "elem_friction", "probe_friction", "probe_radius", "probe_halflen", "probe_radius2", "probe_height")]
+            "damping", "elem_friction", "probe_friction", "probe_radius", "probe_halflen", "probe_radius2", "probe_height")] + \
+        [("substeps", C.c_int32), ("reserved_", C.c_int32)]
 
 
 def build_oracle(native=False):

@@ -20,13 +20,14 @@ MARGIN = {"contact": 5e-6,   # m     : |capsule distance| below which the contac
           "joint": 1e-4}     # rad
 
 
-def _mk(usim, n, torso, mode, seed=3, omp=False, robot="Panda", precision="f64", gpu_extra=None, **extra):
+def _mk(usim, n, torso, mode, seed=3, omp=False, robot="Panda", precision="f64", gpu_extra=None, ora_extra=None, **extra):
     kw = usim.default_robosuite_kwargs()
     kw["controller_configs"] = dict(kw["controller_configs"], impedance_mode=mode)
     kw["robots"] = robot
     kw.update(extra)                                   # options that exist on both sides under the same name
-    env = usim.UltrasoundVecEnv(n, device="cuda:0", seed=seed, torso=torso, **kw, **(gpu_extra or {}))      # gpu_extra: kernel mapping etc.
-    ora = Oracle(n, precision=precision, omp=omp, mode=mode, torso="top" if torso == "soft" else "none", seed=seed, robot=robot, **extra)
+    kw.update(gpu_extra or {})                         # gpu_extra: kernel mapping, robosuite options the oracle spells differently (control_freq)
+    env = usim.UltrasoundVecEnv(n, device="cuda:0", seed=seed, torso=torso, **kw)
+    ora = Oracle(n, precision=precision, omp=omp, mode=mode, torso="top" if torso == "soft" else "none", seed=seed, robot=robot, **extra, **(ora_extra or {}))
     return env, ora
 
 
@@ -154,6 +155,16 @@ def test_ur5e_parity_200_steps(usim, torso, mode):
     """the second robot of ultrasound.py:137 (six joints; the seventh joint lane carries a locked padding joint): same kernels, another
     arm table; same bar against the oracle's generic body tree"""
     _run_parity(usim, 256, 200, torso, mode, robot="UR5e")
+
+
+@pytest.mark.parametrize("torso,mode,freq", [("soft", "tracking", 100), ("soft", "variable_z", 125), ("rigid", "wrench", 50), ("soft", "tracking", 20)])
+def test_control_freq_below_500_runs_physics_substeps(usim, torso, mode, freq):
+    """control_freq below 500 (the env's own default is 20, ultrasound.py:119): robosuite MujocoEnv.step runs int(control_timestep / 2 ms) physics
+    substeps per env.step() -- controller torque from the current state with the policy step's goal and gains, mj_step -- and _post_action
+    once, with the force derivative over the CONTROL timestep (ultrasound.py:542).  Same bars as the single-substep runs; 200+ physics steps"""
+    sub = 500 // freq
+    steps = max(200 // sub, 16)
+    _run_parity(usim, 67, steps, torso, mode, gpu_extra=dict(control_freq=freq), ora_extra=dict(substeps=sub, control_dt=1.0 / freq))
 
 
 def test_full_size_parity_4096_envs(usim):

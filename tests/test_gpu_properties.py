@@ -63,6 +63,48 @@ def test_rollout_random_equals_explicit_actions(usim):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("torso", ["rigid", "soft"])
+def test_substeps_are_the_same_physics_as_single_steps(usim, torso):
+    """control_freq 100 = five 2 ms physics substeps per env.step().  In the open-loop `wrench` mode nothing in the physics depends on the control-step
+    counter, so q, qd and the lattice after k steps at 100 Hz are, bit for bit, those after 5 k steps at 500 Hz with every action held for five
+    steps; the bookkeeping differs as the reference's does (t counts control steps, dF/dt is taken over 10 ms).  Also: every kernel mapping
+    computes the same bits with substeps, and a multi-step rollout equals stepping one control step at a time."""
+    cc = dict(usim.default_robosuite_kwargs()["controller_configs"], impedance_mode="wrench")
+    slow, fast = _env(usim, 300, torso, controller_configs=cc, control_freq=100, early_termination=False), _env(usim, 300, torso, controller_configs=cc, early_termination=False)
+    slow.reset_tensor(); fast.reset_tensor()
+    for k in range(30):
+        act = slow.random_actions_tensor(k).clone()
+        slow.step_tensor(act)
+        for _ in range(5):
+            fast.step_tensor(act)
+    a, b = slow.get_state(), fast.get_state()
+    for key in ("q", "qd", "s", "sd"):
+        assert np.array_equal(a[key], b[key]), key
+    assert np.array_equal(a["t"], np.full(300, 30)) and np.array_equal(b["t"], np.full(300, 150))
+    slow.close(); fast.close()
+    if torso == "soft":
+        kw = dict(control_freq=125, early_termination=True)
+        envs = [_env(usim, 500, lanes_per_env=32, **kw), _env(usim, 500, lanes_per_env=16, **kw), _env(usim, 500, lanes_per_env=64, **kw)]
+        for e in envs:
+            e.reset_tensor()
+        blk = [e.alloc_block(40) for e in envs]
+        envs[0].rollout_random(0, 40, blk[0]); envs[2].rollout_random(0, 40, blk[2])
+        for k in range(40):                                                  # one control step (four substeps) per launch
+            act = envs[1].random_actions_tensor(k)
+            obs, rew, done = envs[1].step_tensor(act)
+            blk[1]["obs"][k], blk[1]["rew"][k], blk[1]["done"][k] = obs, rew, done
+        torch.cuda.synchronize()
+        for key in ("obs", "rew", "done"):
+            assert torch.equal(blk[0][key], blk[1][key]) and torch.equal(blk[0][key], blk[2][key]), key
+        assert int(blk[0]["done"].sum()) > 20                                # episodes ended and restarted from the bank on the way
+        for e in envs:
+            e.close()
+    with pytest.raises(RuntimeError):                                        # `fixed` mode would have to hold its goal across the substeps
+        _env(usim, 8, torso, controller_configs=dict(cc, impedance_mode="fixed"), control_freq=100)
+    with pytest.raises(RuntimeError):                                        # the round-1 kernels have no substep loop
+        _env(usim, 8, torso, control_freq=100, lanes_per_env=8 if torso == "soft" else 1)
+
+
 def test_state_roundtrip_checkpoint(usim):
     a, b = _env(usim, 300), _env(usim, 300)
     a.reset_tensor(); b.reset_tensor()

@@ -82,8 +82,13 @@ def test_config_rejects_what_the_reference_rejects(usim):
         usim.make_config(**{**kw, "controller_configs": {**kw["controller_configs"], "impedance_mode": "variable"}})
     with pytest.raises(TypeError):
         usim.make_config(**{**kw, "no_such_option": 1})
-    with pytest.raises(ValueError):
-        usim.make_config(**{**kw, "control_freq": 20})             # would need 25 physics substeps per step (ultrasound.py:119 default)
+    # control_freq below 500: physics substeps per control step (robosuite MujocoEnv.step); the env's own default 20 (ultrasound.py:119) = 25 of them
+    c20 = usim.make_config(**{**kw, "control_freq": 20})
+    assert c20.substeps == 25 and c20.control_dt == pytest.approx(0.05)
+    assert usim.make_config(**{**kw, "control_freq": 500}).substeps == 1 and usim.make_config(**kw).substeps == 1
+    for bad in (600, 300, 0):                                      # above the 2 ms model step / not a whole number of model steps
+        with pytest.raises(ValueError, match="control_freq"):
+            usim.make_config(**{**kw, "control_freq": bad})
     assert usim.make_config(**{**kw, "use_box_torso": False}).torso_shape == 1 and usim.make_config(**kw).torso_shape == 0
     fixed = usim.make_config(**{**kw, "controller_configs": {**kw["controller_configs"], "impedance_mode": "fixed"}})
     assert fixed.mode == 1 and fixed.kp_fixed == 300.0
