@@ -158,6 +158,14 @@ int usim_random_actions(usim_handle* h, int64_t step, float* act_dev, void* stre
  * slice k (SB3 RolloutBuffer layout, the unit that is all-gathered across GPUs). */
 int usim_rollout_random(usim_handle* h, int64_t first_step, int nsteps, const usim_step_io* io, int block_advance, void* stream);
 
+/* Refill the reset bank now (the launch usim_step issues by itself every 64 steps: the initial states of the episodes that will reuse the ring slots
+ * consumed since the last refill) and restart the 64-step period.  For callers that record a FIXED sequence of steps once and replay it -- a HIP
+ * graph captured around T x usim_step (policy.GraphedCollector): the period counter lives on the host and does not advance at replay, so such a
+ * sequence starts and ends with this call (every ring is then valid at every replay, whatever T).  Capture-safe: on a stream that is being captured
+ * the library records kernel launches only (no events, no synchronising call).  Nothing in the reference corresponds to it (a reset there
+ * recompiles the model, ultrasound.py:416-478). */
+int usim_refill_bank(usim_handle* h, void* stream);
+
 /* usim_rollout_random enqueues its steps in launches of up to `steps` consecutive steps each (1 .. 64, default 64; the 16- and 32-lane
  * mappings -- the others always launch step by step): inside a launch the lattice tables stay in LDS and launch latency is paid once, every
  * step still reads and writes its state and its slice of the rollout block in HBM.  The results do not depend on the value (bit for bit). */

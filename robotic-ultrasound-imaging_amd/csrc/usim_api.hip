@@ -421,6 +421,10 @@ static void refill_collect(usim_handle* h, int slot) {
 static int bank_refill(usim_handle* h, hipStream_t s) {
     DevIO b{}; b.items = h->d_items; b.count = h->d_count; b.refill = 1;
     h->steps_since_refill = 0;
+    // a stream that is being captured into a graph (policy.GraphedCollector: the whole rollout loop as one hipGraph) takes the launch only: no
+    // event bookkeeping, no synchronising call
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (s && hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return launch<1>(h, b, 0, 0, s);
     const int slot = h->rf_next;
     h->rf_next = (slot + 1) % usim_handle::RF_RING;
     refill_collect(h, slot);                          // (a pair that is reused was recorded RF_RING refills = 512 steps ago: long finished)
@@ -487,6 +491,12 @@ int usim_step(usim_handle* h, const usim_step_io* s, int auto_reset, void* strea
     DevIO io; int rc = fill_io(s, io, true);
     if (rc) return rc;
     return step_common(h, io, auto_reset ? LF_AUTO_RESET : 0, 0, stream);
+}
+
+int usim_refill_bank(usim_handle* h, void* stream) {
+    if (!h) return USIM_ERR_INVALID;
+    DeviceGuard guard(h->device);
+    return bank_refill(h, (hipStream_t)stream);
 }
 
 int usim_random_actions(usim_handle* h, int64_t step, float* act_dev, void* stream) {

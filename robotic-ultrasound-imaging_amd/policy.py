@@ -151,25 +151,30 @@ class DeviceVecNormalize:
 
     def __init__(self, num_envs, obs_dim=19, device="cuda:0", clip_obs=10.0, clip_reward=10.0, gamma=0.99, epsilon=1e-8, training=True, norm_reward=True):
         dev = torch.device(device)
+        # every statistic is a tensor that is updated IN PLACE (the sample counts too): a captured graph of the rollout loop (GraphedCollector)
+        # then reads and writes the same addresses at every replay
         self.obs_mean = torch.zeros(obs_dim, dtype=torch.float64, device=dev)
         self.obs_var = torch.ones(obs_dim, dtype=torch.float64, device=dev)
-        self.obs_count = 1e-4
+        self._obs_count = torch.full((), 1e-4, dtype=torch.float64, device=dev)
         self.ret_mean = torch.zeros((), dtype=torch.float64, device=dev)
         self.ret_var = torch.ones((), dtype=torch.float64, device=dev)
-        self.ret_count = 1e-4
+        self._ret_count = torch.full((), 1e-4, dtype=torch.float64, device=dev)
         self.returns = torch.zeros(num_envs, dtype=torch.float64, device=dev)
         self.clip_obs, self.clip_reward, self.gamma, self.epsilon = clip_obs, clip_reward, gamma, epsilon
         self.training, self.norm_reward = training, norm_reward
 
+    obs_count = property(lambda self: float(self._obs_count))          # (a host read: synchronises)
+    ret_count = property(lambda self: float(self._ret_count))
+
     @classmethod
     def from_stats(cls, stats, num_envs, device="cuda:0", training=False, norm_reward=False):
         self = cls(num_envs, len(stats["obs_mean"]), device, stats["clip_obs"], stats["clip_reward"], stats["gamma"], stats["epsilon"], training, norm_reward)
-        self.obs_mean = torch.as_tensor(stats["obs_mean"], dtype=torch.float64, device=self.obs_mean.device)
-        self.obs_var = torch.as_tensor(stats["obs_var"], dtype=torch.float64, device=self.obs_mean.device)
-        self.obs_count = stats["count"]
-        self.ret_mean = torch.as_tensor(stats["ret_mean"], dtype=torch.float64, device=self.obs_mean.device)
-        self.ret_var = torch.as_tensor(stats["ret_var"], dtype=torch.float64, device=self.obs_mean.device)
-        self.ret_count = stats.get("ret_count", stats["count"])
+        self.obs_mean.copy_(torch.as_tensor(stats["obs_mean"], dtype=torch.float64))
+        self.obs_var.copy_(torch.as_tensor(stats["obs_var"], dtype=torch.float64))
+        self._obs_count.fill_(float(stats["count"]))
+        self.ret_mean.fill_(float(stats["ret_mean"]))
+        self.ret_var.fill_(float(stats["ret_var"]))
+        self._ret_count.fill_(float(stats.get("ret_count", stats["count"])))
         return self
 
     def stats(self):
@@ -180,24 +185,25 @@ class DeviceVecNormalize:
 
     @staticmethod
     def _update(mean, var, count, batch):
+        """RunningMeanStd.update_from_moments (parallel-variance update), in place on the three tensors"""
         b = batch.to(torch.float64)
         bm, bv, bn = b.mean(0), b.var(0, unbiased=False), b.shape[0]
         delta, tot = bm - mean, count + bn
         new_mean = mean + delta * bn / tot
         m2 = var * count + bv * bn + delta * delta * count * bn / tot
-        return new_mean, m2 / tot, tot
+        mean.copy_(new_mean); var.copy_(m2 / tot); count.copy_(tot)
 
     def normalize_obs(self, obs):
         if self.training:
-            self.obs_mean, self.obs_var, self.obs_count = self._update(self.obs_mean, self.obs_var, self.obs_count, obs)
+            self._update(self.obs_mean, self.obs_var, self._obs_count, obs)
         out = (obs.to(torch.float64) - self.obs_mean) / torch.sqrt(self.obs_var + self.epsilon)
         return torch.clamp(out, -self.clip_obs, self.clip_obs).to(torch.float32)
 
     def normalize_reward(self, rew, done):
         if self.training:
-            self.returns = self.returns * self.gamma + rew.to(torch.float64)
-            self.ret_mean, self.ret_var, self.ret_count = self._update(self.ret_mean, self.ret_var, self.ret_count, self.returns)
-            self.returns = torch.where(done.bool(), torch.zeros_like(self.returns), self.returns)
+            self.returns.mul_(self.gamma).add_(rew.to(torch.float64))
+            self._update(self.ret_mean, self.ret_var, self._ret_count, self.returns)
+            self.returns.masked_fill_(done.bool(), 0.0)
         if not self.norm_reward:
             return rew
         return torch.clamp(rew.to(torch.float64) / torch.sqrt(self.ret_var + self.epsilon), -self.clip_reward, self.clip_reward).to(torch.float32)
@@ -388,3 +394,86 @@ def collect_rollouts(env, policy, vecnorm, buffer, obs=None, episode_start=None,
         vecnorm.training = was_training
     buffer.compute_returns_and_advantage(last_value, done.bool())
     return obs, episode_start
+
+
+class GraphedCollector:
+    """collect_rollouts recorded once as a HIP graph (torch.cuda.CUDAGraph) and replayed with one launch per rollout.
+
+    With a policy in the loop a rollout step is ~40 small launches -- observation statistics and normalisation, two MLPs, sampling, clipping, the
+    simulator step, return statistics, six buffer writes -- and the simulator kernel is 15 us of it: issued one by one from Python the loop is bound
+    by launch overhead (~0.4 ms per step at 2048 environments).  The loop has no host dependency (the simulator resets finished environments on
+    the device, the running statistics are tensors updated in place), so the T steps of a rollout, the bootstrap value and the GAE recursion are
+    captured into one graph; `collect()` replays it.  Semantics are those of collect_rollouts (same operations in the same order on the same
+    tensors): `tests/test_gpu_policy_replay.py` compares the two bit for bit.
+
+    The simulator's reset bank is refilled every 64 steps by a launch that usim_step issues from a HOST counter, which does not advance at replay:
+    the recorded sequence therefore starts and ends with an explicit refill (env.refill_bank) and contains the periodic ones in between, so every
+    ring is valid at every replay for any T.  Sampling uses the default CUDA generator (graph-safe: the Philox offset advances per replay) or a
+    generator registered with the graph.  The policy's parameters are read at their addresses: an optimiser that updates them in place (torch.optim)
+    is seen by the next replay."""
+
+    def __init__(self, env, policy, vecnorm, buffer, generator=None, warmup_steps=2):
+        self.env, self.policy, self.vecnorm, self.buffer, self.generator = env, policy, vecnorm, buffer, generator
+        dev = env.device
+        self._low, self._high = torch.as_tensor(env.action_space.low, device=dev), torch.as_tensor(env.action_space.high, device=dev)
+        self.obs = env.reset_tensor().clone()                                   # raw observation the next rollout starts from
+        self.episode_start = torch.ones(env.num_envs, dtype=torch.bool, device=dev)
+        self.last_done = torch.zeros(env.num_envs, dtype=torch.bool, device=dev)
+        self.raw_reward_sum = torch.zeros((), dtype=torch.float64, device=dev)  # sum of the raw rewards of the last rollout (diagnostics)
+        self.graph = torch.cuda.CUDAGraph()
+        if generator is not None:
+            self.graph.register_generator_state(generator)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            # library handles, lazy initialisation and the allocator's warm-up happen outside the capture: a few eager steps on the side stream.
+            # They are real steps (the statistics and the environments advance), exactly like the first steps of an eager collect_rollouts.
+            obs, start = self.obs, self.episode_start
+            for _ in range(warmup_steps):
+                obs, start, _ = self._step(obs, start, None)
+            self.obs.copy_(obs); self.episode_start.copy_(start)
+            env.refill_bank()
+            torch.cuda.current_stream(dev).synchronize()
+            with torch.cuda.graph(self.graph, stream=side):
+                self._record()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        buffer.pos, buffer.full = buffer.buffer_size, True
+
+    @torch.no_grad()
+    def _step(self, obs, episode_start, t):
+        vn, env = self.vecnorm, self.env
+        nobs = vn.normalize_obs(obs)
+        act, value, logp = self.policy.sample(nobs, self.generator)
+        o, rew, done = env.step_tensor(torch.max(torch.min(act, self._high), self._low))
+        if t is not None:
+            self.raw_reward_sum.add_(rew.sum())
+        nrew = vn.normalize_reward(rew, done)
+        if t is not None:
+            b = self.buffer
+            b.observations[t].copy_(nobs); b.actions[t].copy_(act); b.rewards[t].copy_(nrew)
+            b.episode_starts[t].copy_(episode_start.to(torch.float32)); b.values[t].copy_(value); b.log_probs[t].copy_(logp)
+        return o.clone(), done.bool().clone(), done
+
+    @torch.no_grad()
+    def _record(self):
+        vn, b = self.vecnorm, self.buffer
+        obs, start = self.obs, self.episode_start
+        self.raw_reward_sum.zero_()
+        done = None
+        for t in range(b.buffer_size):
+            obs, start, done = self._step(obs, start, t)
+        was_training, vn.training = vn.training, False
+        try:
+            _, last_value = self.policy.forward(vn.normalize_obs(obs))
+        finally:
+            vn.training = was_training
+        self.last_done.copy_(done.bool())
+        b.compute_returns_and_advantage(last_value, self.last_done)
+        self.obs.copy_(obs); self.episode_start.copy_(start)
+        self.env.refill_bank()
+
+    def collect(self):
+        """one rollout of buffer.buffer_size steps into the buffer (returns / advantages included); returns (next raw obs, next episode_start)"""
+        self.graph.replay()
+        self.buffer.pos, self.buffer.full = self.buffer.buffer_size, True
+        return self.obs, self.episode_start

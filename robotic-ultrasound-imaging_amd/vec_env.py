@@ -153,6 +153,10 @@ class UltrasoundVecEnv:
         self._check(self.lib.usim_refill_time(self._handle, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
 
+    def refill_bank(self):
+        """refill the reset bank now and restart its 64-step period (include/usim.h usim_refill_bank; capture-safe)"""
+        self._check(self.lib.usim_refill_bank(self._handle, self._stream()))
+
     def set_steps_per_launch(self, steps):
         """rollout_random / time_steps: consecutive steps per kernel launch (1 .. 64, default 64; include/usim.h usim_set_steps_per_launch)"""
         self._check(self.lib.usim_set_steps_per_launch(self._handle, int(steps)))
