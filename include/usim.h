@@ -195,6 +195,53 @@ int usim_set_state(usim_handle* h, const float* scalars, const float* lattice);
  * returns USIM_ERR_UNSUPPORTED. */
 int usim_profile_step(usim_handle* h, const usim_step_io* io, int64_t step, uint64_t* ticks, int max_ticks);
 
+/* ---- the caller's side of env.step() on the device: SB3 VecNormalize + MlpPolicy forward + sampling + rollout-buffer
+ * writes + GAE, fused into a few kernels per rollout step (csrc/usim_policy.hip).  Everything is a device pointer into the CALLER's tensors
+ * (torch parameters, policy.DeviceVecNormalize statistics, policy.DeviceRolloutBuffer slices); the library keeps no copy. ---- */
+typedef struct usim_policy_net {               /* stable_baselines3 ActorCriticPolicy("MlpPolicy", net_arch pi=[256,128] vf=[256,128], tanh) of the shipped
+                                                * checkpoints (src/rl.py:143; trained_rl_models/.zip policy.pth); torch.nn.Linear layout weight[out][in] */
+    const float *pi_w1, *pi_b1, *pi_w2, *pi_b2;        /* mlp_extractor.policy_net: [256][19], [256], [128][256], [128] */
+    const float *act_w, *act_b;                        /* action_net: [A][128], [A] */
+    const float *vf_w1, *vf_b1, *vf_w2, *vf_b2;        /* mlp_extractor.value_net */
+    const float *val_w, *val_b;                        /* value_net: [1][128], [1] */
+    const float* log_std;                              /* [A] */
+} usim_policy_net;
+
+typedef struct usim_norm_stats {               /* stable_baselines3 VecNormalize (src/rl.py:140,177-184): RunningMeanStd of observations and of discounted returns */
+    double *obs_mean, *obs_var, *obs_count;            /* [19], [19], scalar -- updated in place when training */
+    double *ret_mean, *ret_var, *ret_count;            /* scalars */
+    double* returns;                                   /* [n] discounted return accumulators */
+    double* scratch;                                   /* USIM_POLICY_SCRATCH doubles of workspace, zero-initialised by the caller once (required when training) */
+    double clip_obs, clip_reward, gamma, epsilon;      /* 10, 10, 0.99, 1e-8 in the shipped pickles */
+} usim_norm_stats;
+
+#define USIM_POLICY_SCRATCH 1280               /* 32 x 19 x 2 partial sums + an arrival counter */
+
+typedef struct usim_policy_out {
+    float* act_env_dev;        /* [n][A] REQUIRED: the sampled action clipped to the action box = the `action` argument of the following usim_step */
+    float* nobs_dev;           /* [n][19] normalised observation            -> RolloutBuffer.observations[t]   (may be NULL, like the rest) */
+    float* act_dev;            /* [n][A]  unclipped sample                  -> RolloutBuffer.actions[t] */
+    float* value_dev;          /* [n]     value_net output                  -> RolloutBuffer.values[t] */
+    float* logp_dev;           /* [n]     log-probability of the sample     -> RolloutBuffer.log_probs[t] */
+    float* episode_start_dev;  /* [n]     1.0 where the previous step ended an episode -> RolloutBuffer.episode_starts[t] */
+} usim_policy_out;
+
+/* VecNormalize.normalize_obs (+ RunningMeanStd.update when training) -> ActorCriticPolicy.forward -> sample -> clip, for the n environments whose raw
+ * observations are obs_dev [n][19].  prev_done_dev [n]: done flags of the previous step (NULL: every environment starts an episode).  The Gaussian
+ * noise comes from a counter-based stream keyed (seed, env_offset + env, counter + *counter_base_dev): a new value per call -- counter from the host,
+ * counter_base_dev (may be NULL) a device word that a recorded sequence of calls (HIP graph) advances between replays.  deterministic != 0: the
+ * mean action. */
+int usim_policy_step(const usim_policy_net* net, const usim_norm_stats* st, const float* obs_dev, const uint8_t* prev_done_dev, int n, int act_dim,
+                     const float* act_low_dev, const float* act_high_dev, uint64_t seed, uint32_t counter, const uint32_t* counter_base_dev, int env_offset,
+                     int training, int deterministic, const usim_policy_out* out, void* stream);
+/* VecNormalize's reward side after the env step: returns = gamma returns + rew, RunningMeanStd.update(returns), nrew = clip(rew / sqrt(ret_var + eps)),
+ * returns reset where done.  raw_sum_dev (may be NULL): += sum of the raw rewards. */
+int usim_policy_reward(const usim_norm_stats* st, const float* rew_dev, const uint8_t* done_dev, int n, int training, int norm_reward, float* nrew_dev,
+                       double* raw_sum_dev, void* stream);
+/* RolloutBuffer.compute_returns_and_advantage over [T][n] buffers (GAE(lambda), SB3's recursion) */
+int usim_policy_gae(const float* rewards_dev, const float* values_dev, const float* episode_starts_dev, const float* last_values_dev, const uint8_t* last_done_dev,
+                    int T, int n, float gamma, float gae_lambda, float* advantages_dev, float* returns_dev, void* stream);
+
 const char* usim_strerror(int status);
 const char* usim_last_hip_error(const usim_handle* h);
 const char* usim_version(void);

@@ -40,8 +40,29 @@ class UsimStepIO(C.Structure):
         "act_out_dev", "status_dev", "log_dev")]
 
 
+class UsimPolicyNet(C.Structure):
+    """struct usim_policy_net (include/usim.h): device pointers to the MlpPolicy parameters"""
+    _fields_ = [(n, C.c_void_p) for n in ("pi_w1", "pi_b1", "pi_w2", "pi_b2", "act_w", "act_b", "vf_w1", "vf_b1", "vf_w2", "vf_b2", "val_w", "val_b", "log_std")]
+
+
+class UsimNormStats(C.Structure):
+    """struct usim_norm_stats (include/usim.h): device pointers to the VecNormalize statistics + its four constants"""
+    _fields_ = [(n, C.c_void_p) for n in ("obs_mean", "obs_var", "obs_count", "ret_mean", "ret_var", "ret_count", "returns", "scratch")] + \
+               [(n, C.c_double) for n in ("clip_obs", "clip_reward", "gamma", "epsilon")]
+
+
+class UsimPolicyOut(C.Structure):
+    """struct usim_policy_out (include/usim.h)"""
+    _fields_ = [(n, C.c_void_p) for n in ("act_env_dev", "nobs_dev", "act_dev", "value_dev", "logp_dev", "episode_start_dev")]
+
+
 # every exported symbol of include/usim.h: name -> (restype, argtypes)
 SYMBOLS = {
+    "usim_policy_step": (C.c_int, [C.POINTER(UsimPolicyNet), C.POINTER(UsimNormStats), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_uint64, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(UsimPolicyOut), C.c_void_p]),
+    "usim_policy_reward": (C.c_int, [C.POINTER(UsimNormStats), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "usim_policy_gae": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
     "usim_default_config": (C.c_int, [C.POINTER(UsimConfig)]),
     "usim_create": (C.c_int, [C.POINTER(UsimConfig), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "usim_destroy": (None, [C.c_void_p]),

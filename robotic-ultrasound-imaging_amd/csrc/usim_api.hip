@@ -649,3 +649,5 @@ const char* usim_last_hip_error(const usim_handle* h) { return h ? h->hip_err.c_
 const char* usim_version(void) { return "usim 0.3 (gfx950) src " USIM_SRC_HASH; }
 
 }  // extern "C"
+
+#include "usim_policy.hip"

@@ -1,0 +1,354 @@
+// usim_policy.hip -- the CALLER's side of env.step() on the device: SB3's VecNormalize + MlpPolicy forward + action sampling + rollout-buffer
+// writes + GAE as four kernels per rollout step (src/rl.py:140 VecNormalize, :143 PPO("MlpPolicy"), :157 / :177-184
+// checkpoints).  Included by usim_api.hip (single translation unit).
+//
+// Why: with a policy in the loop a rollout step in PyTorch is ~100 launches of a few microseconds (float64 running statistics, two 3-layer MLPs,
+// sampling, clipping, buffer copies) around a 15 us simulator kernel -- 300 us per step even when replayed as a graph.  Here:
+//   usim_policy_obs_stats   RunningMeanStd.update on the observation batch (float64 batch moments, parallel-variance merge), one workgroup per channel
+//   usim_policy_act         normalise + clip the observation, both MLPs on the matrix cores (v_mfma_f32_16x16x4_f32, fp32 in / fp32 accumulate),
+//                           Gaussian sample from a counter-based stream, log-probability, clip to the action box; writes the rollout-buffer
+//                           slices (normalised observation, unclipped action, value, log-prob, episode start) and the env's action
+//   [usim_step]
+//   usim_policy_reward      discounted-return statistics (RunningMeanStd on the returns), reward normalisation + clip, buffer write
+//   usim_policy_gae         RolloutBuffer.compute_returns_and_advantage, one thread per environment, once per rollout
+// The weights are read from the caller's tensors (torch parameters: an optimiser step is seen by the next call); nothing is copied.
+// Numerics: same formulas as policy.DeviceVecNormalize / MlpActorCritic; sums are ordered differently from PyTorch's kernels, so results agree to
+// rounding (tests/test_gpu_policy_replay.py: 1e-5 on means / values / log-probs, 1e-12 relative on the float64 statistics), not bit for bit.
+#pragma once
+
+namespace usim {
+
+constexpr int PL_OBS = 19, PL_KPAD = 20, PL_H1 = 256, PL_H2 = 128, PL_TM = 32;          // MlpPolicy of the shipped checkpoints: 19 -> 256 -> 128 -> A / 1
+constexpr int PL_H1S = PL_H1 + 4, PL_H2S = PL_H2 + 4;                                    // LDS row strides (260, 132: 16-byte aligned, off the 32-bank period)
+
+struct PolicyNet {                                       // torch.nn.Linear layouts: weight [out][in], bias [out]
+    const float *pi_w1, *pi_b1, *pi_w2, *pi_b2, *act_w, *act_b;      // policy_net (19 -> 256 -> 128, tanh), action_net (128 -> A)
+    const float *vf_w1, *vf_b1, *vf_w2, *vf_b2, *val_w, *val_b;      // value_net_body, value_net (128 -> 1)
+    const float* log_std;                                             // [A]
+};
+struct NormStats {                                       // policy.DeviceVecNormalize: float64 tensors, updated in place
+    double *obs_mean, *obs_var, *obs_count;              // [19], [19], scalar
+    double *ret_mean, *ret_var, *ret_count, *returns;    // scalars, [n]
+    double clip_obs, clip_reward, gamma, epsilon;
+};
+
+DI double block_sum(double v, double* red) {
+    // sum over the workgroup (any size that is a multiple of 64): wave reduction by DPP-free shuffles, then the wave sums through LDS
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+
+// RunningMeanStd.update(obs).  PL_SB workgroups read their slice of the [n][19] batch once, coalesced (thread t takes words t, t + 128, ...: the
+// channel of a word is its index mod 19, and since 128 * 19 words form a block, slot j of a thread always holds channel (first + t + 128 j) mod 19 --
+// nineteen slots, nineteen different channels), and leave per-channel partial sums (sum x, sum x^2 in float64) in `part`.  The workgroup that
+// finishes last adds the partials in a fixed order -- the result does not depend on which one that is -- and merges the batch moments into the
+// running statistics (parallel-variance update of RunningMeanStd.update_from_moments).
+constexpr int PL_SB = 32, PL_ST = 128;                           // workgroups, threads per workgroup
+__global__ __launch_bounds__(PL_ST) void usim_policy_obs_stats_kernel(const float* __restrict__ obs, int n, NormStats S, double* __restrict__ part,
+                                                                      unsigned int* __restrict__ arrived) {
+    __shared__ double tabx[PL_OBS][PL_ST], tabq[PL_OBS][PL_ST];
+    __shared__ bool last;
+    const int t = threadIdx.x, total = n * PL_OBS;
+    const int per = ((total + PL_SB - 1) / PL_SB + PL_OBS - 1) / PL_OBS * PL_OBS;      // a multiple of 19: every slice starts at channel 0
+    const int lo = blockIdx.x * per, hi = min(total, lo + per);
+    double sx[PL_OBS], sq[PL_OBS];
+#pragma unroll
+    for (int j = 0; j < PL_OBS; ++j) { sx[j] = 0.0; sq[j] = 0.0; }
+    for (int b = lo; b < hi; b += PL_ST * PL_OBS) {
+#pragma unroll
+        for (int j = 0; j < PL_OBS; ++j) {
+            const int w = b + t + PL_ST * j;
+            const double x = (w < hi) ? (double)obs[w] : 0.0;
+            sx[j] += x; sq[j] += x * x;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PL_OBS; ++j) { const int ch = (t + PL_ST * j) % PL_OBS; tabx[ch][t] = sx[j]; tabq[ch][t] = sq[j]; }
+    __syncthreads();
+    if (t < PL_OBS * 4) {                                          // four lanes per channel, 32 table entries each, combined in a fixed order
+        const int c = t >> 2, seg = t & 3;
+        double a = 0.0, b = 0.0;
+#pragma unroll 8
+        for (int k = seg * (PL_ST / 4); k < (seg + 1) * (PL_ST / 4); ++k) { a += tabx[c][k]; b += tabq[c][k]; }
+        a += __shfl_xor(a, 1); b += __shfl_xor(b, 1); a += __shfl_xor(a, 2); b += __shfl_xor(b, 2);
+        if (seg == 0) { part[(blockIdx.x * PL_OBS + c) * 2] = a; part[(blockIdx.x * PL_OBS + c) * 2 + 1] = b; }
+    }
+    __threadfence();
+    __syncthreads();
+    if (t == 0) last = atomicAdd(arrived, 1u) == (unsigned)(PL_SB - 1);
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (t < PL_OBS) {
+        double2 pp[PL_SB];                                        // all loads first (independent), then the sums in a fixed order
+#pragma unroll
+        for (int k = 0; k < PL_SB; ++k) pp[k] = *reinterpret_cast<const double2*>(&part[(k * PL_OBS + t) * 2]);
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int k = 0; k < PL_SB; ++k) { a += pp[k].x; b += pp[k].y; }
+        const double bm = a / n, bv = fmax(b / n - bm * bm, 0.0);
+        const double cnt = *S.obs_count, tot = cnt + n, delta = bm - S.obs_mean[t];
+        const double m2 = S.obs_var[t] * cnt + bv * n + delta * delta * cnt * n / tot;
+        S.obs_mean[t] += delta * n / tot; S.obs_var[t] = m2 / tot;
+    }
+    __syncthreads();
+    if (t == 0) { *S.obs_count += n; *arrived = 0u; }
+}
+
+typedef float v4f_ __attribute__((ext_vector_type(4)));
+// tanh(x) = 1 - 2 / (exp(2x) + 1): v_exp_f32 + v_rcp_f32 (absolute error ~1e-7; saturates to +-1 through exp -> inf / 0), a tenth of the library routine
+DI float tanh_(float x) { const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f); return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f); }
+
+// One workgroup = 32 environments through ONE of the two networks (blockIdx.y: 0 policy, 1 value): 256 workgroups at 4096 environments.
+// Measured at 4096 environments (rocprofv3, by early exits): weight prefetch + observation normalisation 5.0 us, layer 1 +1.5, layer 2 +7.2, heads
+// + sampling +2.7 = 16 us -- of which the 9.5 k matrix-core cycles of a wave are 4 us; replacing the layer-2 instructions by plain multiply-adds,
+// halving the weight traffic (32 rows x one network instead of 16 rows x both: 78 -> 39 MB of L2 reads), rotating the order in which the
+// workgroups walk the weights, prefetching them into registers at the top: none of them moved the total -- what is left is the per-CU rate at
+// which a wave's 16-row x 64-byte operand reads go through the texture cache.
+// Matrix-core layout (v_mfma_f32_16x16x4_f32): lane l supplies A[row l % 16][k l / 16] and B[k l / 16][col l % 16], receives
+// D[row 4 (l / 16) + r][col l % 16] in accumulator register r.  The k order inside a group of 16 is free as long as A and B agree: group g = l / 16
+// takes k = 16 s + 4 g + j in the j-th of four instructions, so that both operands are 16-byte reads.
+__global__ __launch_bounds__(256) void usim_policy_act_kernel(PolicyNet P, NormStats S, const float* __restrict__ obs,
+                                                              const uint8_t* __restrict__ prev_done, int n, int adim, const float* __restrict__ act_low,
+                                                              const float* __restrict__ act_high, uint32_t key0, uint32_t key1, uint32_t ctr0, const uint32_t* __restrict__ ctr_base, int env_offset,
+                                                              int deterministic, float* __restrict__ nobs_out, float* __restrict__ act_out,
+                                                              float* __restrict__ act_env, float* __restrict__ value_out, float* __restrict__ logp_out,
+                                                              float* __restrict__ start_out) {
+    __shared__ __attribute__((aligned(16))) float xs[PL_TM][PL_KPAD];
+    __shared__ __attribute__((aligned(16))) float h1[PL_TM][PL_H1S];
+    __shared__ __attribute__((aligned(16))) float h2[PL_TM][PL_H2S];
+    __shared__ __attribute__((aligned(16))) float w1s[PL_H1 * PL_OBS];        // layer-1 weights [256][19] of this workgroup's network
+    __shared__ __attribute__((aligned(16))) float whs[8 * PL_H2];             // head weights: action_net [A][128] or value_net [1][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, net = blockIdx.y, row0 = blockIdx.x * PL_TM;
+    const int lr = lane & 15, lg = lane >> 4;
+    const uint32_t ctr = ctr0 + (ctr_base ? *ctr_base : 0u);                  // call counter: host part + a device word (a recorded graph advances the latter)
+    // ---- every weight read is issued up front: this lane's layer-2 operands into registers (2 column tiles x 256 k = 32 x 16 bytes; they are
+    //      consumed two barriers later, so their L2 latency is covered by the normalisation and layer 1), layer-1 and head weights into LDS with
+    //      coalesced loads ----
+    const int c0 = (wave * 2) * 16 + lr, c1 = c0 + 16;
+    float4 wb0[PL_H1 / 16], wb1[PL_H1 / 16];
+    {
+        const float* W2 = net ? P.vf_w2 : P.pi_w2;
+#pragma unroll
+        for (int s = 0; s < PL_H1 / 16; ++s) {
+            const int k = 16 * s + 4 * lg;
+            wb0[s] = *reinterpret_cast<const float4*>(&W2[c0 * PL_H1 + k]);
+            wb1[s] = *reinterpret_cast<const float4*>(&W2[c1 * PL_H1 + k]);
+        }
+        const float4* W1 = reinterpret_cast<const float4*>(net ? P.vf_w1 : P.pi_w1);
+#pragma unroll
+        for (int i = 0; i < (PL_H1 * PL_OBS / 4 + 255) / 256; ++i) { const int v = tid + 256 * i; if (v < PL_H1 * PL_OBS / 4) reinterpret_cast<float4*>(w1s)[v] = W1[v]; }
+        const int nh = (net ? 1 : adim) * PL_H2 / 4;
+        const float4* WH = reinterpret_cast<const float4*>(net ? P.val_w : P.act_w);
+        if (tid < nh) reinterpret_cast<float4*>(whs)[tid] = WH[tid];
+    }
+    // ---- VecNormalize.normalize_obs: clip((obs - mean) / sqrt(var + eps)) in float64, stored as float32 ----
+    for (int t = tid; t < PL_TM * PL_KPAD; t += 256) {
+        const int r = t / PL_KPAD, c = t - r * PL_KPAD, env = row0 + r;
+        float v = 0.f;
+        if (c < PL_OBS && env < n) {
+            double x = ((double)obs[(size_t)env * PL_OBS + c] - S.obs_mean[c]) / sqrt(S.obs_var[c] + S.epsilon);
+            x = x < -S.clip_obs ? -S.clip_obs : (x > S.clip_obs ? S.clip_obs : x);
+            v = (float)x;
+            if (nobs_out && net == 0) nobs_out[(size_t)env * PL_OBS + c] = v;
+        }
+        xs[r][c] = v;
+    }
+    __syncthreads();
+    // ---- layer 1 (19 -> 256, tanh): wave w owns column tiles 4 w .. 4 w + 3, both row tiles ----
+    {
+        const float* W = w1s;
+        const float* B = net ? P.vf_b1 : P.pi_b1;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int col = (wave * 4 + tt) * 16 + lr;
+            v4f_ acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < PL_KPAD / 4; ++s) {
+                const int k = 4 * s + lg;
+                const float b = (k < PL_OBS) ? W[col * PL_OBS + k] : 0.f;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[lr][k], b, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[16 + lr][k], b, acc1, 0, 0, 0);
+            }
+            const float bias = B[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { h1[4 * lg + r][col] = tanh_(acc0[r] + bias); h1[16 + 4 * lg + r][col] = tanh_(acc1[r] + bias); }
+        }
+    }
+    __syncthreads();
+    // ---- layer 2 (256 -> 128, tanh): wave w owns column tiles 2 w, 2 w + 1 for both row tiles; 16 k values per pass (one 16-byte read per operand,
+    //      four instructions per accumulator): a weight word read once serves 32 environments ----
+    {
+        const float* B = net ? P.vf_b2 : P.pi_b2;
+        v4f_ a00 = {0.f, 0.f, 0.f, 0.f}, a01 = {0.f, 0.f, 0.f, 0.f}, a10 = {0.f, 0.f, 0.f, 0.f}, a11 = {0.f, 0.f, 0.f, 0.f};     // [row tile][column tile]
+#pragma unroll
+        for (int s = 0; s < PL_H1 / 16; ++s) {
+            const int k = 16 * s + 4 * lg;
+            const float4 x0 = *reinterpret_cast<const float4*>(&h1[lr][k]), x1 = *reinterpret_cast<const float4*>(&h1[16 + lr][k]);
+            const float4 b0 = wb0[s], b1 = wb1[s];
+#define USIM_MM4(ACC, X, BB) ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(X.x, BB.x, ACC, 0, 0, 0); ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(X.y, BB.y, ACC, 0, 0, 0); \
+                             ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(X.z, BB.z, ACC, 0, 0, 0); ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(X.w, BB.w, ACC, 0, 0, 0);
+            USIM_MM4(a00, x0, b0) USIM_MM4(a01, x0, b1) USIM_MM4(a10, x1, b0) USIM_MM4(a11, x1, b1)
+#undef USIM_MM4
+        }
+        const float bias0 = B[c0], bias1 = B[c1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            h2[4 * lg + r][c0] = tanh_(a00[r] + bias0); h2[4 * lg + r][c1] = tanh_(a01[r] + bias1);
+            h2[16 + 4 * lg + r][c0] = tanh_(a10[r] + bias0); h2[16 + 4 * lg + r][c1] = tanh_(a11[r] + bias1);
+        }
+    }
+    __syncthreads();
+    // ---- head: eight lanes per environment.  Policy network: lane o < A forms the mean of action component o (128 -> A), then sampling and the
+    //      log-probability; value network: the eight lanes split the 128 -> 1 dot product ----
+    const int r = tid >> 3, o = tid & 7, env = row0 + r;
+    if (net == 0) {
+        const bool is_act = o < adim;
+        const float* Wr = whs + (is_act ? o : 0) * PL_H2;
+        float acc = 0.f, bcc = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < PL_H2; k += 4) {
+            const float4 h = *reinterpret_cast<const float4*>(&h2[r][k]);
+            const float4 w = *reinterpret_cast<const float4*>(&Wr[k]);
+            acc = fmaf(h.x, w.x, acc); bcc = fmaf(h.y, w.y, bcc); acc = fmaf(h.z, w.z, acc); bcc = fmaf(h.w, w.w, bcc);
+        }
+        const float mean = acc + bcc + P.act_b[is_act ? o : 0];
+        // N(0, 1) for (environment, component): Box-Muller on one Philox block per pair of components
+        float noise = 0.f;
+        if (!deterministic && is_act) {
+            const u4 rr = philox((uint32_t)(env_offset + env), ctr, (uint32_t)(o >> 1), 0x504f4c59u, key0, key1);
+            const float u1 = ((float)(rr.a >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(rr.b >> 8) * (1.0f / 16777216.0f);
+            const float rad = sqrtf(-2.f * logf(u1)), ang = 2.f * PI_F * u2;
+            noise = (o & 1) ? rad * sinf(ang) : rad * cosf(ang);
+        }
+        const float ls = is_act ? P.log_std[o] : 0.f;
+        const float a = mean + expf(ls) * noise;
+        // DiagGaussianDistribution.log_prob of the sample: sum over the components (the eight lanes of this environment)
+        float lp = is_act ? (-0.5f * noise * noise - ls - 0.9189385332046727f) : 0.f;
+        lp += __shfl_xor(lp, 1); lp += __shfl_xor(lp, 2); lp += __shfl_xor(lp, 4);
+        if (env < n) {
+            if (is_act) {
+                if (act_out) act_out[(size_t)env * adim + o] = a;
+                act_env[(size_t)env * adim + o] = fminf(fmaxf(a, act_low[o]), act_high[o]);
+            }
+            if (o == 0) {
+                if (logp_out) logp_out[env] = lp;
+                if (start_out) start_out[env] = prev_done ? (prev_done[env] ? 1.f : 0.f) : 1.f;
+            }
+        }
+    } else {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 16 * o; k < 16 * o + 16; k += 4) {
+            const float4 h = *reinterpret_cast<const float4*>(&h2[r][k]);
+            const float4 w = *reinterpret_cast<const float4*>(&whs[k]);
+            acc = fmaf(h.x, w.x, acc); acc = fmaf(h.y, w.y, acc); acc = fmaf(h.z, w.z, acc); acc = fmaf(h.w, w.w, acc);
+        }
+        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+        if (env < n && o == 0 && value_out) value_out[env] = acc + P.val_b[0];
+    }
+}
+
+// VecNormalize.step_wait after the env step: returns = gamma returns + reward; RunningMeanStd.update(returns); normalised, clipped reward; returns
+// reset where an episode ended.  One workgroup, one pass over the batch (sum r, sum r^2, sum of the raw rewards reduced together).
+__global__ __launch_bounds__(1024) void usim_policy_reward_kernel(const float* __restrict__ rew, const uint8_t* __restrict__ done, int n, NormStats S, int training,
+                                                                  int norm_reward, float* __restrict__ nrew_out, double* __restrict__ raw_sum) {
+    __shared__ double red[3][16];
+    __shared__ double scale;
+    double raw = 0.0, s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double rw = (double)rew[i];
+        raw += rw;
+        if (training) { const double r = S.returns[i] * S.gamma + rw; s += r; q += r * r; S.returns[i] = done[i] ? 0.0 : r; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { raw += __shfl_xor(raw, o); s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = raw; red[1][threadIdx.x >> 6] = s; red[2][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0, c = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { a += red[0][i]; b += red[1][i]; c += red[2][i]; }
+        if (raw_sum) *raw_sum += a;
+        if (training) {
+            const double bm = b / n, bv = fmax(c / n - bm * bm, 0.0);
+            const double cnt = *S.ret_count, tot = cnt + n, delta = bm - *S.ret_mean;
+            const double m2 = *S.ret_var * cnt + bv * n + delta * delta * cnt * n / tot;
+            *S.ret_mean += delta * n / tot; *S.ret_var = m2 / tot; *S.ret_count = tot;
+        }
+        scale = 1.0 / sqrt(*S.ret_var + S.epsilon);
+    }
+    __syncthreads();
+    const double sc = scale;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double v = (double)rew[i];
+        if (norm_reward) { v *= sc; v = v < -S.clip_reward ? -S.clip_reward : (v > S.clip_reward ? S.clip_reward : v); }
+        nrew_out[i] = (float)v;
+    }
+}
+
+// RolloutBuffer.compute_returns_and_advantage: one thread per environment walks its column of the [T][n] buffers backwards
+__global__ void usim_policy_gae_kernel(const float* __restrict__ rewards, const float* __restrict__ values, const float* __restrict__ starts,
+                                       const float* __restrict__ last_values, const uint8_t* __restrict__ last_done, int T, int n, float gamma, float lam,
+                                       float* __restrict__ adv, float* __restrict__ ret) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float gae = 0.f, next_v = last_values[i], next_nt = 1.f - (last_done[i] ? 1.f : 0.f);
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t ix = (size_t)t * n + i;
+        const float v = values[ix];
+        const float delta = rewards[ix] + gamma * next_v * next_nt - v;
+        gae = delta + gamma * lam * next_nt * gae;
+        adv[ix] = gae; ret[ix] = gae + v;
+        next_v = v; next_nt = 1.f - starts[ix];
+    }
+}
+
+}  // namespace usim
+
+extern "C" {
+
+int usim_policy_step(const usim_policy_net* net, const usim_norm_stats* st, const float* obs_dev, const uint8_t* prev_done_dev, int n, int act_dim,
+                     const float* act_low_dev, const float* act_high_dev, uint64_t seed, uint32_t counter, const uint32_t* counter_base_dev, int env_offset,
+                     int training, int deterministic, const usim_policy_out* out, void* stream) {
+    using namespace usim;
+    if (!net || !st || !obs_dev || !out || !out->act_env_dev || n <= 0 || act_dim < 1 || act_dim > 7 || !act_low_dev || !act_high_dev) return USIM_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    PolicyNet P{net->pi_w1, net->pi_b1, net->pi_w2, net->pi_b2, net->act_w, net->act_b, net->vf_w1, net->vf_b1, net->vf_w2, net->vf_b2, net->val_w, net->val_b, net->log_std};
+    NormStats S{st->obs_mean, st->obs_var, st->obs_count, st->ret_mean, st->ret_var, st->ret_count, st->returns, st->clip_obs, st->clip_reward, st->gamma, st->epsilon};
+    if (training) {
+        if (!st->scratch) return USIM_ERR_INVALID;
+        // scratch: PL_SB x 19 x 2 partial sums, then the arrival counter (zero on entry, left zero)
+        hipLaunchKernelGGL(usim_policy_obs_stats_kernel, dim3(PL_SB), dim3(PL_ST), 0, s, obs_dev, n, S, st->scratch, reinterpret_cast<unsigned int*>(st->scratch + PL_SB * PL_OBS * 2));
+    }
+    hipLaunchKernelGGL(usim_policy_act_kernel, dim3((n + PL_TM - 1) / PL_TM, 2), dim3(256), 0, s, P, S, obs_dev, prev_done_dev, n,
+                       act_dim, act_low_dev, act_high_dev, (uint32_t)seed, (uint32_t)(seed >> 32), counter, counter_base_dev, env_offset, deterministic, out->nobs_dev, out->act_dev,
+                       out->act_env_dev, out->value_dev, out->logp_dev, out->episode_start_dev);
+    return hipGetLastError() == hipSuccess ? USIM_OK : USIM_ERR_HIP;
+}
+
+int usim_policy_reward(const usim_norm_stats* st, const float* rew_dev, const uint8_t* done_dev, int n, int training, int norm_reward, float* nrew_dev,
+                       double* raw_sum_dev, void* stream) {
+    using namespace usim;
+    if (!st || !rew_dev || !done_dev || !nrew_dev || n <= 0) return USIM_ERR_INVALID;
+    NormStats S{st->obs_mean, st->obs_var, st->obs_count, st->ret_mean, st->ret_var, st->ret_count, st->returns, st->clip_obs, st->clip_reward, st->gamma, st->epsilon};
+    hipLaunchKernelGGL(usim_policy_reward_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rew_dev, done_dev, n, S, training, norm_reward, nrew_dev, raw_sum_dev);
+    return hipGetLastError() == hipSuccess ? USIM_OK : USIM_ERR_HIP;
+}
+
+int usim_policy_gae(const float* rewards_dev, const float* values_dev, const float* episode_starts_dev, const float* last_values_dev, const uint8_t* last_done_dev,
+                    int T, int n, float gamma, float gae_lambda, float* advantages_dev, float* returns_dev, void* stream) {
+    using namespace usim;
+    if (!rewards_dev || !values_dev || !episode_starts_dev || !last_values_dev || !last_done_dev || !advantages_dev || !returns_dev || T <= 0 || n <= 0) return USIM_ERR_INVALID;
+    hipLaunchKernelGGL(usim_policy_gae_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, rewards_dev, values_dev, episode_starts_dev, last_values_dev,
+                       last_done_dev, T, n, gamma, gae_lambda, advantages_dev, returns_dev);
+    return hipGetLastError() == hipSuccess ? USIM_OK : USIM_ERR_HIP;
+}
+
+}  // extern "C"

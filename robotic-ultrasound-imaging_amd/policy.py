@@ -8,6 +8,7 @@ ActorCriticPolicy with net_arch [dict(pi=[256,128], vf=[256,128])], tanh activat
 torch.load(weights_only=True), the pickle with a restricted unpickler that maps the four SB3 / gym classes to local stand-ins
 (sys.modules is never touched).  save_sb3_zip / save_vecnormalize_pkl write the same formats (the model.save / env.save step at the
 end of src/rl.py's training branch, :157-158)."""
+import ctypes as C
 import io
 import json
 import pickle
@@ -477,3 +478,100 @@ class GraphedCollector:
         self.graph.replay()
         self.buffer.pos, self.buffer.full = self.buffer.buffer_size, True
         return self.obs, self.episode_start
+
+
+class FusedRollout:
+    """The rollout loop with the policy in it on the library's fused kernels (include/usim.h usim_policy_step / usim_policy_reward / usim_policy_gae;
+    csrc/usim_policy.hip) instead of ~100 PyTorch launches per step: per step one statistics kernel, one kernel that normalises the observation,
+    runs both MLPs on the matrix cores, samples, clips and writes the buffer slices, the simulator step, and one reward kernel; GAE is one more
+    kernel per rollout.  The whole rollout is recorded as a HIP graph, as in GraphedCollector.  The parameters stay the torch module's (read at
+    their addresses), the statistics stay the DeviceVecNormalize's tensors, the buffer is the DeviceRolloutBuffer: a PPO update written against
+    those objects is unchanged.  Differences from collect_rollouts: sums are ordered differently (agreement to rounding, not bit for bit) and the
+    Gaussian noise comes from the library's counter-based stream (seed, environment, step), not from a torch generator."""
+
+    def __init__(self, env, policy, vecnorm, buffer, seed=0, graph=True):
+        from . import _lib
+        if policy.pi_sizes != (256, 128) or policy.vf_sizes != (256, 128) or policy.policy_net[0].in_features != 19:
+            raise ValueError("the fused kernels implement the MlpPolicy of the shipped checkpoints: 19 -> 256 -> 128 (tanh) for both networks")
+        self.env, self.policy, self.vecnorm, self.buffer, self.seed = env, policy, vecnorm, buffer, int(seed)
+        self.lib = _lib.load()
+        dev = env.device
+        for p_ in policy.parameters():
+            if p_.device != dev or p_.dtype != torch.float32 or not p_.is_contiguous():
+                raise ValueError("policy parameters must be contiguous float32 tensors on the environment's device")
+        ptr = lambda t: t.data_ptr()
+        pn, vb = policy.policy_net, policy.value_net_body
+        self._net = _lib.UsimPolicyNet(ptr(pn[0].weight), ptr(pn[0].bias), ptr(pn[2].weight), ptr(pn[2].bias), ptr(policy.action_net.weight), ptr(policy.action_net.bias),
+                                       ptr(vb[0].weight), ptr(vb[0].bias), ptr(vb[2].weight), ptr(vb[2].bias), ptr(policy.value_net.weight), ptr(policy.value_net.bias),
+                                       ptr(policy.log_std))
+        vn = vecnorm
+        self._scratch = torch.zeros(1280, dtype=torch.float64, device=dev)                  # USIM_POLICY_SCRATCH (include/usim.h)
+        self._stats = _lib.UsimNormStats(ptr(vn.obs_mean), ptr(vn.obs_var), ptr(vn._obs_count), ptr(vn.ret_mean), ptr(vn.ret_var), ptr(vn._ret_count), ptr(vn.returns),
+                                         ptr(self._scratch), float(vn.clip_obs), float(vn.clip_reward), float(vn.gamma), float(vn.epsilon))
+        self._low = torch.as_tensor(env.action_space.low, dtype=torch.float32, device=dev).contiguous()
+        self._high = torch.as_tensor(env.action_space.high, dtype=torch.float32, device=dev).contiguous()
+        self._act_env = torch.zeros(env.num_envs, env.action_dim, dtype=torch.float32, device=dev)
+        self._value = torch.zeros(env.num_envs, dtype=torch.float32, device=dev)
+        self.raw_reward_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        self.counter = 0                                                                    # rollouts collected
+        self._ctr = torch.zeros(1, dtype=torch.int32, device=dev)                           # device part of the noise counter: advanced by every rollout
+        self.obs = env.reset_tensor()                                                       # the env's own observation buffer: rewritten by every step
+        self._prev_done = env._done                                                         # ... and its done flags: read by the policy kernel BEFORE the next step rewrites them
+        self._prev_done.fill_(1)                                                            # every environment starts an episode
+        self.graph = None
+        if graph:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                env.refill_bank()
+                torch.cuda.current_stream(dev).synchronize()
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, stream=side):
+                    self._record()
+            torch.cuda.current_stream(dev).wait_stream(side)
+
+    def _check(self, rc):
+        from . import _lib
+        _lib.check(self.lib, rc, None)
+
+    def act(self, obs, prev_done, counter, training=None, deterministic=False, t=None):
+        """usim_policy_step on raw observations [n, 19]: returns (clipped action for the env, value); with t, the buffer slices of step t are written"""
+        from . import _lib
+        env, b = self.env, self.buffer
+        training = self.vecnorm.training if training is None else training
+        ptr = lambda x: None if x is None else x.data_ptr()
+        out = _lib.UsimPolicyOut(ptr(self._act_env), None if t is None else ptr(b.observations[t]), None if t is None else ptr(b.actions[t]),
+                                 ptr(self._value) if t is None else ptr(b.values[t]), None if t is None else ptr(b.log_probs[t]), None if t is None else ptr(b.episode_starts[t]))
+        self._check(self.lib.usim_policy_step(C.byref(self._net), C.byref(self._stats), ptr(obs), ptr(prev_done), env.num_envs, env.action_dim, ptr(self._low), ptr(self._high),
+                                              self.seed, int(counter) & 0xffffffff, ptr(self._ctr), int(getattr(env, "env_offset", 0)), int(bool(training)),
+                                              int(bool(deterministic)), C.byref(out), env._stream()))
+        return self._act_env, (self._value if t is None else b.values[t])
+
+    def _record(self):
+        """one rollout: T x (policy, env, reward) + bootstrap value + GAE.  The noise of step t is keyed on (seed, environment, t + device counter); the
+        recorded sequence advances the device counter by T + 1 at its end, so a replay draws fresh noise"""
+        env, b, vn = self.env, self.buffer, self.vecnorm
+        T, n = b.buffer_size, env.num_envs
+        self.raw_reward_sum.zero_()
+        for t in range(T):
+            self.act(self.obs, self._prev_done, counter=t, t=t)
+            o, rew, done = env.step_tensor(self._act_env)
+            self._check(self.lib.usim_policy_reward(C.byref(self._stats), rew.data_ptr(), done.data_ptr(), n, int(bool(vn.training)), int(bool(vn.norm_reward)),
+                                                    b.rewards[t].data_ptr(), self.raw_reward_sum.data_ptr(), env._stream()))
+        # bootstrap with the value of the last observation, statistics frozen (collect_rollouts does the same)
+        self.act(self.obs, self._prev_done, counter=T, training=False, deterministic=True)
+        self._check(self.lib.usim_policy_gae(b.rewards.data_ptr(), b.values.data_ptr(), b.episode_starts.data_ptr(), self._value.data_ptr(), self._prev_done.data_ptr(),
+                                             T, n, b.gamma, b.gae_lambda, b.advantages.data_ptr(), b.returns.data_ptr(), env._stream()))
+        self._ctr.add_(T + 1)
+        env.refill_bank()
+
+    def collect(self):
+        """one rollout of buffer.buffer_size steps into the buffer (returns / advantages included)"""
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.env.refill_bank()
+            self._record()
+        self.counter += 1
+        self.buffer.pos, self.buffer.full = self.buffer.buffer_size, True
+        return self.obs, self._prev_done

@@ -192,3 +192,104 @@ def test_graphed_collector_equals_eager_collect_rollouts(usim):
     sa, sb = env.get_state(), env2.get_state()
     assert all(np.array_equal(sa[k], sb[k]) for k in sa)
     env.close(); env2.close()
+
+
+def test_fused_policy_kernels_match_the_torch_policy(usim, pins):
+    """include/usim.h usim_policy_step / usim_policy_reward / usim_policy_gae (csrc/usim_policy.hip: VecNormalize + both MLPs on the matrix cores +
+    sampling + buffer writes in one kernel) against policy.DeviceVecNormalize / MlpActorCritic / DeviceRolloutBuffer in PyTorch: the reference's
+    trained `tracking` weights and a random 7-action policy, a batch that does not fill its last tile of 16 environments."""
+    pol = importlib.import_module("robotic-ultrasound-imaging_amd.policy")
+    dev = torch.device("cuda:0")
+    sd = {k: torch.from_numpy(v) for k, v in np.load(ROOT / "tests/golden/tracking_policy.npz").items()}
+    for mode, n in (("tracking", 1000), ("variable_z", 333)):
+        kw = usim.default_robosuite_kwargs(); kw["controller_configs"] = dict(kw["controller_configs"], impedance_mode=mode)
+        env = usim.UltrasoundVecEnv(n, device="cuda:0", seed=3, **kw)
+        torch.manual_seed(1)
+        policy = (pol.MlpActorCritic.from_sb3_state_dict(sd) if mode == "tracking" else pol.MlpActorCritic(19, env.action_dim)).to(dev)
+        with torch.no_grad():
+            policy.log_std.copy_(torch.linspace(-0.7, 0.2, env.action_dim))
+        T = 4
+        vn, twin = (pol.DeviceVecNormalize(n, 19, device=dev, training=True, norm_reward=True) for _ in range(2))
+        buf = pol.DeviceRolloutBuffer(T, n, 19, env.action_dim, device=dev)
+        fr = pol.FusedRollout(env, policy, vn, buf, seed=5, graph=False)
+        env.reset_tensor(); env.rollout_random(0, 40)
+        obs = env.step_tensor(env.random_actions_tensor(40))[0].clone()
+        prev_done = (torch.rand(n, device=dev) < 0.3).to(torch.uint8)
+        for t in range(2):                                                   # two updates: the second merges into non-trivial statistics
+            act_env, _ = fr.act(obs * (1.0 + t), prev_done, counter=10 + t, t=t)
+            nobs = twin.normalize_obs(obs * (1.0 + t))
+            assert torch.allclose(vn.obs_mean, twin.obs_mean, rtol=1e-12, atol=1e-14) and torch.allclose(vn.obs_var, twin.obs_var, rtol=1e-11, atol=1e-14)
+            assert abs(vn.obs_count - twin.obs_count) < 1e-9
+            assert torch.allclose(buf.observations[t], nobs, atol=2e-6)
+            mean, value = policy.forward(buf.observations[t])
+            assert torch.allclose(buf.values[t], value, atol=3e-5), float((buf.values[t] - value).abs().max())
+            noise = (buf.actions[t] - mean) / torch.exp(policy.log_std)
+            assert abs(float(noise.mean())) < 0.06 and abs(float(noise.std()) - 1.0) < 0.05 and float(noise.abs().max()) < 6.0
+            assert torch.allclose(buf.log_probs[t], policy._log_prob(mean, policy.log_std, buf.actions[t]), atol=2e-4)
+            low, high = torch.as_tensor(env.action_space.low, device=dev), torch.as_tensor(env.action_space.high, device=dev)
+            assert torch.equal(act_env, torch.max(torch.min(buf.actions[t], high), low))
+            assert torch.equal(buf.episode_starts[t], prev_done.to(torch.float32))
+        n0, n1 = ((buf.actions[t] - policy.forward(buf.observations[t])[0]) / torch.exp(policy.log_std) for t in range(2))
+        assert float((n0 - n1).abs().mean()) > 0.5                          # another counter, another draw
+        # deterministic, statistics frozen: the mean action and the value of the torch modules
+        c0 = vn.obs_count
+        act_env, value = fr.act(obs, None, counter=99, training=False, deterministic=True)
+        twin.training = False
+        mean, v = policy.forward(twin.normalize_obs(obs))
+        assert vn.obs_count == c0 and torch.allclose(value, v, atol=3e-5)
+        assert torch.allclose(act_env, torch.max(torch.min(mean, high), low), atol=3e-5)
+        twin.training = True
+        # reward side
+        lib, C = fr.lib, pol.C
+        for k in range(3):
+            rew, done = torch.rand(n, device=dev) * 9, (torch.rand(n, device=dev) < 0.2).to(torch.uint8)
+            out = torch.zeros(n, device=dev)
+            assert lib.usim_policy_reward(C.byref(fr._stats), rew.data_ptr(), done.data_ptr(), n, 1, 1, out.data_ptr(), fr.raw_reward_sum.data_ptr(), env._stream()) == 0
+            ref = twin.normalize_reward(rew, done)
+            assert torch.allclose(out, ref, atol=1e-6) and torch.allclose(vn.returns, twin.returns, rtol=1e-13)
+            assert torch.allclose(vn.ret_var, twin.ret_var, rtol=1e-11) and torch.allclose(vn.ret_mean, twin.ret_mean, rtol=1e-11) and abs(vn.ret_count - twin.ret_count) < 1e-9
+        # GAE
+        b2 = pol.DeviceRolloutBuffer(37, n, 19, env.action_dim, device=dev)
+        b2.rewards.uniform_(-1, 1); b2.values.normal_(); b2.episode_starts.copy_((torch.rand(37, n, device=dev) < 0.1).float())
+        last_v, last_d = torch.randn(n, device=dev), (torch.rand(n, device=dev) < 0.1)
+        b2.compute_returns_and_advantage(last_v, last_d)
+        adv, ret = torch.zeros_like(b2.advantages), torch.zeros_like(b2.advantages)
+        ld = last_d.to(torch.uint8)
+        assert lib.usim_policy_gae(b2.rewards.data_ptr(), b2.values.data_ptr(), b2.episode_starts.data_ptr(), last_v.data_ptr(), ld.data_ptr(), 37, n, 0.99, 0.95,
+                                   adv.data_ptr(), ret.data_ptr(), env._stream()) == 0
+        assert torch.allclose(adv, b2.advantages, atol=1e-5) and torch.allclose(ret, b2.returns, atol=1e-5)
+        env.close()
+
+
+def test_fused_rollout_graph_collects_like_the_eager_collector(usim):
+    """policy.FusedRollout: T x (usim_policy_step, usim_step, usim_policy_reward) + bootstrap + GAE as one HIP graph.  Same semantics as
+    collect_rollouts (buffer invariants, statistics counts, fresh noise at every replay, environments that end and restart on the way); the numbers
+    differ from the eager collector's only through the noise stream, so the comparison is statistical."""
+    pol = importlib.import_module("robotic-ultrasound-imaging_amd.policy")
+    dev, n, T = torch.device("cuda:0"), 1024, 96
+    torch.manual_seed(0)
+    env = usim.UltrasoundVecEnv(n, device="cuda:0", seed=4, **usim.default_robosuite_kwargs())
+    policy = pol.MlpActorCritic(19, env.action_dim).to(dev)
+    vn = pol.DeviceVecNormalize(n, 19, device=dev, training=True, norm_reward=True)
+    buf = pol.DeviceRolloutBuffer(T, n, 19, env.action_dim, device=dev)
+    fr = pol.FusedRollout(env, policy, vn, buf, seed=9)
+    c0 = vn.obs_count                                        # (recording executes nothing)
+    fr.collect(); torch.cuda.synchronize()
+    a1, r1 = buf.actions.clone(), float(fr.raw_reward_sum) / (n * T)
+    assert buf.full and abs(vn.obs_count - (c0 + n * T)) < 1e-6
+    fr.collect(); torch.cuda.synchronize()
+    assert abs(vn.obs_count - (c0 + 2 * n * T)) < 1e-6 and not torch.equal(a1, buf.actions)
+    r, v, s, adv = (x.cpu().numpy().astype(np.float64) for x in (buf.rewards, buf.values, buf.episode_starts, buf.advantages))
+    nnt = 1.0 - s[1:]
+    assert np.allclose(adv[:-1], r[:-1] + 0.99 * v[1:] * nnt - v[:-1] + 0.99 * 0.95 * nnt * adv[1:], atol=2e-4)
+    assert torch.isfinite(buf.returns).all() and torch.isfinite(buf.log_probs).all() and float(buf.observations.abs().max()) <= 10.0 + 1e-6
+    assert 3 < int(s[1:].sum()) and 4.0 < r1 < 9.0          # episodes ended and restarted; reward per step of an untrained policy ~ 6
+    noise = (buf.actions - policy.forward(buf.observations.reshape(-1, 19))[0].reshape(T, n, -1)) / torch.exp(policy.log_std)
+    assert abs(float(noise.mean())) < 0.02 and abs(float(noise.std()) - 1.0) < 0.02
+    # the eager collector on a twin gives the same reward level and statistics
+    env2 = usim.UltrasoundVecEnv(n, device="cuda:0", seed=4, **usim.default_robosuite_kwargs())
+    vn2, buf2 = pol.DeviceVecNormalize(n, 19, device=dev, training=True, norm_reward=True), pol.DeviceRolloutBuffer(T, n, 19, env.action_dim, device=dev)
+    obs, start = pol.collect_rollouts(env2, policy, vn2, buf2)
+    pol.collect_rollouts(env2, policy, vn2, buf2, obs=obs, episode_start=start)
+    assert torch.allclose(vn.obs_mean, vn2.obs_mean, atol=0.15 * float(vn2.obs_var.sqrt().max())) and abs(float(vn.ret_var) / float(vn2.ret_var) - 1.0) < 0.2
+    env.close(); env2.close()
