@@ -221,7 +221,8 @@ def test_fused_policy_kernels_match_the_torch_policy(usim, pins):
             assert torch.allclose(vn.obs_mean, twin.obs_mean, rtol=1e-12, atol=1e-14) and torch.allclose(vn.obs_var, twin.obs_var, rtol=1e-11, atol=1e-14)
             assert abs(vn.obs_count - twin.obs_count) < 1e-9
             assert torch.allclose(buf.observations[t], nobs, atol=2e-6)
-            mean, value = policy.forward(buf.observations[t])
+            with torch.no_grad():
+                mean, value = policy.forward(buf.observations[t])
             assert torch.allclose(buf.values[t], value, atol=3e-5), float((buf.values[t] - value).abs().max())
             noise = (buf.actions[t] - mean) / torch.exp(policy.log_std)
             assert abs(float(noise.mean())) < 0.06 and abs(float(noise.std()) - 1.0) < 0.05 and float(noise.abs().max()) < 6.0
@@ -229,13 +230,15 @@ def test_fused_policy_kernels_match_the_torch_policy(usim, pins):
             low, high = torch.as_tensor(env.action_space.low, device=dev), torch.as_tensor(env.action_space.high, device=dev)
             assert torch.equal(act_env, torch.max(torch.min(buf.actions[t], high), low))
             assert torch.equal(buf.episode_starts[t], prev_done.to(torch.float32))
-        n0, n1 = ((buf.actions[t] - policy.forward(buf.observations[t])[0]) / torch.exp(policy.log_std) for t in range(2))
+        with torch.no_grad():
+            n0, n1 = [(buf.actions[t] - policy.forward(buf.observations[t])[0]) / torch.exp(policy.log_std) for t in range(2)]
         assert float((n0 - n1).abs().mean()) > 0.5                          # another counter, another draw
         # deterministic, statistics frozen: the mean action and the value of the torch modules
         c0 = vn.obs_count
         act_env, value = fr.act(obs, None, counter=99, training=False, deterministic=True)
         twin.training = False
-        mean, v = policy.forward(twin.normalize_obs(obs))
+        with torch.no_grad():
+            mean, v = policy.forward(twin.normalize_obs(obs))
         assert vn.obs_count == c0 and torch.allclose(value, v, atol=3e-5)
         assert torch.allclose(act_env, torch.max(torch.min(mean, high), low), atol=3e-5)
         twin.training = True
@@ -284,7 +287,8 @@ def test_fused_rollout_graph_collects_like_the_eager_collector(usim):
     assert np.allclose(adv[:-1], r[:-1] + 0.99 * v[1:] * nnt - v[:-1] + 0.99 * 0.95 * nnt * adv[1:], atol=2e-4)
     assert torch.isfinite(buf.returns).all() and torch.isfinite(buf.log_probs).all() and float(buf.observations.abs().max()) <= 10.0 + 1e-6
     assert 3 < int(s[1:].sum()) and 4.0 < r1 < 9.0          # episodes ended and restarted; reward per step of an untrained policy ~ 6
-    noise = (buf.actions - policy.forward(buf.observations.reshape(-1, 19))[0].reshape(T, n, -1)) / torch.exp(policy.log_std)
+    with torch.no_grad():
+        noise = (buf.actions - policy.forward(buf.observations.reshape(-1, 19))[0].reshape(T, n, -1)) / torch.exp(policy.log_std)
     assert abs(float(noise.mean())) < 0.02 and abs(float(noise.std()) - 1.0) < 0.02
     # the eager collector on a twin gives the same reward level and statistics
     env2 = usim.UltrasoundVecEnv(n, device="cuda:0", seed=4, **usim.default_robosuite_kwargs())
