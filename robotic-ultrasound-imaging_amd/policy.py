@@ -282,10 +282,12 @@ class MlpActorCritic(torch.nn.Module):
 
 
 @torch.no_grad()
-def policy_rollout(env, policy, vecnorm, steps, deterministic=False, seed=0):
+def policy_rollout(env, policy, vecnorm, steps, deterministic=False, seed=0, fused=False):
     """Run `steps` env steps of the policy on the device-resident fast path (no host synchronisation inside the loop).
-    Returns raw-observation running statistics (mean, var over all visited steps), mean reward per step, and episode stats."""
+    Returns raw-observation running statistics (mean, var over all visited steps), mean reward per step, and episode stats.
+    fused=True: normalisation, both MLPs, sampling and clipping by the library's policy kernel (usim_policy_step) instead of PyTorch modules."""
     dev = env.device
+    fr = FusedRollout(env, policy, vecnorm, DeviceRolloutBuffer(1, env.num_envs, 19, env.action_dim, device=dev), seed=seed, graph=False) if fused else None
     low = torch.as_tensor(env.action_space.low, device=dev)
     high = torch.as_tensor(env.action_space.high, device=dev)
     gen = torch.Generator(device=dev); gen.manual_seed(seed)
@@ -297,7 +299,10 @@ def policy_rollout(env, policy, vecnorm, steps, deterministic=False, seed=0):
     for _ in range(steps):
         o = obs.to(torch.float64)
         s1 += o.sum(0); s2 += (o * o).sum(0)
-        act = policy.predict(vecnorm.normalize_obs(obs), deterministic, low, high, gen)
+        if fr is not None:
+            act, _ = fr.act(obs, None, counter=_, deterministic=deterministic)
+        else:
+            act = policy.predict(vecnorm.normalize_obs(obs), deterministic, low, high, gen)
         obs, rew, done = env.step_tensor(act)
         vecnorm.normalize_reward(rew, done)
         rew_sum += rew.sum()

@@ -29,6 +29,10 @@ def test_reference_trained_policy_transfers(usim, pins):
     assert sum(p.numel() for p in policy.parameters()) == 19 * 256 * 2 + 256 * 2 + 256 * 128 * 2 + 128 * 2 + 128 * 6 + 6 + 128 + 1 + 6
     vn = pol.DeviceVecNormalize.from_stats(stats, n, device=env.device, training=False, norm_reward=False)
     out = pol.policy_rollout(env, policy, vn, steps, deterministic=False)      # stochastic, as during the reference's training
+    # the same replay through the library's fused policy kernel (usim_policy_step: VecNormalize + both MLPs on the matrix cores + sampling)
+    fused = pol.policy_rollout(env, policy, vn, steps, deterministic=False, fused=True)
+    assert abs(fused["reward_per_step"] - out["reward_per_step"]) < 0.15 and abs(fused["mean_episode_length"] / out["mean_episode_length"] - 1.0) < 0.15
+    assert np.allclose(fused["obs_mean"][6:], out["obs_mean"][6:], atol=0.1 * np.sqrt(out["obs_var"][6:]).max())
     ref_rate = meta["ep_mean_return"] / meta["ep_mean_length"]                  # 8.12 reward per step on MuJoCo
     assert abs(out["reward_per_step"] - ref_rate) < 0.6, (out["reward_per_step"], ref_rate)
     assert 0.6 * meta["ep_mean_length"] < out["mean_episode_length"] < 1.4 * meta["ep_mean_length"]
@@ -224,7 +228,7 @@ def test_fused_policy_kernels_match_the_torch_policy(usim, pins):
             with torch.no_grad():
                 mean, value = policy.forward(buf.observations[t])
             assert torch.allclose(buf.values[t], value, atol=3e-5), float((buf.values[t] - value).abs().max())
-            noise = (buf.actions[t] - mean) / torch.exp(policy.log_std)
+            noise = ((buf.actions[t] - mean) / torch.exp(policy.log_std)).detach()
             assert abs(float(noise.mean())) < 0.06 and abs(float(noise.std()) - 1.0) < 0.05 and float(noise.abs().max()) < 6.0
             assert torch.allclose(buf.log_probs[t], policy._log_prob(mean, policy.log_std, buf.actions[t]), atol=2e-4)
             low, high = torch.as_tensor(env.action_space.low, device=dev), torch.as_tensor(env.action_space.high, device=dev)
