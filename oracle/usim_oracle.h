@@ -26,8 +26,12 @@ extern "C" {
 #endif
 
 #define USO_OBS_DIM 19
+#ifndef USO_MAXC
 #define USO_MAXC 8          /* contact slots per env */
+#endif
+#ifndef USO_MAXCAND
 #define USO_MAXCAND 16      /* penetrating elements considered before the USO_MAXC deepest are kept */
+#endif
 #define USO_NSCALAR 40      /* scalar state words per env exported by uso_get_state */
 
 /* impedance_mode of the OSC controller (rl_config.yaml:41, main.py:33, utils/plot.py:203-211,303-313) */
