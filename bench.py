@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--presteps", type=int, default=0, help="studies only: untimed steps between the synchronous reset and the warm-up (after one horizon the episodes of "
+                    "the batch are de-synchronised; right after the reset every probe has just been pressed in and the first ~100 steps carry a third more contacts).  "
+                    "Default 0: the run starts from the reset, as the W warm-up steps of the contract imply")
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--workload", choices=["soft", "rigid"], default="soft")
     ap.add_argument("--block", type=int, default=128, help="rollout block length T (steps per all-gather)")
@@ -120,6 +123,11 @@ def main():
 
     env.reset_tensor()
     step = 0
+    done_p = 0
+    while done_p < args.presteps:                          # state preparation (see --presteps): untimed, before the W warm-up steps
+        k = min(T, args.presteps - done_p)
+        env.rollout_random(step, k, blocks[0])
+        step += k; done_p += k
     done_w = 0
     adaptive_ms = []
     if adaptive and args.warmup > 0:
@@ -233,7 +241,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD_NAME[wl], "envs_per_gpu": n, "global_envs": n * world,
-                       "controller": "OSC_POSE impedance_mode=tracking", "rollout_block": T, "domain_randomisation": "stiffness+damping" + ("+friction" if args.randomize else ""),
+                       "controller": "OSC_POSE impedance_mode=tracking", "rollout_block": T,
+                       "presteps": args.presteps,           # untimed steps before the warm-up that de-synchronise the episodes after the synchronous reset (0: none) "domain_randomisation": "stiffness+damping" + ("+friction" if args.randomize else ""),
                        "parallelism": f"env-shard x{world}" + ("" if gather is None else (" + RCCL all-gather of transition blocks" if args.gather == "rccl" else
                                                                  " + peer-to-peer copies of transition blocks (copy engines)")),
                        "gather": None if gather is None else args.gather, "mapping_next_to_gather": None if gather is None else ("adaptive" if adaptive else "plain"),

@@ -28,6 +28,7 @@ def test_bench_json_contract_default_workload():
     assert out["metric"].startswith("env-steps/sec") and out["unit"] == "env-steps/s" and out["higher_is_better"] is True
     assert out["n_gpus"] == 1 and out["steps"] == 256 and out["warmup"] == 32 and out["scaling"] == "weak" and out["vs_baseline"] is None
     assert out["dtype"] == "f32" and out["data"] == "synthetic" and "workload" in out["config"] and "model" not in out["config"]
+    assert out["config"]["presteps"] == 0              # no untimed steps besides the W warm-up steps (bench.py --presteps is for studies)
     assert out["value"] > 1e6 and abs(out["value"] - 4096 * 256 / (out["ms_per_step"] * 256e-3)) / out["value"] < 1e-6
     rf = out["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0

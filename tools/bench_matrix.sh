@@ -10,9 +10,11 @@ print('%-34s %8.1f M env-steps/s  %7.2f us/step  kernel %7.2f us  frac %.4f  lan
 run "configs[2] soft 4096"            --steps 2000 --warmup 100
 run "configs[2] soft 4096 spl 1"      --steps 2000 --warmup 100 --steps-per-launch 1
 run "configs[2] driver-style 20/5"    --steps 20 --warmup 5
+run "configs[2] 20/5 after 1000 steps" --steps 20 --warmup 5 --presteps 1000
 run "configs[2] lanes 16"             --steps 2000 --warmup 100 --lanes-per-env 16
 run "configs[1] rigid 4096"           --steps 2000 --warmup 100 --workload rigid
 run "configs[4] 8192 randomised auto" --steps 1000 --warmup 100 --envs-per-gpu 8192 --randomize
+run "configs[4] after 1000 steps"      --steps 1000 --warmup 100 --envs-per-gpu 8192 --randomize --presteps 1000
 run "configs[4] 8192 randomised l32"  --steps 1000 --warmup 100 --envs-per-gpu 8192 --randomize --lanes-per-env 32
 run "configs[4] 8192 randomised l64"  --steps 1000 --warmup 100 --envs-per-gpu 8192 --randomize --lanes-per-env 64
 run "configs[4] 8192 randomised l8"   --steps 1000 --warmup 100 --envs-per-gpu 8192 --randomize --lanes-per-env 8
