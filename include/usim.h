@@ -89,8 +89,8 @@ typedef struct usim_config {
     double probe_radius2, probe_height;        /* ... upper capsule: radius, height of its axis above the tip capsule's (probe_height > |probe_radius2 - probe_radius|) */
     int32_t substeps;                          /* physics steps per env.step(): int(control_timestep / model_timestep) of robosuite MujocoEnv.step, model timestep 2 ms
                                                 * (1 with the shipped control_freq 500, rl_config.yaml:26; 25 with the env default 20, ultrasound.py:119).  control_dt above is
-                                                * the CONTROL timestep (ultrasound.py:542); the physics step is control_dt / substeps.  substeps > 1: 16-lane kernels, not in
-                                                * `fixed` mode (USIM_ERR_UNSUPPORTED otherwise) */
+                                                * the CONTROL timestep (ultrasound.py:542); the physics step is control_dt / substeps.  substeps > 1: 16-lane kernels only
+                                                * (USIM_ERR_UNSUPPORTED otherwise) */
     int32_t reserved_;
 } usim_config;
 

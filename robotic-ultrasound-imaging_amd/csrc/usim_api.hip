@@ -338,10 +338,9 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
         h->hip_err = "the UR5e runs on the table-driven 16-lane kernels only (lanes_per_env 0 or 16)";
         return USIM_ERR_UNSUPPORTED;
     }
-    if (C.substeps > 1 && ((h->lpe != 16 && h->lpe != 32 && h->lpe != 64) || cfg->mode == USIM_MODE_FIXED)) {
-        // several physics substeps per control step run inside the multi-step kernels; in `fixed` mode the goal anchored at the policy step would have
-        // to be held across the substeps (no state words for it): main.py, the one caller of that mode, uses control_freq 500
-        h->hip_err = "substeps > 1 (control_freq below 500) needs the 16-lane kernels (lanes_per_env 0, 16, 32, 64) and an impedance_mode other than 'fixed'";
+    if (C.substeps > 1 && h->lpe != 16 && h->lpe != 32 && h->lpe != 64) {
+        // several physics substeps per control step run inside the multi-step kernels (the `fixed` mode's goal, anchored at the policy step, is held in LDS)
+        h->hip_err = "substeps > 1 (control_freq below 500) needs the 16-lane kernels (lanes_per_env 0, 16, 32, 64)";
         return USIM_ERR_UNSUPPORTED;
     }
     h->occ = cfg->waves_per_simd ? cfg->waves_per_simd : (n_envs <= 4096 ? 1 : 2);

@@ -224,7 +224,7 @@ DI float solve6_task(float* A, float b, const int gl) {
 
 // per-environment LDS scratch of the two transposes: 8 x 8 words
 constexpr int X16_WORDS = 64;
-constexpr int X16_RIGID_STRIDE = 68;                  // rigid-torso launches: one block of 68 words per environment (68 mod 32 = 4)
+constexpr int X16_RIGID_STRIDE = 84;                  // rigid-torso launches: one block per environment: 64 words transpose scratch + 12 words `fixed`-mode goal (84 mod 32 = 20)
 
 // OCC = waves per SIMD the register allocation aims at.  1: the whole register file for one wave (no spills; the choice up to 4096 envs/GPU,
 // where every SIMD holds one wave anyway).  2: 256 registers per lane (the soft-torso kernel then keeps ~27 values in scratch): beyond 4096
@@ -248,7 +248,8 @@ template <int G> constexpr int mb_op() { return mb_pose<G>() + 12; }
 template <int G> constexpr int mb_w() { return mb_op<G>() + 64; }
 template <int G> constexpr int mb_ca() { return G == 16 ? mb_w<G>() + 16 : 0; }                                       // arm-side contact records
 template <int G> constexpr int mb_q() { return G == 16 ? mb_ca<G>() + (MAXCAND + 1) * CG_WORDS : mb_w<G>() + 16; }    // broad-phase queue (element ids)
-template <int G> constexpr int x2_stride() { return mb_q<G>() + 100; }
+template <int G> constexpr int mb_goal() { return mb_q<G>() + 100; }                                              // `fixed` mode with physics substeps: the goal anchored at the policy step (12 words)
+template <int G> constexpr int x2_stride() { return mb_goal<G>() + 12; }
 static_assert((mb_ca<16>() % 4) == 0 && (mb_pose<8>() % 4) == 0 && (x2_stride<16>() % 4) == 0 && (x2_stride<8>() % 4) == 0, "mailbox block");
 static_assert((x2_base<8>() + 32 * x2_stride<8>()) * 4 <= 160 * 1024, "split kernel with 8-lane groups: LDS of a CU");
 // Collision in the split kernel: the ARM side, which has the site pose first, runs the broad phase over all 99 elements (collide_cull) while the
@@ -333,6 +334,11 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
     float* const xl = (ROLE != 0) ? &lds[X2_BASE + eb * X2_STRIDE]
                                   : (TORSO ? &lds[TB_WORDS + eb * GE_STRIDE + GE_WS] : &lds[eb * X16_RIGID_STRIDE]);   // transpose scratch of this environment
     static_assert(GE_WS + X16_WORDS <= GE_STRIDE, "transpose scratch overlays the wrench records");
+    // `fixed`-mode goal held across physics substeps: split kernel -- in the mailbox block; single wave, soft torso -- the last 12 words of the environment's
+    // block, behind the spare contact record; rigid torso -- behind the transpose scratch
+    constexpr int GOAL_OFF = (ROLE != 0) ? mb_goal<G>() : (TORSO ? GE_CG + (MAXCAND + 1) * CG_WORDS - GE_WS : X16_WORDS);
+    static_assert(GE_CG + (MAXCAND + 1) * CG_WORDS + 12 <= GE_STRIDE && X16_WORDS + 12 <= X16_RIGID_STRIDE, "room for the goal");
+    float* const goal_lds = xl + GOAL_OFF;
 
     USIM_STAMP(dbg, 0);
     if constexpr (ROLE == 1) { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[20] = __builtin_readcyclecounter(); }
@@ -810,6 +816,19 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
                 gx = e0 * sx.x + e1 * sx.y + e2 * sx.z; gy = e0 * sy.x + e1 * sy.y + e2 * sy.z; gz = e0 * sz.x + e1 * sz.y + e2 * sz.z;
             }
             kp = C.kp_fixed;
+            if (C.substeps > 1) {
+                // SingleArm.control: `if policy_step: controller.set_goal(action)` -- the goal is anchored at the first physics substep of a control
+                // step and held for the others: parked in the environment's LDS block (same lanes write and read it)
+                if (sub == 0) {
+                    if (gl == 0) {
+                        goal_lds[0] = gpos.x; goal_lds[1] = gpos.y; goal_lds[2] = gpos.z; goal_lds[3] = gx.x; goal_lds[4] = gx.y; goal_lds[5] = gx.z;
+                        goal_lds[6] = gy.x; goal_lds[7] = gy.y; goal_lds[8] = gy.z; goal_lds[9] = gz.x; goal_lds[10] = gz.y; goal_lds[11] = gz.z;
+                    }
+                } else {
+                    gpos = mk(goal_lds[0], goal_lds[1], goal_lds[2]); gx = mk(goal_lds[3], goal_lds[4], goal_lds[5]);
+                    gy = mk(goal_lds[6], goal_lds[7], goal_lds[8]); gz = mk(goal_lds[9], goal_lds[10], goal_lds[11]);
+                }
+            }
         } else {
             const float v = (C.mode == 3) ? 0.f : clampf(act_own, 0.f, 1.f);   // wrench mode: no impedance term
             kp = C.kp_min + v * (C.kp_max - C.kp_min);

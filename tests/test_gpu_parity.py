@@ -157,7 +157,8 @@ def test_ur5e_parity_200_steps(usim, torso, mode):
     _run_parity(usim, 256, 200, torso, mode, robot="UR5e")
 
 
-@pytest.mark.parametrize("torso,mode,freq", [("soft", "tracking", 100), ("soft", "variable_z", 125), ("rigid", "wrench", 50), ("soft", "tracking", 20)])
+@pytest.mark.parametrize("torso,mode,freq", [("soft", "tracking", 100), ("soft", "variable_z", 125), ("rigid", "wrench", 50), ("soft", "tracking", 20),
+                                             ("soft", "fixed", 100), ("rigid", "fixed", 125)])
 def test_control_freq_below_500_runs_physics_substeps(usim, torso, mode, freq):
     """control_freq below 500 (the env's own default is 20, ultrasound.py:119): robosuite MujocoEnv.step runs int(control_timestep / 2 ms) physics
     substeps per env.step() -- controller torque from the current state with the policy step's goal and gains, mj_step -- and _post_action

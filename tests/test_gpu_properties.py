@@ -99,8 +99,18 @@ def test_substeps_are_the_same_physics_as_single_steps(usim, torso):
         assert int(blk[0]["done"].sum()) > 20                                # episodes ended and restarted from the bank on the way
         for e in envs:
             e.close()
-    with pytest.raises(RuntimeError):                                        # `fixed` mode would have to hold its goal across the substeps
-        _env(usim, 8, torso, controller_configs=dict(cc, impedance_mode="fixed"), control_freq=100)
+    # `fixed` mode: the goal anchored at the policy step is held across the substeps; every mapping holds it the same way
+    fx = dict(controller_configs=dict(cc, impedance_mode="fixed"), control_freq=100, early_termination=True)
+    fenvs = [_env(usim, 200, torso, **fx)] + ([_env(usim, 200, torso, lanes_per_env=16, **fx), _env(usim, 200, torso, lanes_per_env=64, **fx)] if torso == "soft" else [])
+    for e in fenvs:
+        e.reset_tensor()
+    for k in range(40):
+        act = fenvs[0].random_actions_tensor(k).clone()
+        res = [[x.clone() for x in e.step_tensor(act)] for e in fenvs]
+        for r in res[1:]:
+            assert all(torch.equal(a, b) for a, b in zip(res[0], r)), k
+    for e in fenvs:
+        e.close()
     with pytest.raises(RuntimeError):                                        # the round-1 kernels have no substep loop
         _env(usim, 8, torso, control_freq=100, lanes_per_env=8 if torso == "soft" else 1)
 
