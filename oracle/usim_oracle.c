@@ -706,6 +706,13 @@ static real probe_sdf(const Sim* S, const real* p, real* g) {
     return d;
 }
 
+/* MuJoCo impedance of a violation r >= 0 for solimp (d0 0.9, dmax 0.95, width 0.001, midpoint 0.5, power 2) [RESTATED] */
+static real solimp_d(real r) {
+    real x = r / (real)SOLIMP_WIDTH; if (x > 1) x = 1;
+    real y = x < (real)0.5 ? 2 * x * x : 1 - 2 * (1 - x) * (1 - x);
+    return (real)SOLIMP_D0 + y * (real)(SOLIMP_DMAX - SOLIMP_D0);
+}
+
 static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, const real* tau, Fwd* out) {
     const Model* m = &S->m;
     const real dt = (real)S->cfg.control_dt; (void)dt;
@@ -727,17 +734,55 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
         const real bfix = (real)(2.0 / (SOLIMP_DMAX * SOLREF_TC));
         const real kten = E->kt_stiff / dmax, bten = E->kt_damp / dmax;   /* direct mode: k = stiffness d/dmax^2, b = damping/dmax */
         real rhs[N_TOP];
-        for (int e = 0; e < n; e++) {
-            real as = -((real)GRAV + az) * m->el_axis[e][2];
-            real r = as + m->w_fix * (-bfix * E->sd[e] - kfix * E->s[e]);
-            for (int d = 0; d < m->el_nnbr[e]; d++) {
-                int j = m->el_nbr[e][d];
-                real sj = j >= 0 ? E->s[j] : 0, sdj = j >= 0 ? E->sd[j] : 0;
-                r += m->w_ten * (-bten * (E->sd[e] - sdj) - kten * (E->s[e] - sj));
+        const real* lat_Linv = m->lat_Linv;      /* inverse used by the contact rows below */
+        real* ramp_buf = 0;
+        if (!S->cfg.lattice_ramp) {
+            for (int e = 0; e < n; e++) {
+                real as = -((real)GRAV + az) * m->el_axis[e][2];
+                real r = as + m->w_fix * (-bfix * E->sd[e] - kfix * E->s[e]);
+                for (int d = 0; d < m->el_nnbr[e]; d++) {
+                    int j = m->el_nbr[e][d];
+                    real sj = j >= 0 ? E->s[j] : 0, sdj = j >= 0 ? E->sd[j] : 0;
+                    r += m->w_ten * (-bten * (E->sd[e] - sdj) - kten * (E->s[e] - sj));
+                }
+                rhs[e] = r;
             }
-            rhs[e] = r;
+            chol_solve(m->lat_L, n, rhs);        /* rhs now holds a~ (element accelerations without contacts) */
+        } else {
+            /* STUDY path (uso_config.lattice_ramp): MuJoCo's impedance d(|r|) per row -- r = s_e for the joint-equality row of element e, s_e - s_j for
+             * the tendon row of an edge --, hence per-row weights d / (1 - d) (x 1/2 for a tendon row: its inverse weight is 2 / m) and, in the reference
+             * acceleration, k scaled by d / d_max (solref: k = d / (d_max^2 tc^2); direct mode: k = stiffness d / d_max^2).  The matrix changes with the
+             * state: assembled, factorised and inverted here, per environment and step. */
+            ramp_buf = (real*)calloc((size_t)2 * n * n, sizeof(real));
+            real* Lm = ramp_buf; real* Li_ = ramp_buf + (size_t)n * n;
+            for (int e = 0; e < n; e++) {
+                real as = -((real)GRAV + az) * m->el_axis[e][2];
+                real de = solimp_d((real)fabs((double)E->s[e]));
+                real wf = de / (1 - de);
+                real r = as + wf * (-bfix * E->sd[e] - kfix * (de / dmax) * E->s[e]);
+                real diag = 1 + wf;
+                for (int d = 0; d < m->el_nnbr[e]; d++) {
+                    int j = m->el_nbr[e][d];
+                    real sj = j >= 0 ? E->s[j] : 0, sdj = j >= 0 ? E->sd[j] : 0;
+                    real dt_ = solimp_d((real)fabs((double)(E->s[e] - sj)));
+                    real wt = (real)0.5 * dt_ / (1 - dt_);
+                    r += wt * (-bten * (E->sd[e] - sdj) - kten * (dt_ / dmax) * (E->s[e] - sj));
+                    diag += wt;
+                    if (j >= 0) Lm[e * n + j] = -wt;
+                }
+                Lm[e * n + e] = diag;
+                rhs[e] = r;
+            }
+            if (chol(Lm, n)) { fprintf(stderr, "usim_oracle: ramped lattice matrix not SPD\n"); abort(); }
+            chol_solve(Lm, n, rhs);
+            real col[N_TOP];
+            for (int j = 0; j < n; j++) {
+                for (int i = 0; i < n; i++) col[i] = (i == j) ? 1 : 0;
+                chol_solve(Lm, n, col);
+                for (int i = 0; i < n; i++) Li_[i * n + j] = col[i];
+            }
+            lat_Linv = Li_;
         }
-        chol_solve(m->lat_L, n, rhs);            /* rhs now holds a~ (element accelerations without contacts) */
 
         /* ---- collision: probe blade vs every dynamic element capsule, ascending shell id ---- */
         /* candidates: the first USO_MAXCAND penetrating elements in ascending shell id; when more than USO_MAXC are found the
@@ -833,7 +878,7 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
                     for (int a = 0; a < 6; a++) vrel += w[c][d][a] * vsite[a];
                     aref[c][d] = -b * vrel - (d == 0 ? kk * cdist[c] : 0);
                     Rr[c][d] = d == 0 ? Rn : Rn / (real)IMPRATIO;
-                    real Aii = g[c][d] * g[c][d] * m->lat_Linv[e * n + e] / (real)ELEM_MASS;
+                    real Aii = g[c][d] * g[c][d] * lat_Linv[e * n + e] / (real)ELEM_MASS;
                     for (int a = 0; a < 6; a++) Aii += w[c][d][a] * Liw[c][d][a];
                     Ad[c][d] = Aii;
                     f[c][d] = 0;
@@ -858,7 +903,7 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
                         real df = fn - f[c][d];
                         f[c][d] = fn;
                         for (int a = 0; a < 6; a++) alpha[a] += Liw[c][d][a] * df;
-                        for (int c2 = 0; c2 < nc; c2++) ae[c2] += m->lat_Linv[out->con_el[c2] * n + e] * g[c][d] * df / (real)ELEM_MASS;
+                        for (int c2 = 0; c2 < nc; c2++) ae[c2] += lat_Linv[out->con_el[c2] * n + e] * g[c][d] * df / (real)ELEM_MASS;
                     }
                     if (normal_only) continue;
                     /* elliptic cone: |f_t| <= mu f_n */
@@ -869,7 +914,7 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
                             real df = f[c][d] * sc - f[c][d];
                             f[c][d] += df;
                             for (int a = 0; a < 6; a++) alpha[a] += Liw[c][d][a] * df;
-                            for (int c2 = 0; c2 < nc; c2++) ae[c2] += m->lat_Linv[out->con_el[c2] * n + e] * g[c][d] * df / (real)ELEM_MASS;
+                            for (int c2 = 0; c2 < nc; c2++) ae[c2] += lat_Linv[out->con_el[c2] * n + e] * g[c][d] * df / (real)ELEM_MASS;
                         }
                     }
                 }
@@ -890,12 +935,13 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
         for (int i = 0; i < NJ; i++) out->qacc[i] += qs[i];
         for (int e = 0; e < n; e++) {
             real a = rhs[e];
-            for (int c = 0; c < nc; c++) a += m->lat_Linv[e * n + out->con_el[c]] * gf[c] / (real)ELEM_MASS;
+            for (int c = 0; c < nc; c++) a += lat_Linv[e * n + out->con_el[c]] * gf[c] / (real)ELEM_MASS;
             out->ael[e] = a;
         }
         v3set(out->fc, W[0], W[1], W[2]);
         /* contact torque about the site is W[3..5] */
         out->tq_sensor[0] = W[3]; out->tq_sensor[1] = W[4]; out->tq_sensor[2] = W[5];
+        free(ramp_buf);
     }
 }
 

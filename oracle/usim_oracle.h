@@ -68,7 +68,9 @@ typedef struct uso_config {
     double probe_radius2, probe_height;   /* ... radius of the upper edge of the flared blade and its height above the tip axis */
     int32_t substeps;             /* physics steps per env.step(): int(control_timestep / model_timestep) of robosuite MujocoEnv.step [RESTATED, SURVEY C.1];
                                    * control_dt is the CONTROL timestep (ultrasound.py:542), the physics step is control_dt / substeps (0 or 1: one) */
-    int32_t reserved_;
+    int32_t lattice_ramp;         /* STUDY switch, oracle only (tests/lattice_ramp_study.py): 1 = evaluate MuJoCo's impedance ramp d(r) of solimp (0.9 0.95 0.001 0.5 2)
+                                   * on every lattice row (the lattice matrix is then assembled and factorised per step); 0 = the product's model, d fixed at
+                                   * d_max = 0.95 so that the inverse is a constant */
 } uso_config;
 
 void  uso_default_config(uso_config* c);
