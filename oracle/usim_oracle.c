@@ -730,8 +730,9 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
     } else {
         /* ---- lattice equality rows, primal form: L a = a_s + w_fix aref_fix + w_ten sum aref_ij ---- */
         const real dmax = (real)SOLIMP_DMAX;
-        const real kfix = (real)(1.0 / (SOLIMP_DMAX * SOLREF_TC * SOLREF_TC * SOLREF_DR * SOLREF_DR));  /* d/(dmax^2 tc^2 dr^2), d=dmax */
-        const real bfix = (real)(2.0 / (SOLIMP_DMAX * SOLREF_TC));
+        const double tcf = S->cfg.study_fix_tc > 0 ? S->cfg.study_fix_tc : SOLREF_TC;       /* (study switch; the product's value is SOLREF_TC) */
+        const real kfix = (real)(1.0 / (SOLIMP_DMAX * tcf * tcf * SOLREF_DR * SOLREF_DR));  /* d/(dmax^2 tc^2 dr^2), d=dmax */
+        const real bfix = (real)(2.0 / (SOLIMP_DMAX * tcf));
         const real kten = E->kt_stiff / dmax, bten = E->kt_damp / dmax;   /* direct mode: k = stiffness d/dmax^2, b = damping/dmax */
         real rhs[N_TOP];
         const real* lat_Linv = m->lat_Linv;      /* inverse used by the contact rows below */

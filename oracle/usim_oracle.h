@@ -71,6 +71,8 @@ typedef struct uso_config {
     int32_t lattice_ramp;         /* STUDY switch, oracle only (tests/lattice_ramp_study.py): 1 = evaluate MuJoCo's impedance ramp d(r) of solimp (0.9 0.95 0.001 0.5 2)
                                    * on every lattice row (the lattice matrix is then assembled and factorised per step); 0 = the product's model, d fixed at
                                    * d_max = 0.95 so that the inverse is a constant */
+    double study_fix_tc;          /* STUDY switch, oracle only (tests/sustained_load_study.py): time constant of the joint-equality ("fix") rows of the lattice; 0 = MuJoCo's
+                                   * default solref time constant 0.02 s, which the product uses */
 } uso_config;
 
 void  uso_default_config(uso_config* c);
