@@ -91,7 +91,12 @@ typedef struct usim_config {
                                                 * (1 with the shipped control_freq 500, rl_config.yaml:26; 25 with the env default 20, ultrasound.py:119).  control_dt above is
                                                 * the CONTROL timestep (ultrasound.py:542); the physics step is control_dt / substeps.  substeps > 1: 16-lane kernels only
                                                 * (USIM_ERR_UNSUPPORTED otherwise) */
-    int32_t reserved_;
+    int32_t probe_geoms;                       /* colliding geoms of the probe body.  2 (default): ultrasound_probe_gripper.xml:8-9 declares `probe_collision` AND `probe_visual`
+                                                * on the same mesh, and the visual one carries no contype = conaffinity = 0 -- with MuJoCo's defaults it collides too, with the
+                                                * default friction (1, 0.005, 0.0001): every probe-element pair has two coincident contacts.  Restated as one contact whose normal
+                                                * row has half the regulariser (two equal rows in parallel), whose friction rows are those of the high-friction contact (the other
+                                                * cone, mu = 0.01, saturates at once) and whose cone limit is (mu_1 + mu_2) / 2 of the total normal force.  1: a single probe geom */
+    double probe_friction2;                    /* sliding friction of the second geom (MuJoCo default 1.0) */
 } usim_config;
 
 typedef struct usim_handle usim_handle;

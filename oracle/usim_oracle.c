@@ -134,13 +134,16 @@ static const RobotDesc ROBOT_UR5E = {
 static const double PROBE_POS[3] = {-0.004, -0.063, 0.128};   /* ultrasound_probe_gripper.xml:6 */
 #define PROBE_MASS 1.0                                         /* ultrasound_probe_gripper.xml:8 */
 /* The probe mesh is missing from the reference snapshot (.MISSING_LARGE_BLOBS:1): stand-in geometry.  Collision shape = flared blade
- * (probe_sdf), long axis = site x (docs/images/frontview.png, sideview.png: the transducer is wide along world y at goal_quat), sizes
- * calibrated on the 192 decoded reset observations (tests/calib_probe.py; tests/test_oracle_env_formulas.py) */
+ * (probe_sdf), long axis = site x (docs/images/frontview.png, sideview.png: the transducer is wide along world y at goal_quat); footprint
+ * 60 x 20 mm.  The XML declares TWO colliding geoms on the mesh (uso_config.probe_geoms: `probe_visual` lacks
+ * contype = conaffinity = 0, ultrasound_probe_gripper.xml:9), the second with MuJoCo's default friction 1.0 -- where the lateral forces and the
+ * torque about the probe axis of the reference's reset rows come from.  Sizes calibrated with that contact law on all six force / torque
+ * channels of the 192 decoded reset observations (tests/calib_probe.py, profiles/r03/calib_probe.txt; tests/test_oracle_env_formulas.py) */
 static const double PROBE_COM[3] = {0.0013, 0.021, -0.043};
 static const double PROBE_INERTIA[3] = {1.6e-3, 1.6e-3, 2.0e-4};
-#define PROBE_RADIUS 0.012
-#define PROBE_HALFLEN 0.030
-#define PROBE_RADIUS2 0.050
+#define PROBE_RADIUS 0.010
+#define PROBE_HALFLEN 0.020
+#define PROBE_RADIUS2 0.040
 #define PROBE_HEIGHT 0.047
 
 /* soft torso lattice (soft_box.xml:9-10) */
@@ -859,9 +862,17 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
                 int e = out->con_el[c];
                 real dir[3][3];
                 v3cpy(dir[0], cn[c]);
-                real ref[3] = {1, 0, 0}; if (fabs((double)cn[c][0]) > 0.9) v3set(ref, 0, 1, 0);
-                v3cross(dir[1], cn[c], ref); real l1 = v3norm(dir[1]); for (int a = 0; a < 3; a++) dir[1][a] /= l1;
-                v3cross(dir[2], cn[c], dir[1]);
+                /* tangent frame without a case distinction in the range the normals live in (Duff et al. 2017: continuous except at n.z = -1; contact normals
+                 * point from the element towards the probe, n.z > 0).  The converged friction force does not depend on the frame (isotropic cone, equal
+                 * regularisers), but the iterate after a fixed number of row-by-row sweeps does: a frame chosen by comparing |n.x| with a threshold -- the
+                 * first form -- made float32 and float64 pick different frames on the blade's flanks (n.x ~ 0.85) and disagree by 0.1 N once friction
+                 * mattered (probe_geoms = 2) */
+                {
+                    const real nx = cn[c][0], ny = cn[c][1], nz = cn[c][2];
+                    const real sg = nz >= 0 ? (real)1 : (real)-1, aa = -1 / (sg + nz), bb = nx * ny * aa;
+                    v3set(dir[1], 1 + sg * nx * nx * aa, sg * bb, -sg * nx);
+                    v3set(dir[2], bb, sg + ny * ny * aa, -ny);
+                }
                 real r[3]; v3sub(r, cp[c], k->x);
                 /* impedance d(r) (solimp .9 .95 .001 .5 2) */
                 real xx = -cdist[c] / (real)SOLIMP_WIDTH; if (xx > 1) xx = 1;
@@ -878,7 +889,7 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
                     real vrel = g[c][d] * E->sd[e] - dir[d][2] * vz;
                     for (int a = 0; a < 6; a++) vrel += w[c][d][a] * vsite[a];
                     aref[c][d] = -b * vrel - (d == 0 ? kk * cdist[c] : 0);
-                    Rr[c][d] = d == 0 ? Rn : Rn / (real)IMPRATIO;
+                    Rr[c][d] = d == 0 ? (S->cfg.probe_geoms == 2 ? (real)0.5 * Rn : Rn) : Rn / (real)IMPRATIO;   /* two geoms: two equal normal rows in parallel */
                     real Aii = g[c][d] * g[c][d] * lat_Linv[e * n + e] / (real)ELEM_MASS;
                     for (int a = 0; a < 6; a++) Aii += w[c][d][a] * Liw[c][d][a];
                     Ad[c][d] = Aii;
@@ -1114,6 +1125,10 @@ static void reset_env(Sim* S, int i, const double* ex /* explicit draws or NULL 
         double pf = c->probe_friction;
         if (c->friction_randomization) pf *= 0.5 + 1.5 * u01(C[3]);
         mu = pf > c->elem_friction ? pf : c->elem_friction;   /* MuJoCo contact friction = max of the two geoms [RESTATED] */
+        if (c->probe_geoms == 2) {                            /* two coincident contacts per pair restated as one (uso_config.probe_geoms) */
+            double mu2 = c->probe_friction2 > c->elem_friction ? c->probe_friction2 : c->elem_friction;
+            mu = 0.5 * (mu + mu2);
+        }
     }
     memset(E, 0, sizeof *E);
     E->episode = episode;
@@ -1259,7 +1274,7 @@ void uso_default_config(uso_config* c) {
     c->friction_randomization = 0; c->torso_drop = 1; c->pgs_iters = 4; c->ik_iters = 5; c->env_offset = 0; c->robot = 0;
     c->substeps = 1; c->seed = 3; c->control_dt = 0.002; c->kp_fixed = 300; c->damping_ratio = 1; c->kp_min = 0; c->kp_max = 500;
     c->out_max_pos = 0.05; c->out_max_ori = 0.5; c->stiffness = 1324.17; c->damping = 17.59;
-    c->elem_friction = 0.01; c->probe_friction = 1e-4;
+    c->elem_friction = 0.01; c->probe_friction = 1e-4; c->probe_friction2 = 1.0; c->probe_geoms = 2;
     c->probe_radius = PROBE_RADIUS; c->probe_halflen = PROBE_HALFLEN; c->probe_radius2 = PROBE_RADIUS2; c->probe_height = PROBE_HEIGHT; c->torso_shape = 0;
 }
 void* uso_create(const uso_config* c, int n) {

@@ -73,6 +73,13 @@ typedef struct uso_config {
                                    * d_max = 0.95 so that the inverse is a constant */
     double study_fix_tc;          /* STUDY switch, oracle only (tests/sustained_load_study.py): time constant of the joint-equality ("fix") rows of the lattice; 0 = MuJoCo's
                                    * default solref time constant 0.02 s, which the product uses */
+    double probe_friction2;       /* sliding friction of the probe's SECOND colliding geom, see probe_geoms (MuJoCo default 1.0) */
+    int32_t probe_geoms;          /* 1: one probe geom collides; 2: two coincident ones (ultrasound_probe_gripper.xml:8-9: `probe_collision` AND `probe_visual` -- the
+                                   * latter carries no contype / conaffinity = 0, so with MuJoCo's defaults it collides as well, with the default friction 1.0): every
+                                   * element pair then has two contacts of the same geometry.  Restated as one contact: normal row with half the regulariser (two equal
+                                   * rows in parallel), friction rows of the high-friction contact alone (the other one's cone, mu = 0.01, is saturated at once),
+                                   * cone limit (mu_1 + mu_2) / 2 of the TOTAL normal force */
+    int32_t reserved2_;
 } uso_config;
 
 void  uso_default_config(uso_config* c);

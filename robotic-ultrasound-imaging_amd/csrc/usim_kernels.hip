@@ -479,9 +479,11 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
         f3 nn = mk(EB(b + 0), EB(b + 1), EB(b + 2)), rr = mk(EB(b + 3), EB(b + 4), EB(b + 5));
         const int e = __float_as_int(EB(b + 6));
         const float dist = EB(b + 7);
-        f3 ref = (fabsf(nn.x) > 0.9f) ? mk(0, 1, 0) : mk(1, 0, 0);
-        f3 t1 = cross(nn, ref); t1 = t1 * rsq_(dot(t1, t1));
-        f3 t2 = cross(nn, t1);
+        // tangent frame without a threshold on the normal (Duff et al. 2017; contact normals point from the element towards the probe, n.z > 0): the iterate
+        // of a fixed number of row-by-row sweeps depends on the frame, so float32 and float64 must not be able to choose different ones (oracle: same lines)
+        const float sg = nn.z >= 0.f ? 1.f : -1.f, aa = -rcp_(sg + nn.z), bb = nn.x * nn.y * aa;
+        f3 t1 = mk(1.f + sg * nn.x * nn.x * aa, sg * bb, -sg * nn.x);
+        f3 t2 = mk(bb, sg + nn.y * nn.y * aa, -nn.y);
         f3 ax = mk(lds[TB_AXIS + 3 * e], lds[TB_AXIS + 3 * e + 1], lds[TB_AXIS + 3 * e + 2]);
         const float sde = EB(GE_SD + e);
         const float bcon = 2.0f / (SI_DMAX * SR_TC);
@@ -510,7 +512,7 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
                 wa = fmaf(w[d][a], alpha[a], wa);
             }
             const float aref = -bcon * vrel - (d == 0 ? kk * dist : 0.f);
-            Rd[d] = (d == 0) ? Rn : Rn * (1.0f / IMPRATIO);
+            Rd[d] = (d == 0) ? Rn * C.rn_scale : Rn * (1.0f / IMPRATIO);      // (two colliding probe geoms: two equal normal rows in parallel = half the regulariser)
             cres[d] = fmaf(g[d], ae0, wa) - aref;             // residual of row d at zero force
         }
     }
@@ -832,6 +834,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                     float pf = C.probe_fric;
                     if (C.rand_fric) pf *= 0.5f + 1.5f * u01(Cc.d);
                     mu = fmaxf(pf, C.elem_fric);
+            if (C.probe_geoms == 2) mu = 0.5f * (mu + fmaxf(C.probe_fric2, C.elem_fric));   // two coincident contacts per pair restated as one (usim_config.probe_geoms)
                 }
                 // ================= initial pose: damped-least-squares IK from init_qpos (ultrasound.py:812-844) ==========
                 float uu = clampf(u0, 0.f, 1.f);

@@ -64,7 +64,7 @@ if __name__ == "__main__":
     for a in sys.argv[1:]:
         k, v = a.split("=")
         names.append(k)
-        lists.append([float(x) for x in v.split(",")])
+        lists.append([(int(x) if x.lstrip('-').isdigit() else float(x)) for x in v.split(",")])
     for combo in itertools.product(*lists):
         kw = dict(zip(names, combo))
         o = Oracle(1536, **kw)

@@ -259,27 +259,38 @@ def test_f32_oracle_tracks_f64_oracle():
 
 
 def test_pgs_is_converged_at_default_sweeps():
-    """The default contact schedule -- four full sweeps of the block Gauss-Seidel interleaved with three normal-only sweeps, N N F F N F F --
-    leaves the contact forces within 3e-5 N of the converged solution of the convex problem (measured 1.8e-5 N on forces up to 70 N, where one
-    float32 ulp is 8e-6 N; with the round-2 probe stand-in, whose contact normals were nearly parallel, it was 2.9e-6), in a mixed batch as in
-    the first steps after a synchronous reset; six full sweeps reach 5e-7 N.  (A direct solve of the normal block followed by two or three
-    full sweeps was tried and is two to three orders of magnitude WORSE: the slow modes are the friction rows, whose regulariser is 20 times
-    smaller -- impratio -- not the normal rows.)  With domain-randomised friction of 0.15 .. 0.6 (BASELINE configs[4]) the fixed schedule is
-    0.6 N away from convergence; both sides run the same schedule, which is what the parity tests compare."""
+    """The default contact schedule -- four full sweeps of the block Gauss-Seidel interleaved with three normal-only sweeps, N N F F N F F -- against
+    the converged solution of the convex problem (600 sweeps), in a mixed batch as in the first steps after a synchronous reset.  With the
+    frictionless-in-effect contact of rounds 1-2 (mu = 0.01) the schedule was converged to float32 resolution (1.8e-5 N on 70 N).  Since the second
+    colliding probe geom of the reference's XML is modelled (usim_config.probe_geoms = 2: friction 1.0, i.e. an effective cone of 0.5) the friction rows
+    carry real force and projected Gauss-Seidel converges slowly on them, whatever the order of the sweeps (five plain full sweeps: no better): at the
+    default the typical error is 0.004 - 0.03 N, 1 % of the environments are off by ~1 N and the worst by ~2 N on forces of 50 - 60 N; eight full sweeps
+    (pgs_iters = 8): typical 2e-4 N, 1 %: 0.2 N.  Replays of the reference's trained policy are insensitive to it (reward per step 7.48 / 7.50 / 7.50 at
+    4 / 8 / 16 sweeps, tests/sustained_load_study.py), so the default stays at the cheaper schedule; both sides run the same one, which is what the
+    parity tests compare.  With mu = 0.01 (probe_geoms = 1) the old bound still holds."""
     n = 256
     for pre in (8, 40):
-        ref = Oracle(n, pgs_iters=300)
-        assert Oracle(1).cfg.pgs_iters == 4
+        ref = Oracle(n, pgs_iters=600)
+        assert Oracle(1).cfg.pgs_iters == 4 and Oracle(1).cfg.probe_geoms == 2
         ref.reset()
         for k in range(pre):
             ref.step(ref.random_actions(k))
         st, act = ref.get_state(), ref.random_actions(pre)
         orf = ref.step(act, auto_reset=False)[0]
-        for iters, tol in ((4, 3e-5), (6, 1e-6)):
+        assert np.abs(orf[:, :3]).max() > 20.0
+        for iters, typical, q99, worst in ((4, 0.05, 1.5, 3.5), (8, 1e-3, 0.35, 1.0), (32, 1e-6, 5e-3, 1e-2)):
             d = Oracle(n, pgs_iters=iters)
             d.reset(); d.set_state(st)
-            od = d.step(act, auto_reset=False)[0]
-            assert np.abs(orf[:, :3]).max() > 20.0 and np.abs(od[:, :3] - orf[:, :3]).max() < tol, (pre, iters)
+            e = np.abs(d.step(act, auto_reset=False)[0][:, :3] - orf[:, :3]).max(1)
+            assert np.median(e[np.abs(orf[:, 2]) > 0]) < typical and np.quantile(e, 0.99) < q99 and e.max() < worst, (pre, iters, np.median(e), np.quantile(e, 0.99), e.max())
+    # a single probe geom (the collision geom's friction 1e-4 against the elements' 0.01): converged to float32 resolution at the default
+    ref = Oracle(n, pgs_iters=300, probe_geoms=1); ref.reset()
+    for k in range(8):
+        ref.step(ref.random_actions(k))
+    st, act = ref.get_state(), ref.random_actions(8)
+    orf = ref.step(act, auto_reset=False)[0]
+    d = Oracle(n, pgs_iters=4, probe_geoms=1); d.reset(); d.set_state(st)
+    assert np.abs(d.step(act, auto_reset=False)[0][:, :3] - orf[:, :3]).max() < 1e-4
 
 
 def test_oracle_is_clean_under_asan_and_ubsan():
