@@ -862,16 +862,16 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
                 int e = out->con_el[c];
                 real dir[3][3];
                 v3cpy(dir[0], cn[c]);
-                /* tangent frame without a case distinction in the range the normals live in (Duff et al. 2017: continuous except at n.z = -1; contact normals
-                 * point from the element towards the probe, n.z > 0).  The converged friction force does not depend on the frame (isotropic cone, equal
+                /* tangent frame without a case distinction (Frisvad 2012: continuous on the whole sphere except at n.z = -1; contact normals point from the
+                 * element towards the probe -- an element sits below or beside the probe, never above it).  The converged friction force does not depend on the frame (isotropic cone, equal
                  * regularisers), but the iterate after a fixed number of row-by-row sweeps does: a frame chosen by comparing |n.x| with a threshold -- the
                  * first form -- made float32 and float64 pick different frames on the blade's flanks (n.x ~ 0.85) and disagree by 0.1 N once friction
                  * mattered (probe_geoms = 2) */
                 {
                     const real nx = cn[c][0], ny = cn[c][1], nz = cn[c][2];
-                    const real sg = nz >= 0 ? (real)1 : (real)-1, aa = -1 / (sg + nz), bb = nx * ny * aa;
-                    v3set(dir[1], 1 + sg * nx * nx * aa, sg * bb, -sg * nx);
-                    v3set(dir[2], bb, sg + ny * ny * aa, -ny);
+                    const real aa = -1 / (1 + nz), bb = nx * ny * aa;
+                    v3set(dir[1], 1 + nx * nx * aa, bb, -nx);
+                    v3set(dir[2], bb, 1 + ny * ny * aa, -ny);
                 }
                 real r[3]; v3sub(r, cp[c], k->x);
                 /* impedance d(r) (solimp .9 .95 .001 .5 2) */

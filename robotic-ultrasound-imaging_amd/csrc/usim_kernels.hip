@@ -479,11 +479,12 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
         f3 nn = mk(EB(b + 0), EB(b + 1), EB(b + 2)), rr = mk(EB(b + 3), EB(b + 4), EB(b + 5));
         const int e = __float_as_int(EB(b + 6));
         const float dist = EB(b + 7);
-        // tangent frame without a threshold on the normal (Duff et al. 2017; contact normals point from the element towards the probe, n.z > 0): the iterate
-        // of a fixed number of row-by-row sweeps depends on the frame, so float32 and float64 must not be able to choose different ones (oracle: same lines)
-        const float sg = nn.z >= 0.f ? 1.f : -1.f, aa = -rcp_(sg + nn.z), bb = nn.x * nn.y * aa;
-        f3 t1 = mk(1.f + sg * nn.x * nn.x * aa, sg * bb, -sg * nn.x);
-        f3 t2 = mk(bb, sg + nn.y * nn.y * aa, -nn.y);
+        // tangent frame without a case distinction (Frisvad 2012: continuous except at n.z = -1; contact normals point from the element towards the probe,
+        // and no element sits above it): the iterate of a fixed number of row-by-row sweeps depends on the frame, so float32 and float64 must not be able
+        // to choose different ones (oracle: same lines)
+        const float aa = -rcp_(1.f + nn.z), bb = nn.x * nn.y * aa;
+        f3 t1 = mk(1.f + nn.x * nn.x * aa, bb, -nn.x);
+        f3 t2 = mk(bb, 1.f + nn.y * nn.y * aa, -nn.y);
         f3 ax = mk(lds[TB_AXIS + 3 * e], lds[TB_AXIS + 3 * e + 1], lds[TB_AXIS + 3 * e + 2]);
         const float sde = EB(GE_SD + e);
         const float bcon = 2.0f / (SI_DMAX * SR_TC);

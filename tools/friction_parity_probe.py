@@ -4,7 +4,7 @@ sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 usim = importlib.import_module("robotic-ultrasound-imaging_amd")
 from oracle_lib import Oracle
 mode = sys.argv[1] if len(sys.argv) > 1 else "fixed"
-n = 256
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 kw = usim.default_robosuite_kwargs(); kw["controller_configs"] = dict(kw["controller_configs"], impedance_mode=mode)
 env = usim.UltrasoundVecEnv(n, device="cuda:0", seed=3, torso="soft", **kw)
 ora = Oracle(n, mode={"tracking":0,"fixed":1,"variable_z":2,"wrench":3}[mode], torso="top", seed=3)
