@@ -63,6 +63,6 @@ for it in range(iters):
             loss = pg + 0.5 * vf - 0.0 * ent.mean()
             opt.zero_grad(); loss.backward(); torch.nn.utils.clip_grad_norm_(policy.parameters(), 0.5); opt.step()
     print(f"iter {it:3d}  env-steps {(it + 1) * n * T:9d}  reward/step {float(raw) / (n * T):6.3f}  value loss {float(vf.detach()):7.4f}  "
-          f"std {float(torch.exp(policy.log_std).mean()):5.3f}  wall {time.time() - t0:6.1f}s  (collecting {t_collect:5.2f}s)", flush=True)
+          f"std {float(torch.exp(policy.log_std.detach()).mean()):5.3f}  wall {time.time() - t0:6.1f}s  (collecting {t_collect:5.2f}s)", flush=True)
 print(f"collection: {iters * n * T / t_collect / 1e6:.1f} M env-steps/s; with the PPO updates: {iters * n * T / (time.time() - t0) / 1e6:.2f} M env-steps/s")
 env.close()
