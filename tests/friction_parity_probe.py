@@ -1,6 +1,8 @@
 import importlib, sys
 import numpy as np, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 usim = importlib.import_module("robotic-ultrasound-imaging_amd")
 from oracle_lib import Oracle
 mode = sys.argv[1] if len(sys.argv) > 1 else "fixed"
