@@ -235,14 +235,16 @@ typedef struct usim_policy_out {
  * observations are obs_dev [n][19].  prev_done_dev [n]: done flags of the previous step (NULL: every environment starts an episode).  The Gaussian
  * noise comes from a counter-based stream keyed (seed, env_offset + env, counter + *counter_base_dev): a new value per call -- counter from the host,
  * counter_base_dev (may be NULL) a device word that a recorded sequence of calls (HIP graph) advances between replays.  deterministic != 0: the
- * mean action. */
+ * mean action.  training: 0 = statistics frozen, 1 = update them with obs_dev first, 2 = they already contain obs_dev (see usim_policy_reward). */
 int usim_policy_step(const usim_policy_net* net, const usim_norm_stats* st, const float* obs_dev, const uint8_t* prev_done_dev, int n, int act_dim,
                      const float* act_low_dev, const float* act_high_dev, uint64_t seed, uint32_t counter, const uint32_t* counter_base_dev, int env_offset,
                      int training, int deterministic, const usim_policy_out* out, void* stream);
 /* VecNormalize's reward side after the env step: returns = gamma returns + rew, RunningMeanStd.update(returns), nrew = clip(rew / sqrt(ret_var + eps)),
- * returns reset where done.  raw_sum_dev (may be NULL): += sum of the raw rewards. */
+ * returns reset where done.  raw_sum_dev (may be NULL): += sum of the raw rewards.  next_obs_dev (may be NULL; used when training): the observation the step
+ * returned -- its RunningMeanStd.update is made in the same launch (as VecNormalize.step_wait does, before the observation is normalised); the
+ * usim_policy_step that consumes that observation is then called with training = 2 ("statistics already updated with this observation"). */
 int usim_policy_reward(const usim_norm_stats* st, const float* rew_dev, const uint8_t* done_dev, int n, int training, int norm_reward, float* nrew_dev,
-                       double* raw_sum_dev, void* stream);
+                       double* raw_sum_dev, const float* next_obs_dev, void* stream);
 /* RolloutBuffer.compute_returns_and_advantage over [T][n] buffers (GAE(lambda), SB3's recursion) */
 int usim_policy_gae(const float* rewards_dev, const float* values_dev, const float* episode_starts_dev, const float* last_values_dev, const uint8_t* last_done_dev,
                     int T, int n, float gamma, float gae_lambda, float* advantages_dev, float* returns_dev, void* stream);

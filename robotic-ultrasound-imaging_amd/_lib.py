@@ -60,7 +60,7 @@ class UsimPolicyOut(C.Structure):
 SYMBOLS = {
     "usim_policy_step": (C.c_int, [C.POINTER(UsimPolicyNet), C.POINTER(UsimNormStats), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_uint64, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(UsimPolicyOut), C.c_void_p]),
-    "usim_policy_reward": (C.c_int, [C.POINTER(UsimNormStats), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "usim_policy_reward": (C.c_int, [C.POINTER(UsimNormStats), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "usim_policy_gae": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
     "usim_default_config": (C.c_int, [C.POINTER(UsimConfig)]),

@@ -51,26 +51,29 @@ DI double block_sum(double v, double* red) {
 // finishes last adds the partials in a fixed order -- the result does not depend on which one that is -- and merges the batch moments into the
 // running statistics (parallel-variance update of RunningMeanStd.update_from_moments).
 constexpr int PL_SB = 32, PL_ST = 128;                           // workgroups, threads per workgroup
-__global__ __launch_bounds__(PL_ST) void usim_policy_obs_stats_kernel(const float* __restrict__ obs, int n, NormStats S, double* __restrict__ part,
-                                                                      unsigned int* __restrict__ arrived) {
-    __shared__ double tabx[PL_OBS][PL_ST], tabq[PL_OBS][PL_ST];
-    __shared__ bool last;
+struct ObsStatsLds { double tabx[PL_OBS][PL_ST], tabq[PL_OBS][PL_ST]; bool last; };
+DI void obs_stats_body(ObsStatsLds& L, const float* __restrict__ obs, int n, const NormStats& S, double* __restrict__ part, unsigned int* __restrict__ arrived) {
+    // (executed by the first PL_ST threads of workgroups 0 .. PL_SB - 1; every barrier below is passed by all of them)
+    double (&tabx)[PL_OBS][PL_ST] = L.tabx; double (&tabq)[PL_OBS][PL_ST] = L.tabq; bool& last = L.last;
     const int t = threadIdx.x, total = n * PL_OBS;
     const int per = ((total + PL_SB - 1) / PL_SB + PL_OBS - 1) / PL_OBS * PL_OBS;      // a multiple of 19: every slice starts at channel 0
     const int lo = blockIdx.x * per, hi = min(total, lo + per);
+    const bool act = t < PL_ST;                                    // (a workgroup may bring more threads than the PL_ST that work here)
     double sx[PL_OBS], sq[PL_OBS];
 #pragma unroll
     for (int j = 0; j < PL_OBS; ++j) { sx[j] = 0.0; sq[j] = 0.0; }
-    for (int b = lo; b < hi; b += PL_ST * PL_OBS) {
+    if (act) {
+        for (int b = lo; b < hi; b += PL_ST * PL_OBS) {
 #pragma unroll
-        for (int j = 0; j < PL_OBS; ++j) {
-            const int w = b + t + PL_ST * j;
-            const double x = (w < hi) ? (double)obs[w] : 0.0;
-            sx[j] += x; sq[j] += x * x;
+            for (int j = 0; j < PL_OBS; ++j) {
+                const int w = b + t + PL_ST * j;
+                const double x = (w < hi) ? (double)obs[w] : 0.0;
+                sx[j] += x; sq[j] += x * x;
+            }
         }
-    }
 #pragma unroll
-    for (int j = 0; j < PL_OBS; ++j) { const int ch = (t + PL_ST * j) % PL_OBS; tabx[ch][t] = sx[j]; tabq[ch][t] = sq[j]; }
+        for (int j = 0; j < PL_OBS; ++j) { const int ch = (t + PL_ST * j) % PL_OBS; tabx[ch][t] = sx[j]; tabq[ch][t] = sq[j]; }
+    }
     __syncthreads();
     if (t < PL_OBS * 4) {                                          // four lanes per channel, 32 table entries each, combined in a fixed order
         const int c = t >> 2, seg = t & 3;
@@ -100,6 +103,11 @@ __global__ __launch_bounds__(PL_ST) void usim_policy_obs_stats_kernel(const floa
     }
     __syncthreads();
     if (t == 0) { *S.obs_count += n; *arrived = 0u; }
+}
+__global__ __launch_bounds__(PL_ST) void usim_policy_obs_stats_kernel(const float* __restrict__ obs, int n, NormStats S, double* __restrict__ part,
+                                                                      unsigned int* __restrict__ arrived) {
+    __shared__ ObsStatsLds L;
+    obs_stats_body(L, obs, n, S, part, arrived);
 }
 
 typedef float v4f_ __attribute__((ext_vector_type(4)));
@@ -258,10 +266,10 @@ __global__ __launch_bounds__(256) void usim_policy_act_kernel(PolicyNet P, NormS
 
 // VecNormalize.step_wait after the env step: returns = gamma returns + reward; RunningMeanStd.update(returns); normalised, clipped reward; returns
 // reset where an episode ended.  One workgroup, one pass over the batch (sum r, sum r^2, sum of the raw rewards reduced together).
-__global__ __launch_bounds__(1024) void usim_policy_reward_kernel(const float* __restrict__ rew, const uint8_t* __restrict__ done, int n, NormStats S, int training,
-                                                                  int norm_reward, float* __restrict__ nrew_out, double* __restrict__ raw_sum) {
-    __shared__ double red[3][16];
-    __shared__ double scale;
+struct RewardLds { double red[3][16]; double scale; };
+DI void reward_body(RewardLds& L, const float* __restrict__ rew, const uint8_t* __restrict__ done, int n, const NormStats& S, int training,
+                    int norm_reward, float* __restrict__ nrew_out, double* __restrict__ raw_sum) {
+    double (&red)[3][16] = L.red; double& scale = L.scale;
     double raw = 0.0, s = 0.0, q = 0.0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const double rw = (double)rew[i];
@@ -291,6 +299,21 @@ __global__ __launch_bounds__(1024) void usim_policy_reward_kernel(const float* _
         if (norm_reward) { v *= sc; v = v < -S.clip_reward ? -S.clip_reward : (v > S.clip_reward ? S.clip_reward : v); }
         nrew_out[i] = (float)v;
     }
+}
+__global__ __launch_bounds__(1024) void usim_policy_reward_kernel(const float* __restrict__ rew, const uint8_t* __restrict__ done, int n, NormStats S, int training,
+                                                                  int norm_reward, float* __restrict__ nrew_out, double* __restrict__ raw_sum) {
+    __shared__ RewardLds L;
+    reward_body(L, rew, done, n, S, training, norm_reward, nrew_out, raw_sum);
+}
+// Both halves of VecNormalize.step_wait in ONE launch: workgroups 0 .. PL_SB - 1 update the observation statistics with the observation the step just
+// produced (the policy kernel of the next step then only normalises: usim_policy_step training = 2), workgroup PL_SB does the reward side.  Two tiny,
+// latency-bound kernels (11 + 7 us) become one.
+__global__ __launch_bounds__(1024) void usim_policy_post_kernel(const float* __restrict__ rew, const uint8_t* __restrict__ done, int n, NormStats S, int training,
+                                                                int norm_reward, float* __restrict__ nrew_out, double* __restrict__ raw_sum,
+                                                                const float* __restrict__ next_obs, double* __restrict__ part, unsigned int* __restrict__ arrived) {
+    __shared__ union { ObsStatsLds a; RewardLds b; } L;
+    if (blockIdx.x < PL_SB) obs_stats_body(L.a, next_obs, n, S, part, arrived);
+    else reward_body(L.b, rew, done, n, S, training, norm_reward, nrew_out, raw_sum);
 }
 
 // RolloutBuffer.compute_returns_and_advantage: one thread per environment walks its column of the [T][n] buffers backwards
@@ -322,7 +345,7 @@ int usim_policy_step(const usim_policy_net* net, const usim_norm_stats* st, cons
     hipStream_t s = (hipStream_t)stream;
     PolicyNet P{net->pi_w1, net->pi_b1, net->pi_w2, net->pi_b2, net->act_w, net->act_b, net->vf_w1, net->vf_b1, net->vf_w2, net->vf_b2, net->val_w, net->val_b, net->log_std};
     NormStats S{st->obs_mean, st->obs_var, st->obs_count, st->ret_mean, st->ret_var, st->ret_count, st->returns, st->clip_obs, st->clip_reward, st->gamma, st->epsilon};
-    if (training) {
+    if (training == 1) {
         if (!st->scratch) return USIM_ERR_INVALID;
         // scratch: PL_SB x 19 x 2 partial sums, then the arrival counter (zero on entry, left zero)
         hipLaunchKernelGGL(usim_policy_obs_stats_kernel, dim3(PL_SB), dim3(PL_ST), 0, s, obs_dev, n, S, st->scratch, reinterpret_cast<unsigned int*>(st->scratch + PL_SB * PL_OBS * 2));
@@ -334,10 +357,15 @@ int usim_policy_step(const usim_policy_net* net, const usim_norm_stats* st, cons
 }
 
 int usim_policy_reward(const usim_norm_stats* st, const float* rew_dev, const uint8_t* done_dev, int n, int training, int norm_reward, float* nrew_dev,
-                       double* raw_sum_dev, void* stream) {
+                       double* raw_sum_dev, const float* next_obs_dev, void* stream) {
     using namespace usim;
     if (!st || !rew_dev || !done_dev || !nrew_dev || n <= 0) return USIM_ERR_INVALID;
     NormStats S{st->obs_mean, st->obs_var, st->obs_count, st->ret_mean, st->ret_var, st->ret_count, st->returns, st->clip_obs, st->clip_reward, st->gamma, st->epsilon};
+    if (next_obs_dev && training) {
+        if (!st->scratch) return USIM_ERR_INVALID;
+        hipLaunchKernelGGL(usim_policy_post_kernel, dim3(PL_SB + 1), dim3(1024), 0, (hipStream_t)stream, rew_dev, done_dev, n, S, training, norm_reward, nrew_dev, raw_sum_dev,
+                           next_obs_dev, st->scratch, reinterpret_cast<unsigned int*>(st->scratch + PL_SB * PL_OBS * 2));
+    } else
     hipLaunchKernelGGL(usim_policy_reward_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rew_dev, done_dev, n, S, training, norm_reward, nrew_dev, raw_sum_dev);
     return hipGetLastError() == hipSuccess ? USIM_OK : USIM_ERR_HIP;
 }

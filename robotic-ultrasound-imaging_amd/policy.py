@@ -523,6 +523,8 @@ class FusedRollout:
         self.obs = env.reset_tensor()                                                       # the env's own observation buffer: rewritten by every step
         self._prev_done = env._done                                                         # ... and its done flags: read by the policy kernel BEFORE the next step rewrites them
         self._prev_done.fill_(1)                                                            # every environment starts an episode
+        if vecnorm.training:                                                                # VecNormalize.reset(): the statistics see the reset observation
+            self.act(self.obs, self._prev_done, counter=0, training=1, deterministic=True)
         self.graph = None
         if graph:
             side = torch.cuda.Stream(device=dev)
@@ -548,7 +550,7 @@ class FusedRollout:
         out = _lib.UsimPolicyOut(ptr(self._act_env), None if t is None else ptr(b.observations[t]), None if t is None else ptr(b.actions[t]),
                                  ptr(self._value) if t is None else ptr(b.values[t]), None if t is None else ptr(b.log_probs[t]), None if t is None else ptr(b.episode_starts[t]))
         self._check(self.lib.usim_policy_step(C.byref(self._net), C.byref(self._stats), ptr(obs), ptr(prev_done), env.num_envs, env.action_dim, ptr(self._low), ptr(self._high),
-                                              self.seed, int(counter) & 0xffffffff, ptr(self._ctr), int(getattr(env, "env_offset", 0)), int(bool(training)),
+                                              self.seed, int(counter) & 0xffffffff, ptr(self._ctr), int(getattr(env, "env_offset", 0)), int(training),
                                               int(bool(deterministic)), C.byref(out), env._stream()))
         return self._act_env, (self._value if t is None else b.values[t])
 
@@ -558,13 +560,15 @@ class FusedRollout:
         env, b, vn = self.env, self.buffer, self.vecnorm
         T, n = b.buffer_size, env.num_envs
         self.raw_reward_sum.zero_()
+        # The observation statistics follow VecNormalize's timing: RunningMeanStd.update(obs) when the environment RETURNS the observation (reset: once, in
+        # __init__; step: in the launch that also does the reward side), so the policy kernel only normalises (training = 2) and the bootstrap value sees
+        # statistics that include the last observation, as SB3's `_last_obs` does.
         for t in range(T):
-            self.act(self.obs, self._prev_done, counter=t, t=t)
+            self.act(self.obs, self._prev_done, counter=t, training=2 if vn.training else 0, t=t)
             o, rew, done = env.step_tensor(self._act_env)
             self._check(self.lib.usim_policy_reward(C.byref(self._stats), rew.data_ptr(), done.data_ptr(), n, int(bool(vn.training)), int(bool(vn.norm_reward)),
-                                                    b.rewards[t].data_ptr(), self.raw_reward_sum.data_ptr(), env._stream()))
-        # bootstrap with the value of the last observation, statistics frozen (collect_rollouts does the same)
-        self.act(self.obs, self._prev_done, counter=T, training=False, deterministic=True)
+                                                    b.rewards[t].data_ptr(), self.raw_reward_sum.data_ptr(), o.data_ptr() if vn.training else None, env._stream()))
+        self.act(self.obs, self._prev_done, counter=T, training=0, deterministic=True)
         self._check(self.lib.usim_policy_gae(b.rewards.data_ptr(), b.values.data_ptr(), b.episode_starts.data_ptr(), self._value.data_ptr(), self._prev_done.data_ptr(),
                                              T, n, b.gamma, b.gae_lambda, b.advantages.data_ptr(), b.returns.data_ptr(), env._stream()))
         self._ctr.add_(T + 1)

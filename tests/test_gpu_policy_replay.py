@@ -218,6 +218,8 @@ def test_fused_policy_kernels_match_the_torch_policy(usim, pins):
         vn, twin = (pol.DeviceVecNormalize(n, 19, device=dev, training=True, norm_reward=True) for _ in range(2))
         buf = pol.DeviceRolloutBuffer(T, n, 19, env.action_dim, device=dev)
         fr = pol.FusedRollout(env, policy, vn, buf, seed=5, graph=False)
+        twin.normalize_obs(fr.obs)                                          # (the constructor shows the reset observation to the statistics, as VecNormalize.reset does)
+        assert torch.allclose(vn.obs_mean, twin.obs_mean, rtol=1e-12, atol=1e-14) and abs(vn.obs_count - twin.obs_count) < 1e-9
         env.reset_tensor(); env.rollout_random(0, 40)
         obs = env.step_tensor(env.random_actions_tensor(40))[0].clone()
         prev_done = (torch.rand(n, device=dev) < 0.3).to(torch.uint8)
@@ -253,8 +255,13 @@ def test_fused_policy_kernels_match_the_torch_policy(usim, pins):
         for k in range(3):
             rew, done = torch.rand(n, device=dev) * 9, (torch.rand(n, device=dev) < 0.2).to(torch.uint8)
             out = torch.zeros(n, device=dev)
-            assert lib.usim_policy_reward(C.byref(fr._stats), rew.data_ptr(), done.data_ptr(), n, 1, 1, out.data_ptr(), fr.raw_reward_sum.data_ptr(), env._stream()) == 0
+            nxt = torch.randn(n, 19, device=dev) * (k + 1.0) if k else None    # k > 0: the statistics of the next observation in the same launch
+            assert lib.usim_policy_reward(C.byref(fr._stats), rew.data_ptr(), done.data_ptr(), n, 1, 1, out.data_ptr(), fr.raw_reward_sum.data_ptr(),
+                                          None if nxt is None else nxt.data_ptr(), env._stream()) == 0
             ref = twin.normalize_reward(rew, done)
+            if nxt is not None:
+                twin.normalize_obs(nxt)
+                assert torch.allclose(vn.obs_mean, twin.obs_mean, rtol=1e-11, atol=1e-13) and torch.allclose(vn.obs_var, twin.obs_var, rtol=1e-10) and abs(vn.obs_count - twin.obs_count) < 1e-9
             assert torch.allclose(out, ref, atol=1e-6) and torch.allclose(vn.returns, twin.returns, rtol=1e-13)
             assert torch.allclose(vn.ret_var, twin.ret_var, rtol=1e-11) and torch.allclose(vn.ret_mean, twin.ret_mean, rtol=1e-11) and abs(vn.ret_count - twin.ret_count) < 1e-9
         # GAE
