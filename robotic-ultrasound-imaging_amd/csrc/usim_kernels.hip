@@ -276,7 +276,8 @@ DI void contact_overflow(float* lds, const int eb, const int gl, const int gbase
 // Lattice front end of one forward pass, executed by the G lanes of a group on the group's LDS block: stage (s, sdot), build
 // the right-hand side of the soft-equality system, a~ = Linv rhs, collide the probe capsule with the 99 cap spheres and
 // leave the contact records (ascending shell id; the MAXC deepest when more were found) in LDS.  Returns the number found (may exceed MAXC).
-// PART 0: everything; 1: staging + right-hand side only (needs no arm quantity); 2: solve + collision only (after a PART 1 call).
+// PART 0: everything; 1: staging + right-hand side only (needs no arm quantity); 2: solve + collision only (after a PART 1 call); 3: solve only
+// (needs no arm quantity either: the split kernel's lattice side runs it while it would otherwise wait for the site pose); 4: collision only (after PART 3).
 template <int G, int NE, bool MM, int PART = 0, bool QM = false>
 DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, const DevModel& M, const DevCfg& C, const int tsim,
                      const float kst, const float kdmp, const bool live, const float* s_pre, const float* sd_pre,
@@ -289,7 +290,7 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
 #define EBF(off) lds[TB_WORDS + eb * GE_STRIDE + (off)]
     float dz, vz, az;
     torso_motion(C, tsim, dz, vz, az);
-                    if constexpr (PART != 2) {
+                    if constexpr (PART == 0 || PART == 1) {
                                     // ---- stage s, sdot and the spring-damper potential u = k_t s + b_t sdot: lane gl of the group owns elements
                     //      gl, gl+G, ...  u goes into a zero-bordered 11 x 13 copy of the 9 x 11 grid, so that the four neighbours of an
                     //      element are four unconditional reads; a pinned rim neighbour (s = 0) is a border cell.
@@ -359,12 +360,14 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                         group_sync();                                      // the queue area is rewritten by the solve's result
                     };
                     auto collide_round = [&](const int i) {
-                        if (i != 0) return;
+                        if (i != 0 || PART == 3) return;
                         if constexpr (QM) collide_queue<G>(lds, queue, q0, q1, &EBF(GE_CG), gl, gbase, M, C, &EBF(GE_S), dz, Kx, Ksx, Ksy, Ksz, nc);
                         else collide_all();
                     };
                                     // ---- a~ = Linv * rhs ----
-                    if constexpr (MM) {
+                    if constexpr (PART == 4) {
+                        collide_round(0);
+                    } else if constexpr (MM) {
                         // Matrix-core form (every lane of the wave is active here): the wave's environments are the columns of one dense
                         // product A~[99 x EPW] = Linv[99 x 100] X[100 x EPW], issued as v_mfma_f32_4x4x1 (16 blocks of 4 rows x 4 columns
                         // per instruction).  Lane l feeds Linv row l (and row 64 + l) as the A operand and the rhs of environment l % 4 as
@@ -446,7 +449,7 @@ DI int lattice_front(float* lds, const int eb, const int gl, const int gbase, co
                         }
                         LSTAMP(6);
                     }
-                    if constexpr (!QM) contact_overflow<G>(lds, eb, gl, gbase, nc);
+                    if constexpr (!QM && PART != 3) contact_overflow<G>(lds, eb, gl, gbase, nc);
     return nc;
 #undef EBF
 #undef LSTAMP

@@ -448,6 +448,12 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         float dz, vz, az;
         torso_motion(C, tsim, dz, vz, az);
         lattice_front<G, NE, true, 1>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, true, s_pre, sd_pre, mk(0, 0, 0), mk(0, 0, 0), mk(0, 0, 0), dbg);
+        // The matrix-core solve a~ = Linv rhs needs nothing from the arm side: it runs here, where this wave used to wait for the site pose (hand-off (1)
+        // comes when the arm side has finished its kinematics and the broad phase), and leaves only the narrow phase for after the hand-off: one box,
+        // 14.38 -> 13.65 us/step at 4096 envs, 20.8 -> 20.2 at 8192 (8-lane groups).  Splitting the product around the hand-off so that both sides reach
+        // hand-offs (1) and (2) together (18 / 14 / 21 of the 25 k chunks before it, accumulators live across the barrier) is slower: 13.9 / 14.1 / 13.85,
+        // and with 8-lane groups the accumulators of both column sets spill (44 us).
+        lattice_front<G, NE, true, 3, true>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, true, s_pre, sd_pre, mk(0, 0, 0), mk(0, 0, 0), mk(0, 0, 0), dbg);
         RSTAMP(1);
         USIM_BAR();                                                 // (1) the arm side has published the site pose
         RSTAMP(2);
@@ -468,7 +474,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
             group_sync();
         }
         const int na = (__float_as_int(mb[MB_POSE + 10]) * arm_share_num<G>() + ARM_SHARE_DEN - 1) / ARM_SHARE_DEN;
-        const int ncl = lattice_front<G, NE, true, 2, true>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, true, s_pre, sd_pre, xs, sy, sz, dbg, mb + MB_Q, na, nq);
+        const int ncl = lattice_front<G, NE, true, 4, true>(lds, eb, gl, gbase, M, C, tsim, kst, kdmp, true, s_pre, sd_pre, xs, sy, sz, dbg, mb + MB_Q, na, nq);
         RSTAMP(3);
         USIM_BAR();                                                 // (2) ... and Lambda^-1, alpha = J qs, vs = J qd, and the arm side's contact records
         RSTAMP(4);
