@@ -239,6 +239,25 @@ typedef struct usim_policy_out {
 int usim_policy_step(const usim_policy_net* net, const usim_norm_stats* st, const float* obs_dev, const uint8_t* prev_done_dev, int n, int act_dim,
                      const float* act_low_dev, const float* act_high_dev, uint64_t seed, uint32_t counter, const uint32_t* counter_base_dev, int env_offset,
                      int training, int deterministic, const usim_policy_out* out, void* stream);
+/* The same step with BOTH halves of VecNormalize.step_wait inside the policy launch (two launches per rollout step: this one and usim_step), statistics
+ * updated in place.  update_obs: RunningMeanStd.update(obs_dev) before it is normalised (the observation an env step returned; 0 where the statistics have
+ * already seen obs_dev).  have_prev: the reward side of the step BEFORE this observation -- rew_prev_dev / done_prev_dev [n] (the env's buffers, not yet
+ * overwritten), nrew_prev_dev [n] receives the normalised reward; raw_sum_dev (may be NULL) += the sum of the raw rewards.  The workgroups exchange their
+ * partial sums inside the launch and wait for one another (bounded), which needs all of them resident: n <= USIM_POLICY_FUSED_MAX_ENVS, else
+ * USIM_ERR_UNSUPPORTED (use usim_policy_step + usim_policy_reward), and nothing else running on the device beside the launch.  work_dev: USIM_POLICY_FUSED_WORK(n)
+ * doubles, zero-initialised once; counter + *counter_base_dev must not repeat for a workspace (it stamps the arrival flags).  After a synchronisation,
+ * the 32-bit word behind the 2 x USIM_POLICY_FUSED_ROWS(n) flags that follow the rows is non-zero if a wait ever ran out. */
+#define USIM_POLICY_FUSED_MAX_ENVS 8192
+#define USIM_POLICY_FUSED_ROWS(n) (((n) + 31) / 32)
+#define USIM_POLICY_FUSED_WORK(n) (USIM_POLICY_FUSED_ROWS(n) * 49 + 2)
+typedef struct usim_policy_fused {
+    double* work_dev;                /* USIM_POLICY_FUSED_WORK(n) doubles: one row of 48 per 32 environments (partial sums), then the arrival flags and a status word */
+    const float* rew_prev_dev; const uint8_t* done_prev_dev; float* nrew_prev_dev; double* raw_sum_dev;
+    int32_t update_obs, have_prev, norm_reward, reserved_;
+} usim_policy_fused;
+int usim_policy_step_fused(const usim_policy_net* net, const usim_norm_stats* st, const usim_policy_fused* f, const float* obs_dev, const uint8_t* prev_done_dev, int n,
+                           int act_dim, const float* act_low_dev, const float* act_high_dev, uint64_t seed, uint32_t counter, const uint32_t* counter_base_dev,
+                           int env_offset, int deterministic, const usim_policy_out* out, void* stream);
 /* VecNormalize's reward side after the env step: returns = gamma returns + rew, RunningMeanStd.update(returns), nrew = clip(rew / sqrt(ret_var + eps)),
  * returns reset where done.  raw_sum_dev (may be NULL): += sum of the raw rewards.  next_obs_dev (may be NULL; used when training): the observation the step
  * returned -- its RunningMeanStd.update is made in the same launch (as VecNormalize.step_wait does, before the observation is normalised); the

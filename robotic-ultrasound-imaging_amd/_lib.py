@@ -56,8 +56,16 @@ class UsimPolicyOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("act_env_dev", "nobs_dev", "act_dev", "value_dev", "logp_dev", "episode_start_dev")]
 
 
+class UsimPolicyFused(C.Structure):
+    """struct usim_policy_fused (include/usim.h)"""
+    _fields_ = [(n, C.c_void_p) for n in ("work_dev", "rew_prev_dev", "done_prev_dev", "nrew_prev_dev", "raw_sum_dev")] + \
+               [(n, C.c_int32) for n in ("update_obs", "have_prev", "norm_reward", "reserved_")]
+
+
 # every exported symbol of include/usim.h: name -> (restype, argtypes)
 SYMBOLS = {
+    "usim_policy_step_fused": (C.c_int, [C.POINTER(UsimPolicyNet), C.POINTER(UsimNormStats), C.POINTER(UsimPolicyFused), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.POINTER(UsimPolicyOut), C.c_void_p]),
     "usim_policy_step": (C.c_int, [C.POINTER(UsimPolicyNet), C.POINTER(UsimNormStats), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_uint64, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(UsimPolicyOut), C.c_void_p]),
     "usim_policy_reward": (C.c_int, [C.POINTER(UsimNormStats), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

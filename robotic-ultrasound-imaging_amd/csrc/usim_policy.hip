@@ -32,6 +32,9 @@ struct NormStats {                                       // policy.DeviceVecNorm
     double clip_obs, clip_reward, gamma, epsilon;
 };
 
+DI double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DI void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 DI double block_sum(double v, double* red) {
     // sum over the workgroup (any size that is a multiple of 64): wave reduction by DPP-free shuffles, then the wave sums through LDS
 #pragma unroll
@@ -81,18 +84,19 @@ DI void obs_stats_body(ObsStatsLds& L, const float* __restrict__ obs, int n, con
 #pragma unroll 8
         for (int k = seg * (PL_ST / 4); k < (seg + 1) * (PL_ST / 4); ++k) { a += tabx[c][k]; b += tabq[c][k]; }
         a += __shfl_xor(a, 1); b += __shfl_xor(b, 1); a += __shfl_xor(a, 2); b += __shfl_xor(b, 2);
-        if (seg == 0) { part[(blockIdx.x * PL_OBS + c) * 2] = a; part[(blockIdx.x * PL_OBS + c) * 2 + 1] = b; }
+        if (seg == 0) { st_agent(&part[(blockIdx.x * PL_OBS + c) * 2], a); st_agent(&part[(blockIdx.x * PL_OBS + c) * 2 + 1], b); }
     }
-    __threadfence();
+    // (no __threadfence: a device-scope fence writes back / invalidates the XCD's L2 once per wave; the partial sums travel as device-scope accesses and the
+    //  arrival count follows them in program order -- see the fused policy kernel below)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t == 0) last = atomicAdd(arrived, 1u) == (unsigned)(PL_SB - 1);
+    if (t == 0) last = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(PL_SB - 1);
     __syncthreads();
     if (!last) return;
-    __threadfence();
     if (t < PL_OBS) {
         double2 pp[PL_SB];                                        // all loads first (independent), then the sums in a fixed order
 #pragma unroll
-        for (int k = 0; k < PL_SB; ++k) pp[k] = *reinterpret_cast<const double2*>(&part[(k * PL_OBS + t) * 2]);
+        for (int k = 0; k < PL_SB; ++k) pp[k] = make_double2(ld_agent(&part[(k * PL_OBS + t) * 2]), ld_agent(&part[(k * PL_OBS + t) * 2 + 1]));
         double a = 0.0, b = 0.0;
 #pragma unroll
         for (int k = 0; k < PL_SB; ++k) { a += pp[k].x; b += pp[k].y; }
@@ -123,12 +127,34 @@ DI float tanh_(float x) { const float e = __builtin_amdgcn_exp2f(x * 2.885390081
 // Matrix-core layout (v_mfma_f32_16x16x4_f32): lane l supplies A[row l % 16][k l / 16] and B[k l / 16][col l % 16], receives
 // D[row 4 (l / 16) + r][col l % 16] in accumulator register r.  The k order inside a group of 16 is free as long as A and B agree: group g = l / 16
 // takes k = 16 s + 4 g + j in the j-th of four instructions, so that both operands are 16-byte reads.
+//
+// FUSED: both halves of VecNormalize.step_wait move into this kernel, so that a rollout step is two launches (policy, simulator) instead of three.
+// The statistics need sums over ALL environments before any can be normalised: the policy workgroups (blockIdx.y = 0) leave the float64 moments of
+// their own 32 environments (19 channels: sum x, sum x^2; discounted returns of the step before: sum r, sum r^2; sum of raw rewards) in a workspace row,
+// raise a flag each, and every workgroup waits until all flags are up, adds them in row order (all arrive at the same
+// bits), merges them into the running statistics it read BEFORE the wait and normalises its environments; workgroup (0, 0) stores the merged statistics
+// AFTER the wait, so nobody can read them half-updated.  The grid is at most 2 x 256 workgroups of which two fit a CU (LDS 76 KB, 4 waves): all are
+// resident, which the wait relies on; it is bounded all the same (a status word is raised and the kernel carries on with whatever rows it sees rather than
+// hang).  Measured alternative: every workgroup reducing the whole batch by itself (no wait) -- 256 x 311 KB through L2 cost 20-27 us per launch.
+constexpr int PL_ROW = 48, PL_SG = 13;                          // doubles per workspace row (38 observation moments, 3 reward moments); segments of the final sum
+constexpr unsigned PL_SPIN = 1u << 21;
+struct FusedArgs {
+    const float* rew_prev; const uint8_t* done_prev; float* nrew_prev; double* raw_sum;
+    double* work;                                                // [gridDim.x][PL_ROW] rows, then 2 gridDim.x arrival flags + a status word (32-bit words)
+    int update_obs, have_prev, norm_reward;
+};
+struct FusedLds { double mean[PL_OBS], var[PL_OBS]; double scale; };             // (the raw observations sit where their normalised values go; the partial sums borrow h2)
+struct FusedTab { double tab[2][PL_SG][PL_OBS]; double red[3][4]; };
+static_assert(sizeof(FusedTab) <= PL_TM * PL_H2S * sizeof(float), "partial sums fit the layer-2 output buffer");
+
+template <bool FUSED>
 __global__ __launch_bounds__(256) void usim_policy_act_kernel(PolicyNet P, NormStats S, const float* __restrict__ obs,
                                                               const uint8_t* __restrict__ prev_done, int n, int adim, const float* __restrict__ act_low,
                                                               const float* __restrict__ act_high, uint32_t key0, uint32_t key1, uint32_t ctr0, const uint32_t* __restrict__ ctr_base, int env_offset,
                                                               int deterministic, float* __restrict__ nobs_out, float* __restrict__ act_out,
                                                               float* __restrict__ act_env, float* __restrict__ value_out, float* __restrict__ logp_out,
-                                                              float* __restrict__ start_out) {
+                                                              float* __restrict__ start_out, FusedArgs F) {
+    __shared__ FusedLds FL;
     __shared__ __attribute__((aligned(16))) float xs[PL_TM][PL_KPAD];
     __shared__ __attribute__((aligned(16))) float h1[PL_TM][PL_H1S];
     __shared__ __attribute__((aligned(16))) float h2[PL_TM][PL_H2S];
@@ -157,12 +183,131 @@ __global__ __launch_bounds__(256) void usim_policy_act_kernel(PolicyNet P, NormS
         const float4* WH = reinterpret_cast<const float4*>(net ? P.val_w : P.act_w);
         if (tid < nh) reinterpret_cast<float4*>(whs)[tid] = WH[tid];
     }
+    if constexpr (FUSED) {
+        const int nrow = gridDim.x;
+        FusedTab& FT = *reinterpret_cast<FusedTab*>(&h2[0][0]);
+        unsigned int* flags = reinterpret_cast<unsigned int*>(F.work + (size_t)nrow * PL_ROW);        // [2 nrow] arrival flags (one per workgroup), then a status word
+        const unsigned epoch = 2u * ctr + 1u;                                                          // this call's flag value (never 0, new for every counter)
+        const bool writer = blockIdx.x == 0 && net == 0;
+        // the running statistics as they are before this call (read before the wait; stored only after it)
+        double om = 0.0, ov = 0.0;
+        if (tid < PL_OBS) { om = S.obs_mean[tid]; ov = S.obs_var[tid]; }
+        const double ocnt = *S.obs_count, rmean0 = *S.ret_mean, rvar0 = *S.ret_var, rcnt0 = *S.ret_count;
+        // this workgroup's raw observations
+        for (int t = tid; t < PL_TM * PL_KPAD; t += 256) {
+            const int r = t / PL_KPAD, c = t - r * PL_KPAD, env = row0 + r;
+            xs[r][c] = (c < PL_OBS && env < n) ? obs[(size_t)env * PL_OBS + c] : 0.f;
+        }
+        __syncthreads();
+        if (net == 0) {
+            double* row = F.work + (size_t)blockIdx.x * PL_ROW;
+            if (tid < 4 * PL_OBS) {                                // four lanes per channel, eight environments each
+                const int c = tid >> 2, seg = tid & 3;
+                double a = 0.0, b = 0.0;
+                if (F.update_obs) {
+#pragma unroll
+                    for (int r = 8 * seg; r < 8 * seg + 8; ++r) { const double x = (double)xs[r][c]; a += x; b = fma(x, x, b); }
+                }
+                a += __shfl_xor(a, 1); b += __shfl_xor(b, 1); a += __shfl_xor(a, 2); b += __shfl_xor(b, 2);
+                if (seg == 0) { st_agent(&row[2 * c], a); st_agent(&row[2 * c + 1], b); }
+            } else if (tid >= 128 && tid < 128 + PL_TM) {          // (a wave of its own) the reward side of the step before, this workgroup's environments
+                const int i = row0 + (tid - 128);
+                double rw = 0.0, r = 0.0;
+                if (F.have_prev && i < n) {
+                    rw = (double)F.rew_prev[i]; r = fma(S.returns[i], S.gamma, rw);
+                    S.returns[i] = F.done_prev[i] ? 0.0 : r;
+                }
+                double a = rw, b = r, c = r * r;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+                if (tid == 128) { st_agent(&row[2 * PL_OBS], a); st_agent(&row[2 * PL_OBS + 1], b); st_agent(&row[2 * PL_OBS + 2], c); }
+            }
+        }
+        // every workgroup of both networks announces itself: its rows are written and its reads of the old statistics have returned
+        // No agent-scope fences: a release writes the XCD's L2 back and an acquire invalidates it, per wave (128 of each per XCD: 25 us per launch).  The rows
+        // and flags are written and read with device-scope accesses instead (they go to the memory side directly); the flag follows the rows by program order:
+        // every wave's stores (and its reads of the old statistics) have returned before it reaches the workgroup barrier.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&flags[net * nrow + blockIdx.x], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- wait for all of them (bounded): thread t watches flag t -- a counter that 2 x 128 workgroups on 8 XCDs add to costs ~50 us per launch ----
+        if (wave == 3) {                                            // one wave watches: lane l takes flags 2 l, 2 l + 1 (+ 128 j) as one 8-byte word
+            const unsigned long long want = ((unsigned long long)epoch << 32) | epoch;
+            const unsigned long long* f2 = reinterpret_cast<const unsigned long long*>(flags);
+            for (int k = lane; k < nrow; k += 64) {                 // (2 nrow flags = nrow words)
+                unsigned spins = 0;
+                while (__hip_atomic_load(&f2[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {     // (relaxed: an acquire per poll invalidates the caches per poll)
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > PL_SPIN) { flags[2 * nrow] = 1u; break; }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- all rows in row order: thread (g, c) takes rows g, g + 13, ... of channel c -- every load issued before the first sum (a load that has to
+        //      leave the XCD takes ~2 us; 128 of them one after the other was 50 us) --; then the 13 partial sums in order ----
+        constexpr int JMAX = (USIM_POLICY_FUSED_MAX_ENVS / PL_TM + PL_SG - 1) / PL_SG;
+        if (tid < PL_SG * PL_OBS) {
+            const int g = tid / PL_OBS, c = tid - g * PL_OBS;
+            double a = 0.0, b = 0.0;
+            if (F.update_obs) {
+                double2 v[JMAX];
+#pragma unroll
+                for (int j = 0; j < JMAX; ++j) {
+                    const int k = g + PL_SG * j;
+                    v[j] = (k < nrow) ? make_double2(ld_agent(&F.work[(size_t)k * PL_ROW + 2 * c]), ld_agent(&F.work[(size_t)k * PL_ROW + 2 * c + 1])) : make_double2(0.0, 0.0);
+                }
+#pragma unroll
+                for (int j = 0; j < JMAX; ++j) { a += v[j].x; b += v[j].y; }
+            }
+            FT.tab[0][g][c] = a; FT.tab[1][g][c] = b;
+        }
+        if (F.have_prev) {                                          // the three reward sums: row t in thread t, then wave butterflies and the four wave sums in order
+            double a = 0.0, b = 0.0, c = 0.0;
+            if (tid < nrow) { const double* row = F.work + (size_t)tid * PL_ROW + 2 * PL_OBS; a = ld_agent(&row[0]); b = ld_agent(&row[1]); c = ld_agent(&row[2]); }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+            if (lane == 0) { FT.red[0][wave] = a; FT.red[1][wave] = b; FT.red[2][wave] = c; }
+        }
+        __syncthreads();
+        if (tid < PL_OBS) {
+            if (F.update_obs) {
+                double a = 0.0, b = 0.0;
+#pragma unroll
+                for (int g = 0; g < PL_SG; ++g) { a += FT.tab[0][g][tid]; b += FT.tab[1][g][tid]; }
+                const double bm = a / n, bv = fmax(b / n - bm * bm, 0.0);
+                const double tot = ocnt + n, delta = bm - om;
+                const double m2 = ov * ocnt + bv * n + delta * delta * ocnt * n / tot;
+                om += delta * n / tot; ov = m2 / tot;
+                if (writer) { S.obs_mean[tid] = om; S.obs_var[tid] = ov; if (tid == 0) *S.obs_count = tot; }
+            }
+            FL.mean[tid] = om; FL.var[tid] = ov;
+        } else if (tid == 64) {
+            double rmean = rmean0, rvar = rvar0, rcnt = rcnt0;
+            if (F.have_prev) {
+                const double a = (FT.red[0][0] + FT.red[0][1]) + (FT.red[0][2] + FT.red[0][3]), b = (FT.red[1][0] + FT.red[1][1]) + (FT.red[1][2] + FT.red[1][3]),
+                             c = (FT.red[2][0] + FT.red[2][1]) + (FT.red[2][2] + FT.red[2][3]);
+                const double bm = b / n, bv = fmax(c / n - bm * bm, 0.0);
+                const double tot = rcnt + n, delta = bm - rmean;
+                const double m2 = rvar * rcnt + bv * n + delta * delta * rcnt * n / tot;
+                rmean += delta * n / tot; rvar = m2 / tot; rcnt = tot;
+                if (writer) { *S.ret_mean = rmean; *S.ret_var = rvar; *S.ret_count = rcnt; if (F.raw_sum) *F.raw_sum += a; }
+            }
+            FL.scale = 1.0 / sqrt(rvar + S.epsilon);
+        }
+        __syncthreads();
+        if (F.have_prev && net == 0 && tid < PL_TM && row0 + tid < n) {
+            double v = (double)F.rew_prev[row0 + tid];
+            if (F.norm_reward) { v *= FL.scale; v = v < -S.clip_reward ? -S.clip_reward : (v > S.clip_reward ? S.clip_reward : v); }
+            F.nrew_prev[row0 + tid] = (float)v;
+        }
+    }
     // ---- VecNormalize.normalize_obs: clip((obs - mean) / sqrt(var + eps)) in float64, stored as float32 ----
     for (int t = tid; t < PL_TM * PL_KPAD; t += 256) {
         const int r = t / PL_KPAD, c = t - r * PL_KPAD, env = row0 + r;
         float v = 0.f;
         if (c < PL_OBS && env < n) {
-            double x = ((double)obs[(size_t)env * PL_OBS + c] - S.obs_mean[c]) / sqrt(S.obs_var[c] + S.epsilon);
+            const double om = FUSED ? FL.mean[c] : S.obs_mean[c], ov = FUSED ? FL.var[c] : S.obs_var[c];
+            double x = ((double)(FUSED ? xs[r][c] : obs[(size_t)env * PL_OBS + c]) - om) / sqrt(ov + S.epsilon);
             x = x < -S.clip_obs ? -S.clip_obs : (x > S.clip_obs ? S.clip_obs : x);
             v = (float)x;
             if (nobs_out && net == 0) nobs_out[(size_t)env * PL_OBS + c] = v;
@@ -350,9 +495,25 @@ int usim_policy_step(const usim_policy_net* net, const usim_norm_stats* st, cons
         // scratch: PL_SB x 19 x 2 partial sums, then the arrival counter (zero on entry, left zero)
         hipLaunchKernelGGL(usim_policy_obs_stats_kernel, dim3(PL_SB), dim3(PL_ST), 0, s, obs_dev, n, S, st->scratch, reinterpret_cast<unsigned int*>(st->scratch + PL_SB * PL_OBS * 2));
     }
-    hipLaunchKernelGGL(usim_policy_act_kernel, dim3((n + PL_TM - 1) / PL_TM, 2), dim3(256), 0, s, P, S, obs_dev, prev_done_dev, n,
+    hipLaunchKernelGGL(usim_policy_act_kernel<false>, dim3((n + PL_TM - 1) / PL_TM, 2), dim3(256), 0, s, P, S, obs_dev, prev_done_dev, n,
                        act_dim, act_low_dev, act_high_dev, (uint32_t)seed, (uint32_t)(seed >> 32), counter, counter_base_dev, env_offset, deterministic, out->nobs_dev, out->act_dev,
-                       out->act_env_dev, out->value_dev, out->logp_dev, out->episode_start_dev);
+                       out->act_env_dev, out->value_dev, out->logp_dev, out->episode_start_dev, FusedArgs{});
+    return hipGetLastError() == hipSuccess ? USIM_OK : USIM_ERR_HIP;
+}
+
+int usim_policy_step_fused(const usim_policy_net* net, const usim_norm_stats* st, const usim_policy_fused* f, const float* obs_dev, const uint8_t* prev_done_dev, int n,
+                           int act_dim, const float* act_low_dev, const float* act_high_dev, uint64_t seed, uint32_t counter, const uint32_t* counter_base_dev,
+                           int env_offset, int deterministic, const usim_policy_out* out, void* stream) {
+    using namespace usim;
+    if (!net || !st || !f || !obs_dev || !out || !out->act_env_dev || n <= 0 || act_dim < 1 || act_dim > 7 || !act_low_dev || !act_high_dev) return USIM_ERR_INVALID;
+    if (!f->work_dev || (f->have_prev && (!f->rew_prev_dev || !f->done_prev_dev || !f->nrew_prev_dev))) return USIM_ERR_INVALID;
+    if (n > USIM_POLICY_FUSED_MAX_ENVS) return USIM_ERR_UNSUPPORTED;          // every workgroup must be resident (see the kernel)
+    PolicyNet P{net->pi_w1, net->pi_b1, net->pi_w2, net->pi_b2, net->act_w, net->act_b, net->vf_w1, net->vf_b1, net->vf_w2, net->vf_b2, net->val_w, net->val_b, net->log_std};
+    NormStats S{st->obs_mean, st->obs_var, st->obs_count, st->ret_mean, st->ret_var, st->ret_count, st->returns, st->clip_obs, st->clip_reward, st->gamma, st->epsilon};
+    FusedArgs F{f->rew_prev_dev, f->done_prev_dev, f->nrew_prev_dev, f->raw_sum_dev, f->work_dev, f->update_obs, f->have_prev, f->norm_reward};
+    hipLaunchKernelGGL(usim_policy_act_kernel<true>, dim3((n + PL_TM - 1) / PL_TM, 2), dim3(256), 0, (hipStream_t)stream, P, S, obs_dev, prev_done_dev, n,
+                       act_dim, act_low_dev, act_high_dev, (uint32_t)seed, (uint32_t)(seed >> 32), counter, counter_base_dev, env_offset, deterministic, out->nobs_dev, out->act_dev,
+                       out->act_env_dev, out->value_dev, out->logp_dev, out->episode_start_dev, F);
     return hipGetLastError() == hipSuccess ? USIM_OK : USIM_ERR_HIP;
 }
 

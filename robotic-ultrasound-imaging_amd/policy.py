@@ -494,8 +494,13 @@ class FusedRollout:
     those objects is unchanged.  Differences from collect_rollouts: sums are ordered differently (agreement to rounding, not bit for bit) and the
     Gaussian noise comes from the library's counter-based stream (seed, environment, step), not from a torch generator."""
 
-    def __init__(self, env, policy, vecnorm, buffer, seed=0, graph=True):
+    def __init__(self, env, policy, vecnorm, buffer, seed=0, graph=True, fused_stats=None):
         from . import _lib
+        # fused_stats: VecNormalize's two updates inside the policy launch (usim_policy_step_fused: two launches per step instead of three); every workgroup
+        # reduces the whole batch, which pays up to 8192 environments
+        self.fused_stats = (vecnorm.training and env.num_envs <= 8192) if fused_stats is None else bool(fused_stats)
+        if self.fused_stats and not vecnorm.training:
+            raise ValueError("fused_stats is the training path (frozen statistics need no update kernels)")
         if policy.pi_sizes != (256, 128) or policy.vf_sizes != (256, 128) or policy.policy_net[0].in_features != 19:
             raise ValueError("the fused kernels implement the MlpPolicy of the shipped checkpoints: 19 -> 256 -> 128 (tanh) for both networks")
         self.env, self.policy, self.vecnorm, self.buffer, self.seed = env, policy, vecnorm, buffer, int(seed)
@@ -520,6 +525,8 @@ class FusedRollout:
         self.raw_reward_sum = torch.zeros((), dtype=torch.float64, device=dev)
         self.counter = 0                                                                    # rollouts collected
         self._ctr = torch.zeros(1, dtype=torch.int32, device=dev)                           # device part of the noise counter: advanced by every rollout
+        self._rows = (env.num_envs + 31) // 32
+        self._work = torch.zeros(self._rows * 49 + 2, dtype=torch.float64, device=dev)                    # USIM_POLICY_FUSED_WORK(n)
         self.obs = env.reset_tensor()                                                       # the env's own observation buffer: rewritten by every step
         self._prev_done = env._done                                                         # ... and its done flags: read by the policy kernel BEFORE the next step rewrites them
         self._prev_done.fill_(1)                                                            # every environment starts an episode
@@ -554,9 +561,50 @@ class FusedRollout:
                                               int(bool(deterministic)), C.byref(out), env._stream()))
         return self._act_env, (self._value if t is None else b.values[t])
 
+    def _fused(self, t, rewards_out):
+        from . import _lib
+        env, vn = self.env, self.vecnorm
+        prev = t > 0
+        return _lib.UsimPolicyFused(self._work.data_ptr(), env._rew.data_ptr() if prev else None, env._done.data_ptr() if prev else None,
+                                    rewards_out.data_ptr() if prev else None, self.raw_reward_sum.data_ptr(), int(prev), int(prev), int(bool(vn.norm_reward)), 0)
+
+    def act_fused(self, obs, prev_done, counter, rewards_out=None, deterministic=False, t=None):
+        """usim_policy_step_fused: as act(), with RunningMeanStd.update(obs) and the reward side of the step before (normalised into rewards_out) in the same
+        launch when counter > 0"""
+        from . import _lib
+        env, b = self.env, self.buffer
+        ptr = lambda x: None if x is None else x.data_ptr()
+        out = _lib.UsimPolicyOut(ptr(self._act_env), None if t is None else ptr(b.observations[t]), None if t is None else ptr(b.actions[t]),
+                                 ptr(self._value) if t is None else ptr(b.values[t]), None if t is None else ptr(b.log_probs[t]), None if t is None else ptr(b.episode_starts[t]))
+        f = self._fused(counter, rewards_out)
+        self._check(self.lib.usim_policy_step_fused(C.byref(self._net), C.byref(self._stats), C.byref(f), ptr(obs), ptr(prev_done), env.num_envs, env.action_dim,
+                                                    ptr(self._low), ptr(self._high), self.seed, int(counter) & 0xffffffff, ptr(self._ctr),
+                                                    int(getattr(env, "env_offset", 0)), int(bool(deterministic)), C.byref(out), env._stream()))
+
+    @property
+    def wait_ran_out(self):
+        """True if a workgroup of usim_policy_step_fused ever gave up waiting for the others' partial sums (the device was shared; statistics are then wrong)"""
+        return bool(self._work[self._rows * 48:].view(torch.int32)[2 * self._rows].item())
+
+    def _record_fused(self):
+        """one rollout with two launches per step: policy (+ the statistics of the observation it reads + the reward side of the step before), env"""
+        env, b = self.env, self.buffer
+        T, n = b.buffer_size, env.num_envs
+        self.raw_reward_sum.zero_()
+        for t in range(T):
+            self.act_fused(self.obs, self._prev_done, counter=t, rewards_out=b.rewards[t - 1] if t else None, t=t)
+            env.step_tensor(self._act_env)
+        self.act_fused(self.obs, self._prev_done, counter=T, rewards_out=b.rewards[T - 1], deterministic=True)      # bootstrap value + the last step's reward side
+        self._check(self.lib.usim_policy_gae(b.rewards.data_ptr(), b.values.data_ptr(), b.episode_starts.data_ptr(), self._value.data_ptr(), self._prev_done.data_ptr(),
+                                             T, n, b.gamma, b.gae_lambda, b.advantages.data_ptr(), b.returns.data_ptr(), env._stream()))
+        self._ctr.add_(T + 1)
+        env.refill_bank()
+
     def _record(self):
         """one rollout: T x (policy, env, reward) + bootstrap value + GAE.  The noise of step t is keyed on (seed, environment, t + device counter); the
         recorded sequence advances the device counter by T + 1 at its end, so a replay draws fresh noise"""
+        if self.fused_stats:
+            return self._record_fused()
         env, b, vn = self.env, self.buffer, self.vecnorm
         T, n = b.buffer_size, env.num_envs
         self.raw_reward_sum.zero_()

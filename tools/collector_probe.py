@@ -63,6 +63,14 @@ for _ in range(reps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
 print(f"fused kernels + graph  : {dt * 1e3:8.2f} ms per rollout of {n} x {T}  = {n * T / dt / 1e6:7.2f} M env-steps/s  ({dt / T * 1e6:6.1f} us per step)")
+f3 = pol.FusedRollout(env3, policy3, vn3, buf3, seed=1, fused_stats=False)
+f3.collect(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(reps):
+    f3.collect()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / reps
+print(f"  (three launches/step): {dt * 1e3:8.2f} ms per rollout of {n} x {T}  = {n * T / dt / 1e6:7.2f} M env-steps/s  ({dt / T * 1e6:6.1f} us per step)")
 fe = pol.FusedRollout(env3, policy3, vn3, buf3, seed=1, graph=False)
 fe.collect(); torch.cuda.synchronize()
 t0 = time.perf_counter()
