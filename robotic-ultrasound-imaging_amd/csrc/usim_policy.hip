@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void usim_policy_act_kernel(PolicyNet P, NormS
     //      coalesced loads ----
     const int c0 = (wave * 2) * 16 + lr, c1 = c0 + 16;
     float4 wb0[PL_H1 / 16], wb1[PL_H1 / 16];
-    {
+    auto prefetch = [&]() {
         const float* W2 = net ? P.vf_w2 : P.pi_w2;
 #pragma unroll
         for (int s = 0; s < PL_H1 / 16; ++s) {
@@ -182,7 +182,8 @@ __global__ __launch_bounds__(256) void usim_policy_act_kernel(PolicyNet P, NormS
         const int nh = (net ? 1 : adim) * PL_H2 / 4;
         const float4* WH = reinterpret_cast<const float4*>(net ? P.val_w : P.act_w);
         if (tid < nh) reinterpret_cast<float4*>(whs)[tid] = WH[tid];
-    }
+    };
+    if constexpr (!FUSED) prefetch();
     if constexpr (FUSED) {
         const int nrow = gridDim.x;
         FusedTab& FT = *reinterpret_cast<FusedTab*>(&h2[0][0]);
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(256) void usim_policy_act_kernel(PolicyNet P, NormS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_store(&flags[net * nrow + blockIdx.x], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        prefetch();                                                 // (after the flag: the wait above would have had to drain these loads too; they fly during the wait below)
         // ---- wait for all of them (bounded): thread t watches flag t -- a counter that 2 x 128 workgroups on 8 XCDs add to costs ~50 us per launch ----
         if (wave == 3) {                                            // one wave watches: lane l takes flags 2 l, 2 l + 1 (+ 128 j) as one 8-byte word
             const unsigned long long want = ((unsigned long long)epoch << 32) | epoch;

@@ -1229,7 +1229,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         // the last workgroup to finish empties the work list for the step kernels that follow on the stream
         __syncthreads();
         if (threadIdx.x == 0) {
-            __threadfence();
+            // (no device-scope fence: the list is read by the launches that FOLLOW on the stream, and a fence costs an L2 write-back per wave)
             if (atomicAdd(io.count + 1, 1) == (int)gridDim.x - 1) { io.count[0] = 0; io.count[1] = 0; }
         }
     }

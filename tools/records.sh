@@ -21,6 +21,7 @@ python3 tests/gpu_parity_fullsize.py > "$G/${TAG}_parity_fullsize.txt" 2>&1
 for m in tracking variable_z wrench; do python3 tools/gpu_policy_replay.py $m 2>&1 | grep -v amdgpu.ids; done > "$G/${TAG}_policy_replay.txt"
 python3 tools/replay_medians.py 1024 3000 2>&1 | grep -v amdgpu.ids > "$G/${TAG}_replay_medians.txt"
 python3 tools/collector_probe.py 4096 128 5 2>&1 | grep -v amdgpu.ids > "$G/${TAG}_collector_probe.txt"
+tools/prof_collector.sh 4096 > "$G/${TAG}_prof_collector.txt" 2>&1
 python3 tools/ppo_demo.py 60 4096 128 tracking fused 2>&1 | grep -v amdgpu.ids > "$G/${TAG}_ppo_fused.txt"
 for m in tracking fixed variable_z wrench; do python3 tools/gpu_soak.py 4096 5000 $m 2>&1 | grep -v amdgpu.ids; done > "$G/${TAG}_soak.txt"
 cat "$G/${TAG}_gputests.txt" "$G/bench_matrix.txt"; tail -4 "$G/${TAG}_parity_fullsize.txt"

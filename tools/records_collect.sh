@@ -11,6 +11,6 @@ cp $G/prof_${TAG}_soft_spl1/stats/stats_kernel_stats.csv $P/rocprofv3_soft_4096_
 cp $G/${TAG}_timeline.txt $P/timeline_split_soft.txt; cp $G/${TAG}_timeline_multi.txt $P/timeline_split_soft_multi_step.txt; cp $G/${TAG}_timeline_g8.txt $P/timeline_split_soft_8lane_groups_8192.txt
 cp $G/${TAG}_parity_fullsize.txt $P/parity_fullsize.txt
 cp $G/${TAG}_policy_replay.txt $P/policy_replay.txt; cp $G/${TAG}_replay_medians.txt $P/replay_medians.txt; cp $G/${TAG}_collector_probe.txt $P/collector_probe.txt
-cp $G/${TAG}_ppo_fused.txt $P/ppo_demo_fused_collector.txt; cp $G/${TAG}_soak.txt $P/soak.txt
+cp $G/${TAG}_prof_collector.txt $P/rocprofv3_fused_collector_4096_summary.txt; cp $G/${TAG}_ppo_fused.txt $P/ppo_demo_fused_collector.txt; cp $G/${TAG}_soak.txt $P/soak.txt
 python3 tools/make_traffic.py $G/prof_${TAG}_soft $G/prof_${TAG}_rigid > $P/traffic.json
 ls -la $P
