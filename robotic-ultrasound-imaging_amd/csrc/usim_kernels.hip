@@ -512,16 +512,19 @@ DI void contact_rows(float* lds, const int eb, const int gl, const DevModel& M, 
 #undef EB
 }
 
-template <int G>
+// PRE: the arm-independent half of the rows comes from contact_rows (P); otherwise the whole set-up is formed here (vz and the records; P is not read) -- one
+// statement sequence for the kernels that do not split it: handing the rows through the struct cost the 16-lane split kernel 0.5 us per step.
+template <int G, bool PRE>
 DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M, const DevCfg& C, const int nc, const int ncmax, const int* cel,
-                      const float* Li, const float* alpha, const float* vs, const float mu, const ContactRows& P, float* W, float* gf,
+                      const float* Li, const float* alpha, const float* vs, const float mu, const float vz, const ContactRows& P, float* W, float* gf,
                       unsigned long long* dbg) {
 #define EB(off) lds[TB_WORDS + eb * GE_STRIDE + (off)]
-    // ---- contact k lives in the registers of lane k of its group.  Set-up: row directions w (contact_rows), Lambda^-1 w, reference acceleration;
-    //      Km[c] = Linv[e_own][e_c] / m ----
+    // ---- contact k lives in the registers of lane k of its group.  Set-up: row directions w, Lambda^-1 w, element
+    //      coupling g, reference acceleration, regulariser; Km[c] = Linv[e_own][e_c] / m ----
     USIM_CSTAMP(dbg, 0);
     const bool own = gl < nc;
     float w[3][6], Liw[3][6], g[3], invD[3], Rd[3], f[3] = {0.f, 0.f, 0.f}, cres[3] = {0.f, 0.f, 0.f}, Km[MAXC];
+    if constexpr (PRE) {
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) Km[c] = P.Km[c];
 #pragma unroll
@@ -547,6 +550,59 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
             const float aref = -bcon * vrel - (d == 0 ? P.kdist : 0.f);
             cres[d] = fmaf(g[d], P.ae0, wa) - aref;           // residual of row d at zero force
         }
+    }
+    } else {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) Km[c] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        g[d] = 0.f; invD[d] = 0.f; Rd[d] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { w[d][a] = 0.f; Liw[d][a] = 0.f; }
+    }
+    if (own) {
+        const int b = GE_CG + gl * CG_WORDS;
+        f3 nn = mk(EB(b + 0), EB(b + 1), EB(b + 2)), rr = mk(EB(b + 3), EB(b + 4), EB(b + 5));
+        const int e = __float_as_int(EB(b + 6));
+        const float dist = EB(b + 7);
+        // tangent frame without a case distinction (Frisvad 2012: continuous except at n.z = -1; contact normals point from the element towards the probe,
+        // and no element sits above it): the iterate of a fixed number of row-by-row sweeps depends on the frame, so float32 and float64 must not be able
+        // to choose different ones (oracle: same lines)
+        const float aa = -rcp_(1.f + nn.z), bb = nn.x * nn.y * aa;
+        f3 t1 = mk(1.f + nn.x * nn.x * aa, bb, -nn.x);
+        f3 t2 = mk(bb, 1.f + nn.y * nn.y * aa, -nn.y);
+        f3 ax = mk(lds[TB_AXIS + 3 * e], lds[TB_AXIS + 3 * e + 1], lds[TB_AXIS + 3 * e + 2]);
+        const float sde = EB(GE_SD + e);
+        const float bcon = 2.0f / (SI_DMAX * SR_TC);
+        float xx = fminf(-dist * (1.0f / SI_WIDTH), 1.f);
+        float yy = (xx < 0.5f) ? 2.f * xx * xx : 1.f - 2.f * (1.f - xx) * (1.f - xx);
+        float dimp = SI_D0 + yy * (SI_DMAX - SI_D0);
+        float kk = dimp * (1.0f / (SI_DMAX * SI_DMAX * SR_TC * SR_TC));
+        float Rn = (1.f - dimp) * rcp_(dimp) * M.invw;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) if (c < nc) Km[c] = lds[TB_LINV + e * LROW + cel[c]] * (1.0f / ELEM_MASS);
+        const float ae0 = EB(GE_A + e);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            f3 dir = (d == 0) ? nn : (d == 1 ? t1 : t2);
+            f3 rx = cross(rr, dir);
+            w[d][0] = dir.x; w[d][1] = dir.y; w[d][2] = dir.z; w[d][3] = rx.x; w[d][4] = rx.y; w[d][5] = rx.z;
+            g[d] = -dot(dir, ax);
+            float vrel = g[d] * sde - dir.z * vz, wa = 0.f;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                float s = 0.f;
+#pragma unroll
+                for (int bb = 0; bb < 6; ++bb) s = fmaf((a >= bb) ? Li[PK(a, bb)] : Li[PK(bb, a)], w[d][bb], s);
+                Liw[d][a] = s;
+                vrel = fmaf(w[d][a], vs[a], vrel);
+                wa = fmaf(w[d][a], alpha[a], wa);
+            }
+            const float aref = -bcon * vrel - (d == 0 ? kk * dist : 0.f);
+            Rd[d] = (d == 0) ? Rn * C.rn_scale : Rn * (1.0f / IMPRATIO);      // (two colliding probe geoms: two equal normal rows in parallel = half the regulariser)
+            cres[d] = fmaf(g[d], ae0, wa) - aref;             // residual of row d at zero force
+        }
+    }
     }
     USIM_STAMP(dbg, 9);
     USIM_CSTAMP(dbg, 1);
@@ -1103,8 +1159,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT) void usim_step_kernel(const DevMo
                         alpha[a] = s; vs[a] = u;
                     }
                     TSTAMP(8);
-                    ContactRows P; contact_rows<G>(lds, eb, gl, M, C, nc, cel, vz, P);
-                    contact_solve<G>(lds, eb, gl, M, C, nc, ncmax, cel, Li, alpha, vs, mu, P, W, gf, io.dbg);
+                    contact_solve<G, false>(lds, eb, gl, M, C, nc, ncmax, cel, Li, alpha, vs, mu, vz, ContactRows{}, W, gf, io.dbg);
                 }
                 TSTAMP(11);
                 // ---- element accelerations a = a~ + Linv[:, e_c] gf_c, semi-implicit Euler, write back ----

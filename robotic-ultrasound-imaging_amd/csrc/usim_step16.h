@@ -480,47 +480,55 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         // One box, kernel us/step: 8-lane groups at 8192 envs 20.19 -> 19.97 (scratch 176 -> 112 bytes per lane); 16-lane groups at 4096 envs 13.67 -> 13.82
         // (same scratch; the two waves share a SIMD's issue slots, so what moves ahead of the barrier is taken from the arm wave) -- only the 8-lane kernel does it.
         constexpr bool EARLY = arm_share_num<G>() == 0 && G == 8;
-        int nc = ncl, overflow = 0, ncmax = 0;
-        float gf[MAXC], W[6] = {0, 0, 0, 0, 0, 0};
-        int cel[MAXC];
         ContactRows P;
-        auto finish_list = [&]() {
-            contact_overflow<G>(lds, eb, gl, gbase, nc);
-            if (nc > MAXC) { overflow = 1; nc = MAXC; }
+        int nc_early = ncl, overflow_early = 0, ncmax_early = 0, cel_early[MAXC];
+        if constexpr (EARLY) {
+            contact_overflow<G>(lds, eb, gl, gbase, nc_early);
+            if (nc_early > MAXC) { overflow_early = 1; nc_early = MAXC; }
             group_sync();
 #pragma unroll
-            for (int k = MAXC; k >= 1; --k) if (ncmax == 0 && __any(nc >= k)) ncmax = k;
+            for (int k = MAXC; k >= 1; --k) if (ncmax_early == 0 && __any(nc_early >= k)) ncmax_early = k;
 #pragma unroll
-            for (int k = 0; k < MAXC; ++k) { gf[k] = 0.f; cel[k] = (k < nc) ? __float_as_int(EB(GE_CG + k * CG_WORDS + 6)) : 0; }
-            if (ncmax > 0) contact_rows<G>(lds, eb, gl, M, C, nc, cel, vz, P);
-        };
-        if constexpr (EARLY) finish_list();
+            for (int k = 0; k < MAXC; ++k) cel_early[k] = (k < nc_early) ? __float_as_int(EB(GE_CG + k * CG_WORDS + 6)) : 0;
+            if (ncmax_early > 0) contact_rows<G>(lds, eb, gl, M, C, nc_early, cel_early, vz, P);
+        }
         RSTAMP(3);
         USIM_BAR();                                                 // (2) ... and Lambda^-1, alpha = J qs, vs = J qd, and the arm side's contact records
         RSTAMP(4);
-        if constexpr (!EARLY) {
-            // one list in ascending shell id: the arm side's records (first part of the queue) first, this side's behind them
-            const int nca = __float_as_int(mb[MB_POSE + 9]);
-            nc = nca + ncl;
-            if (__any(nca > 0)) {
-                constexpr int RPL = MAXCAND / G;                             // records per lane of the group
-                const int na = nca < MAXCAND ? nca : MAXCAND;
-                float4 r0[RPL], r1[RPL];
+        // one list in ascending shell id: the arm side's records (first part of the queue) first, this side's behind them
+        const int nca = EARLY ? 0 : __float_as_int(mb[MB_POSE + 9]);
+        int nc = nca + ncl;
+        if (!EARLY && __any(nca > 0)) {
+            constexpr int RPL = MAXCAND / G;                             // records per lane of the group
+            const int na = nca < MAXCAND ? nca : MAXCAND;
+            float4 r0[RPL], r1[RPL];
 #pragma unroll
-                for (int hh = 0; hh < RPL; ++hh) {
-                    const int gg = gl + hh * G, li = gg - na;
-                    const float4* src = reinterpret_cast<const float4*>(gg < na ? &mb[MB_CA + gg * CG_WORDS] : &EB(GE_CG + (li > 0 ? li : 0) * CG_WORDS));
-                    r0[hh] = src[0]; r1[hh] = src[1];
-                }
-                group_sync();                                                // every record is in registers before any slot is overwritten
-#pragma unroll
-                for (int hh = 0; hh < RPL; ++hh) {
-                    float4* dst = reinterpret_cast<float4*>(&EB(GE_CG + (gl + hh * G) * CG_WORDS));
-                    dst[0] = r0[hh]; dst[1] = r1[hh];
-                }
+            for (int hh = 0; hh < RPL; ++hh) {
+                const int gg = gl + hh * G, li = gg - na;
+                const float4* src = reinterpret_cast<const float4*>(gg < na ? &mb[MB_CA + gg * CG_WORDS] : &EB(GE_CG + (li > 0 ? li : 0) * CG_WORDS));
+                r0[hh] = src[0]; r1[hh] = src[1];
             }
-            finish_list();
+            group_sync();                                                // every record is in registers before any slot is overwritten
+#pragma unroll
+            for (int hh = 0; hh < RPL; ++hh) {
+                float4* dst = reinterpret_cast<float4*>(&EB(GE_CG + (gl + hh * G) * CG_WORDS));
+                dst[0] = r0[hh]; dst[1] = r1[hh];
+            }
         }
+        if constexpr (!EARLY) contact_overflow<G>(lds, eb, gl, gbase, nc);
+        int overflow = 0;
+        if (nc > MAXC) { overflow = 1; nc = MAXC; }
+        if constexpr (!EARLY) group_sync();
+        int ncmax = 0;
+        if constexpr (EARLY) { nc = nc_early; overflow = overflow_early; ncmax = ncmax_early; }
+        else {
+#pragma unroll
+            for (int k = MAXC; k >= 1; --k) if (ncmax == 0 && __any(nc >= k)) ncmax = k;
+        }
+        float gf[MAXC], W[6] = {0, 0, 0, 0, 0, 0};
+        int cel[MAXC];
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) { gf[k] = 0.f; cel[k] = EARLY ? cel_early[k] : ((k < nc) ? __float_as_int(EB(GE_CG + k * CG_WORDS + 6)) : 0); }
         if (ncmax > 0) {
             float alpha[6], vs[6], Lp[21];
 #pragma unroll
@@ -529,7 +537,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
 #pragma unroll
                 for (int b = 0; b <= a; ++b) Lp[PK(a, b)] = mb[MB_OP + a * 8 + b];
             }
-            contact_solve<G>(lds, eb, gl, M, C, nc, ncmax, cel, Lp, alpha, vs, mu, P, W, gf, dbg);
+            contact_solve<G, EARLY>(lds, eb, gl, M, C, nc, ncmax, cel, Lp, alpha, vs, mu, vz, P, W, gf, dbg);
         }
         if (gl == 0) {
             *reinterpret_cast<float4*>(&mb[MB_W]) = make_float4(W[0], W[1], W[2], W[3]);
@@ -1001,9 +1009,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
                 for (int b = 0; b <= a; ++b) Lp[PK(a, b)] = rbc<G, TASK_LANE[a]>(Li[b]);
             });
             USIM_STAMP(dbg, 8);
-            ContactRows P;
-            contact_rows<G>(lds, eb, gl, M, C, nc, cel, vz, P);
-            contact_solve<G>(lds, eb, gl, M, C, nc, ncmax, cel, Lp, alpha, vs, mu, P, W, gf, dbg);
+            contact_solve<G, false>(lds, eb, gl, M, C, nc, ncmax, cel, Lp, alpha, vs, mu, vz, ContactRows{}, W, gf, dbg);
         }
         USIM_STAMP(dbg, 11);
         // ---- element accelerations a = a~ + Linv[:, e_c] gf_c, semi-implicit Euler, write back (a reset leaves the lattice at rest) ----
