@@ -34,14 +34,20 @@ def test_library_exports_every_declared_symbol(usim):
 
 def test_struct_layouts_match_header(usim):
     """ctypes structures must have the C layout of include/usim.h (compile a probe with the system compiler)."""
-    src = '#include "usim.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(usim_config), sizeof(usim_step_io), offsetof(usim_config, seed), offsetof(usim_config, control_dt), offsetof(usim_config, probe_height));return 0;}'
+    src = ('#include "usim.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%zu %zu %zu %zu %zu ", sizeof(usim_config), sizeof(usim_step_io), '
+           'offsetof(usim_config, seed), offsetof(usim_config, control_dt), offsetof(usim_config, probe_height));'
+           'printf("%zu %zu %zu %zu %zu %zu %zu %d\\n", sizeof(usim_policy_net), sizeof(usim_norm_stats), offsetof(usim_norm_stats, clip_obs), sizeof(usim_policy_out), '
+           'sizeof(usim_policy_fused), offsetof(usim_policy_fused, raw_sum_dev), offsetof(usim_policy_fused, update_obs), (int)USIM_POLICY_FUSED_WORK(1000));return 0;}')
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         (Path(d) / "p.c").write_text(src)
         subprocess.run(["gcc", "-I", str(ROOT / "include"), "-o", f"{d}/p", f"{d}/p.c"], check=True)
         out = subprocess.run([f"{d}/p"], capture_output=True, text=True, check=True).stdout.split()
-    cfg, io = usim._lib.UsimConfig, usim._lib.UsimStepIO
-    assert [int(v) for v in out] == [C.sizeof(cfg), C.sizeof(io), cfg.seed.offset, cfg.control_dt.offset, cfg.probe_height.offset]
+    L = usim._lib
+    cfg, io = L.UsimConfig, L.UsimStepIO
+    assert [int(v) for v in out] == [C.sizeof(cfg), C.sizeof(io), cfg.seed.offset, cfg.control_dt.offset, cfg.probe_height.offset,
+                                     C.sizeof(L.UsimPolicyNet), C.sizeof(L.UsimNormStats), L.UsimNormStats.clip_obs.offset, C.sizeof(L.UsimPolicyOut),
+                                     C.sizeof(L.UsimPolicyFused), L.UsimPolicyFused.raw_sum_dev.offset, L.UsimPolicyFused.update_obs.offset, 32 * 49 + 2]
 
 
 def test_default_config_is_the_shipped_rl_config(usim, tmp_path):
