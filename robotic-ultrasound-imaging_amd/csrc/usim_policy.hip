@@ -137,7 +137,7 @@ DI float tanh_(float x) { const float e = __builtin_amdgcn_exp2f(x * 2.885390081
 // resident, which the wait relies on; it is bounded all the same (a status word is raised and the kernel carries on with whatever rows it sees rather than
 // hang).  Measured alternative: every workgroup reducing the whole batch by itself (no wait) -- 256 x 311 KB through L2 cost 20-27 us per launch.
 constexpr int PL_ROW = 48, PL_SG = 13;                          // doubles per workspace row (38 observation moments, 3 reward moments); segments of the final sum
-constexpr unsigned PL_SPIN = 1u << 21;
+constexpr unsigned PL_SPIN = 1u << 17;                             // polls before a wait gives up (~0.1 s; a wait that succeeds takes 5-10 us)
 struct FusedArgs {
     const float* rew_prev; const uint8_t* done_prev; float* nrew_prev; double* raw_sum;
     double* work;                                                // [gridDim.x][PL_ROW] rows, then 2 gridDim.x arrival flags + a status word (32-bit words)

@@ -496,9 +496,10 @@ class FusedRollout:
 
     def __init__(self, env, policy, vecnorm, buffer, seed=0, graph=True, fused_stats=None):
         from . import _lib
-        # fused_stats: VecNormalize's two updates inside the policy launch (usim_policy_step_fused: two launches per step instead of three); every workgroup
-        # reduces the whole batch, which pays up to 8192 environments
-        self.fused_stats = (vecnorm.training and env.num_envs <= 8192) if fused_stats is None else bool(fused_stats)
+        # fused_stats: VecNormalize's two updates inside the policy launch (usim_policy_step_fused: two launches per step instead of three).  Its workgroups wait
+        # for one another, so all of them must be resident: by default only up to 4096 environments (256 workgroups, half of what the device holds -- room
+        # for a collective's kernels beside them); fused_stats=True asks for it up to the library's limit of 8192 (a device to itself)
+        self.fused_stats = (vecnorm.training and env.num_envs <= 4096) if fused_stats is None else bool(fused_stats)
         if self.fused_stats and not vecnorm.training:
             raise ValueError("fused_stats is the training path (frozen statistics need no update kernels)")
         if policy.pi_sizes != (256, 128) or policy.vf_sizes != (256, 128) or policy.policy_net[0].in_features != 19:

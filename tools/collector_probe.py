@@ -55,7 +55,7 @@ if not FUSED_ONLY:
         print(f"{label}: {dt * 1e3:8.2f} ms per rollout of {n} x {T}  = {n * T / dt / 1e6:7.2f} M env-steps/s  ({dt / T * 1e6:6.1f} us per step)")
 # the fused kernels (usim_policy_step / usim_policy_reward / usim_policy_gae), recorded as a graph
 env3, policy3, vn3, buf3 = make()
-fr = pol.FusedRollout(env3, policy3, vn3, buf3, seed=1)
+fr = pol.FusedRollout(env3, policy3, vn3, buf3, seed=1, fused_stats=n <= 8192)      # (two launches per step up to the library's limit)
 fr.collect(); torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(reps):
@@ -71,7 +71,7 @@ for _ in range(reps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
 print(f"  (three launches/step): {dt * 1e3:8.2f} ms per rollout of {n} x {T}  = {n * T / dt / 1e6:7.2f} M env-steps/s  ({dt / T * 1e6:6.1f} us per step)")
-fe = pol.FusedRollout(env3, policy3, vn3, buf3, seed=1, graph=False)
+fe = pol.FusedRollout(env3, policy3, vn3, buf3, seed=1, graph=False, fused_stats=n <= 8192)
 fe.collect(); torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(reps):
