@@ -62,3 +62,32 @@ def test_profile_step_needs_the_profiling_build(usim):
     obs, rew, done = env.step_tensor(env.random_actions_tensor(0))      # the handle is still usable
     assert torch.isfinite(obs).all()
     env.close()
+
+
+def test_plain_c_client_matches_the_python_host_class(usim, tmp_path):
+    """examples/usim_client.c: the ABI from plain C (gcc, HIP runtime for device memory; no Python, no PyTorch in the process) gives, bit for bit, the
+    observations the Python host class gives when driven with the same seed and actions"""
+    import subprocess
+    exe = tmp_path / "usim_client"
+    libdir = ROOT / "robotic-ultrasound-imaging_amd" / "lib"
+    subprocess.run(["gcc", "-O2", "-D__HIP_PLATFORM_AMD__", "-I", str(ROOT / "include"), "-I", "/opt/rocm/include", str(ROOT / "examples" / "usim_client.c"), "-o", str(exe),
+                    "-L", str(libdir), "-lusim", "-L", "/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    n, steps, seed = 256, 60, 5
+    out = subprocess.run([str(exe), str(n), str(steps), str(seed)], capture_output=True, text=True, check=True, timeout=300).stdout.split()
+    rec = dict(zip(out[0::2], out[1::2]))
+    env = usim.UltrasoundVecEnv(n, device="cuda:0", seed=seed, **usim.default_robosuite_kwargs())
+    A = env.action_dim
+    env.reset_tensor()
+    total, ended = 0.0, 0
+    idx = np.arange(n * A, dtype=np.int64)
+    for t in range(steps):
+        act = (((idx * 7 + t * 13) % 21 - 10).astype(np.float32) * np.float32(0.05)).reshape(n, A)
+        obs, rew, done = env.step_tensor(torch.from_numpy(act).to("cuda:0"))
+        total += float(rew.double().sum()); ended += int(done.sum())
+    h = 1469598103934665603
+    for byte in obs.cpu().numpy().astype(np.float32).tobytes():
+        h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert int(rec["n"]) == n and int(rec["steps"]) == steps and int(rec["ended"]) == ended
+    assert rec["obs_hash"] == f"{h:016x}"
+    assert abs(float(rec["mean_reward"]) - total / (n * steps)) < 1e-5
+    env.close()
