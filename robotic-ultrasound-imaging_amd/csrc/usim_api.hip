@@ -246,7 +246,8 @@ static int launch(usim_handle* h, DevIO io, int flags, long long rstep, hipStrea
         else hipLaunchKernelGGL((usim_step32_kernel<false, 8>), grid, block, h->lds64_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
         e = hipGetLastError();
     } else if (h->lpe == 32 && MODE == 0) {
-        dim3 grid((h->n + 15) / 16), block(512);
+        constexpr int EPB16 = 4 * wpr<16>();                            // environments per workgroup
+        dim3 grid((h->n + EPB16 - 1) / EPB16), block(128 * wpr<16>());
         if (io.nsub > 1 || h->C.substeps > 1) hipLaunchKernelGGL((usim_step32_kernel<true, 16>), grid, block, h->lds32_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
         else hipLaunchKernelGGL((usim_step32_kernel<false, 16>), grid, block, h->lds32_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
         e = hipGetLastError();

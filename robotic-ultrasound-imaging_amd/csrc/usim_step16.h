@@ -238,7 +238,15 @@ constexpr int X16_RIGID_STRIDE = 84;                  // rigid-torso launches: o
 // matrix-core solve, collision, contact solve, element integration).  They meet at workgroup barriers and hand over through per-environment
 // LDS mailboxes: site pose (1 -> 2), Lambda^-1 / alpha / vs (1 -> 2), contact wrench and contact list (2 -> 1).  ROLE 0 = one wave does both.
 // behind the per-environment blocks (16 with 16-lane groups, 32 with 8-lane groups): arm scratch + mailboxes of the split kernel
-template <int G> constexpr int x2_base() { return TB_WORDS + (256 / G) * GE_STRIDE; }
+// waves per role in a workgroup of the split kernel (4: one 512-thread workgroup per CU; 2: two 256-thread workgroups per CU with barrier domains of their own)
+#ifndef USIM_WPR16
+#define USIM_WPR16 4
+#endif
+#ifndef USIM_ROLE_FLIP_BIT
+#define USIM_ROLE_FLIP_BIT -1
+#endif
+template <int G> constexpr int wpr() { return G == 16 ? USIM_WPR16 : 4; }
+template <int G> constexpr int x2_base() { return TB_WORDS + (64 * wpr<G>() / G) * GE_STRIDE; }
 // 64 transpose scratch | 12 pose (+ the arm side's hit count in word 9) | 64 op-space (6 x 8 Lambda^-1, alpha 6, vs 6) | 16 wrench + contacts | the arm side's contact records
 // 16-lane groups: 64 transpose scratch | 12 pose | 64 op-space | 16 wrench + contacts | 17 x 8 arm-side contact records | 100 queue.
 // 8-lane groups (32 environments per workgroup have to fit the CU's 160 KB): the arm side's contact records overlay the transpose scratch, which
@@ -287,7 +295,7 @@ struct Carry {
 };
 
 template <int TORSO, int ROLE, int G> constexpr int arm_lds_base() {
-    return ROLE != 0 ? x2_base<G>() + (256 / G) * x2_stride<G>() : (TORSO ? GroupGeom<16>::LDS_WORDS : 16 * X16_RIGID_STRIDE);
+    return ROLE != 0 ? x2_base<G>() + (64 * wpr<G>() / G) * x2_stride<G>() : (TORSO ? GroupGeom<16>::LDS_WORDS : 16 * X16_RIGID_STRIDE);
 }
 static_assert((arm_lds_base<1, 1, 8>() + ARM_LDS_WORDS) * 4 <= 160 * 1024 && arm_lds_base<1, 1, 8>() % 4 == 0 && arm_lds_base<1, 1, 16>() % 4 == 0 && arm_lds_base<1, 0, 16>() % 4 == 0
               && arm_lds_base<0, 0, 16>() % 4 == 0, "arm table behind the LDS blocks of every 16-lane kernel");
@@ -295,14 +303,15 @@ static_assert((arm_lds_base<1, 1, 8>() + ARM_LDS_WORDS) * 4 <= 160 * 1024 && arm
 template <int TORSO, int MODE, int ROLE, int NT, int G = 16, bool RES = false>
 DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __restrict__ st, const int n, const int npad, const DevIO& io, const int flags, const long long rstep,
                    const bool first_pass, const int sub, int& nbar, Carry<TORSO ? (N_TOP + G - 1) / G : 1>& cy) {
-    constexpr int EPW = 64 / G, EPB = 4 * EPW;                          // environments per wave / per workgroup (four waves per role)
+    constexpr int WPR = (ROLE != 0) ? wpr<G>() : 4;
+    constexpr int EPW = 64 / G, EPB = WPR * EPW;                        // environments per wave / per workgroup (WPR waves per role)
     static_assert(!RES || MODE == 0, "resident state: step launches only");
     constexpr int X2_BASE = x2_base<G>(), X2_STRIDE = x2_stride<G>(), MB_Q = mb_q<G>(), MB_POSE = mb_pose<G>(), MB_OP = mb_op<G>(), MB_W = mb_w<G>(), MB_CA = mb_ca<G>();
     constexpr unsigned GMASK = (G == 16) ? 0xffffu : 0xffu;
     static_assert(G == 16 || (TORSO == 1 && MODE == 0 && ROLE != 0), "8-lane groups: the split soft-torso step only");
     constexpr int NE = TORSO ? (N_TOP + G - 1) / G : 1;
     static_assert(ROLE == 0 || (TORSO == 1 && MODE == 0), "the split kernel is the soft-torso step");
-    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;      // wave within its role = quad of environments
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & (WPR - 1);      // wave within its role = quad of environments
     // resident state (see Carry): everywhere but on the lattice side of the split kernel with 16-lane groups, where it measured slower (one box,
     // us/step at 4096 envs: neither side 15.00, arm side only 14.78, both 15.28, lattice side only 15.60; 8-lane groups at 8192 envs: 23.10 / 22.73 / 22.67)
     constexpr bool RES_HERE = RES && !(ROLE == 2 && G == 16);
@@ -435,7 +444,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
     const int tphys = (MODE == 0) ? (t - 1) * C.substeps + sub : 0;     // physics steps since the episode began (prescribed torso drop)
     const float dt = C.dt, inv_h = rcp_((float)C.horizon);
 #if defined(USIM_TSTAMP) || defined(USIM_TSTAMP_NOWAIT)
-#define RSTAMP(k) do { if (dbg && blockIdx.x == 0 && (threadIdx.x & 255) == 0) dbg[(ROLE == 2 ? 30 : 20) + (k)] = __builtin_readcyclecounter(); } while (0)
+#define RSTAMP(k) do { if (dbg && blockIdx.x == 0 && (threadIdx.x & (64 * WPR - 1)) == 0) dbg[(ROLE == 2 ? 30 : 20) + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define RSTAMP(k) do { } while (0)
 #endif
@@ -1289,7 +1298,7 @@ DI void step16_body(float* lds, const DevModel& M, const DevCfg& C, float* __res
         }
     }
 #if defined(USIM_TSTAMP) || defined(USIM_TSTAMP_NOWAIT)
-    if (ROLE != 0 && io0.dbg && blockIdx.x == 0 && (threadIdx.x & 255) == 0) io0.dbg[ROLE == 1 ? 46 : 47] = (unsigned long long)nbar;
+    if (ROLE != 0 && io0.dbg && blockIdx.x == 0 && (threadIdx.x & (64 * wpr<G>() - 1)) == 0) io0.dbg[ROLE == 1 ? 46 : 47] = (unsigned long long)nbar;
 #endif
 }
 
@@ -1311,11 +1320,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 // G = 16: 16 environments per workgroup (a quad per wave pair).  G = 8: 32 environments per workgroup (eight per wave pair; two per DPP row) -- the
 // mapping for more than 4096 envs/GPU, where 16-lane groups would need a second round of workgroups.
 template <bool MULTI, int G = 16>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void usim_step32_kernel(const DevModel M, const DevCfg C, float* __restrict__ st, int n, int npad,
-                                                                                                       const DevIO io, int flags, long long rstep) {
+__global__ __launch_bounds__(128 * wpr<G>()) __attribute__((amdgpu_waves_per_eu(2, 2))) void usim_step32_kernel(const DevModel M, const DevCfg C, float* __restrict__ st, int n, int npad,
+                                                                                                                  const DevIO io, int flags, long long rstep) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    if (threadIdx.x < 256) step16_body<1, 0, 1, 512, MULTI, G>(lds, M, C, st, n, npad, io, flags, rstep);
-    else step16_body<1, 0, 2, 512, MULTI, G>(lds, M, C, st, n, npad, io, flags, rstep);
+    constexpr int NT = 128 * wpr<G>();
+    // (two workgroups per CU: the role order alternates with a bit of the workgroup index, so that a SIMD holds an arm wave of one and a lattice wave of the other)
+    const bool flip = USIM_ROLE_FLIP_BIT >= 0 && ((blockIdx.x >> (USIM_ROLE_FLIP_BIT >= 0 ? USIM_ROLE_FLIP_BIT : 0)) & 1);
+    if ((threadIdx.x < NT / 2) != flip) step16_body<1, 0, 1, NT, MULTI, G>(lds, M, C, st, n, npad, io, flags, rstep);
+    else step16_body<1, 0, 2, NT, MULTI, G>(lds, M, C, st, n, npad, io, flags, rstep);
 }
 
 }  // namespace usim
