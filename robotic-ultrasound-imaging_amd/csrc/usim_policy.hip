@@ -11,6 +11,10 @@
 //   [usim_step]
 //   usim_policy_reward      discounted-return statistics (RunningMeanStd on the returns), reward normalisation + clip, buffer write
 //   usim_policy_gae         RolloutBuffer.compute_returns_and_advantage, one thread per environment, once per rollout
+// or, up to 8192 environments, two launches per step:
+//   usim_policy_step_fused  the policy launch with both VecNormalize updates inside: its workgroups exchange partial sums through device-scope stores /
+//                           loads and arrival flags (no fences: see the kernel), then normalise and run the MLPs as above
+//   [usim_step]
 // The weights are read from the caller's tensors (torch parameters: an optimiser step is seen by the next call); nothing is copied.
 // Numerics: same formulas as policy.DeviceVecNormalize / MlpActorCritic; sums are ordered differently from PyTorch's kernels, so results agree to
 // rounding (tests/test_gpu_policy_replay.py: 1e-5 on means / values / log-probs, 1e-12 relative on the float64 statistics), not bit for bit.
