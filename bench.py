@@ -204,7 +204,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     dev_ms = sum(a.elapsed_time(b_) for a, b_ in evs)
-    # the event brackets contain the step launches and, every 64 steps, one reset-bank refill launch: take its device time out, so that
+    # the event brackets contain the step launches and, every 256 steps, one reset-bank refill launch: take its device time out, so that
     # avg_kernel_us is the step kernel's (what a rocprofv3 kernel trace reports for it)
     refill_ms1, refill_n1 = env.refill_time()
     refill_ms, refill_n = refill_ms1 - refill_ms0, refill_n1 - refill_n0

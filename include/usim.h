@@ -163,8 +163,8 @@ int usim_random_actions(usim_handle* h, int64_t step, float* act_dev, void* stre
  * slice k (SB3 RolloutBuffer layout, the unit that is all-gathered across GPUs). */
 int usim_rollout_random(usim_handle* h, int64_t first_step, int nsteps, const usim_step_io* io, int block_advance, void* stream);
 
-/* Refill the reset bank now (the launch usim_step issues by itself every 64 steps: the initial states of the episodes that will reuse the ring slots
- * consumed since the last refill) and restart the 64-step period.  For callers that record a FIXED sequence of steps once and replay it -- a HIP
+/* Refill the reset bank now (the launch usim_step issues by itself every 256 steps: the initial states of the episodes that will reuse the ring slots
+ * consumed since the last refill) and restart the 256-step period.  For callers that record a FIXED sequence of steps once and replay it -- a HIP
  * graph captured around T x usim_step (policy.GraphedCollector): the period counter lives on the host and does not advance at replay, so such a
  * sequence starts and ends with this call (every ring is then valid at every replay, whatever T).  Capture-safe: on a stream that is being captured
  * the library records kernel launches only (no events, no synchronising call).  Nothing in the reference corresponds to it (a reset there
@@ -176,7 +176,7 @@ int usim_refill_bank(usim_handle* h, void* stream);
  * step still reads and writes its state and its slice of the rollout block in HBM.  The results do not depend on the value (bit for bit). */
 int usim_set_steps_per_launch(usim_handle* h, int steps);
 
-/* Device time spent so far in the reset-bank refill launches of this handle (one every 64 steps with auto-reset: the initial-pose IK and
+/* Device time spent so far in the reset-bank refill launches of this handle (one every 256 steps with auto-reset: the initial-pose IK and
  * zero-torque forward pass of the episodes that will start next), from HIP events around them on their stream.  Blocks
  * until the refill launches issued so far have finished.  bench.py subtracts it from the event time of its step blocks to get the duration of
  * the step kernel alone -- the number a rocprofv3 kernel trace reports. */

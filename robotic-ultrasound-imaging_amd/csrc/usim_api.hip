@@ -316,7 +316,7 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
         const int shape = cfg->torso_shape ? 1 : 0;
         C.top_off = (float)kTopOff[shape]; C.y_range = (float)kYRange[shape]; C.drop = (float)(kTorsoZ[shape] - 0.0525 - 0.8);
     }
-    if (const char* spl = std::getenv("USIM_STEPS_PER_LAUNCH")) { const int v = std::atoi(spl); if (v >= 1 && v <= BANK_DEPTH) h->steps_per_launch = v; }
+    if (const char* spl = std::getenv("USIM_STEPS_PER_LAUNCH")) { const int v = std::atoi(spl); if (v >= 1 && v <= MAX_STEPS_PER_LAUNCH) h->steps_per_launch = v; }
     h->nfields = h->n_el ? F_TOTAL_TOP : F_NSCALAR;
     h->bank_row0 = h->nfields;                                  // two reset-bank slots follow the live state rows
     size_t bytes = (size_t)(h->nfields + BANK_ROWS) * h->npad * sizeof(float);
@@ -393,7 +393,7 @@ int usim_set_mapping(usim_handle* h, int lanes_per_env, int waves_per_simd) {
 }
 
 int usim_set_steps_per_launch(usim_handle* h, int steps) {
-    if (!h || steps < 1 || steps > BANK_DEPTH) return USIM_ERR_INVALID;
+    if (!h || steps < 1 || steps > MAX_STEPS_PER_LAUNCH) return USIM_ERR_INVALID;
     h->steps_per_launch = steps;
     return USIM_OK;
 }

@@ -412,7 +412,7 @@ class GraphedCollector:
     captured into one graph; `collect()` replays it.  Semantics are those of collect_rollouts (same operations in the same order on the same
     tensors): `tests/test_gpu_policy_replay.py` compares the two bit for bit.
 
-    The simulator's reset bank is refilled every 64 steps by a launch that usim_step issues from a HOST counter, which does not advance at replay:
+    The simulator's reset bank is refilled every 256 steps by a launch that usim_step issues from a HOST counter, which does not advance at replay:
     the recorded sequence therefore starts and ends with an explicit refill (env.refill_bank) and contains the periodic ones in between, so every
     ring is valid at every replay for any T.  Sampling uses the default CUDA generator (graph-safe: the Philox offset advances per replay) or a
     generator registered with the graph.  The policy's parameters are read at their addresses: an optimiser that updates them in place (torch.optim)

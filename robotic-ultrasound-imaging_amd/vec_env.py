@@ -154,7 +154,7 @@ class UltrasoundVecEnv:
         return ms.value, cnt.value
 
     def refill_bank(self):
-        """refill the reset bank now and restart its 64-step period (include/usim.h usim_refill_bank; capture-safe)"""
+        """refill the reset bank now and restart its 256-step period (include/usim.h usim_refill_bank; capture-safe)"""
         self._check(self.lib.usim_refill_bank(self._handle, self._stream()))
 
     def set_steps_per_launch(self, steps):

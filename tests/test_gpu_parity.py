@@ -355,9 +355,9 @@ def test_contact_slot_overflow_parity(usim, lanes):
 
 
 def test_reset_bank_ring_wraps(usim):
-    """80 episodes per environment -- more than the 64 prepared episodes of the reset bank: the slots refilled by the bulk refill
-    launches (one per 64 steps) must hold exactly the episodes the oracle draws when it gets there"""
-    n, H, steps = 48, 5, 400
+    """280 episodes per environment -- more than the 256 prepared episodes of the reset bank: the slots refilled by the bulk refill
+    launches (one per 256 steps) must hold exactly the episodes the oracle draws when it gets there"""
+    n, H, steps = 48, 5, 1400
     kw = usim.default_robosuite_kwargs(); kw["horizon"] = H; kw["early_termination"] = False
     kw.update(deterministic_trajectory=False)
     env = usim.UltrasoundVecEnv(n, device="cuda:0", seed=11, torso="soft", **kw)
@@ -376,7 +376,7 @@ def test_reset_bank_ring_wraps(usim):
         if done_o[0]:
             tg = np.stack([i["terminal_observation"] for i in infos])
             assert np.abs(tg[:, 12:19] - term_o[:, 12:19]).max() < 2e-5, k
-    assert ndone == steps // H and ndone > 64
+    assert ndone == steps // H and ndone > 256
     sg, so = env.get_state(), ora.get_state()
     assert np.array_equal(sg["episode"], so["episode"]) and np.allclose(sg["traj_start"], so["traj_start"], atol=1e-6)
     env.close()
