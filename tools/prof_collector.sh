@@ -7,6 +7,7 @@ export FUSED_ONLY=1
 rm -rf /tmp/prof_coll
 rocprofv3 --kernel-trace --stats -d /tmp/prof_coll -o coll --output-format csv -- python3 "$ROOT/tools/collector_probe.py" $N 128 3 > /tmp/prof_coll.log 2>&1
 f=$(find /tmp/prof_coll -name '*kernel_stats.csv' | head -1)
+cp "$f" "$ROOT/gpurun_out/prof_collector_${N}_kernel_stats.csv"
 python3 - "$f" <<'PY' | tee "$ROOT/gpurun_out/prof_collector_$N.txt"
 import csv, sys
 for i, r in enumerate(csv.reader(open(sys.argv[1]))):
