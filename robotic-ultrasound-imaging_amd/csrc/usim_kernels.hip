@@ -522,7 +522,12 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
     // ---- contact k lives in the registers of lane k of its group.  Set-up: row directions w, Lambda^-1 w, element
     //      coupling g, reference acceleration, regulariser; Km[c] = Linv[e_own][e_c] / m ----
     USIM_CSTAMP(dbg, 0);
-    const bool own = gl < nc;
+    // 16 lanes per environment, eight contact slots: lanes 8-15 would idle through the set-up.  They CLONE lanes 0-7 instead (lane 8 + k forms the same rows
+    // of contact k, at no cost: same instructions) and take half of the Delassus blocks off them below.  Everything that leaves this function is masked to
+    // lanes 0-7 or to lane k: forces stay zero in the clones (only lane k keeps an increment), the wrench sum and the publications read lanes < MAXC.
+    constexpr bool CLONE = (G == 16) && !PRE;
+    const int cl = CLONE ? (gl & 7) : gl;
+    const bool own = cl < nc;
     float w[3][6], Liw[3][6], g[3], invD[3], Rd[3], f[3] = {0.f, 0.f, 0.f}, cres[3] = {0.f, 0.f, 0.f}, Km[MAXC];
     if constexpr (PRE) {
 #pragma unroll
@@ -561,7 +566,7 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
         for (int a = 0; a < 6; ++a) { w[d][a] = 0.f; Liw[d][a] = 0.f; }
     }
     if (own) {
-        const int b = GE_CG + gl * CG_WORDS;
+        const int b = GE_CG + cl * CG_WORDS;
         f3 nn = mk(EB(b + 0), EB(b + 1), EB(b + 2)), rr = mk(EB(b + 3), EB(b + 4), EB(b + 5));
         const int e = __float_as_int(EB(b + 6));
         const float dist = EB(b + 7);
@@ -621,6 +626,64 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
         pub[4] = make_float4(Liw[2][4], Liw[2][5], g[0], g[1]); pub[5] = make_float4(g[2], 0.f, 0.f, 0.f);
     }
     group_sync();
+    if constexpr (CLONE) {
+        // lanes 0-7 form the blocks of contacts 0-3, their clones (lanes 8-15) those of contacts 4-7; one rotation of the DPP row by eight lanes per word
+        // then brings the clones' blocks home.  Same multiply-adds per block as below, in the same order: the same bits.
+        const bool hi = gl >= 8;
+        const int k0 = hi ? 4 : 0;
+        float X[4][3][3];
+        float4 rk[6];
+        {
+            const float4* src = reinterpret_cast<const float4*>(&EB(k0 * 24));
+#pragma unroll
+            for (int v = 0; v < 6; ++v) rk[v] = src[v];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < ncmax) {
+                const float Kmj = hi ? Km[4 + j] : Km[j];
+                const float Lk[3][6] = {{rk[0].x, rk[0].y, rk[0].z, rk[0].w, rk[1].x, rk[1].y}, {rk[1].z, rk[1].w, rk[2].x, rk[2].y, rk[2].z, rk[2].w},
+                                        {rk[3].x, rk[3].y, rk[3].z, rk[3].w, rk[4].x, rk[4].y}};
+                const float gk[3] = {rk[4].z * Kmj, rk[4].w * Kmj, rk[5].x * Kmj};
+                if (j + 1 < 4) {
+                    const float4* src = reinterpret_cast<const float4*>(&EB((k0 + j + 1) * 24));
+#pragma unroll
+                    for (int v = 0; v < 6; ++v) rk[v] = src[v];
+                }
+#pragma unroll
+                for (int dd = 0; dd < 3; ++dd) {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        float r1 = fmaf(w[d][4], Lk[dd][4], fmaf(w[d][2], Lk[dd][2], w[d][0] * Lk[dd][0]));
+                        float r2 = fmaf(w[d][5], Lk[dd][5], fmaf(w[d][3], Lk[dd][3], w[d][1] * Lk[dd][1]));
+                        X[j][d][dd] = fmaf(g[d], gk[dd], r1 + r2);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < ncmax) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+#pragma unroll
+                    for (int dd = 0; dd < 3; ++dd) B[j][d][dd] = X[j][d][dd];
+            }
+            if (4 + j < ncmax) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+#pragma unroll
+                    for (int dd = 0; dd < 3; ++dd) B[4 + j][d][dd] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X[j][d][dd]), 0x128, 0xf, 0xf, true));   // row_ror:8
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) {
+            if (k < ncmax && gl == k && own) {      // lanes without a contact keep invD = 0: their solve below yields zeros
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { B[k][d][d] += Rd[d]; invD[d] = rcp_(B[k][d][d]); }
+            }
+        }
+    } else {
     float4 rk[6];
     {
         const float4* src = reinterpret_cast<const float4*>(&EB(0));
@@ -652,6 +715,7 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
                 for (int d = 0; d < 3; ++d) { B[k][d][d] += Rd[d]; invD[d] = rcp_(B[k][d][d]); }
             }
         }
+    }
     }
     USIM_CSTAMP(dbg, 2);
     // ---- projected Gauss-Seidel on the dual over the contact rows (fixed sweeps, cold start).  Contacts are visited in
