@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/s of the batched Ultrasound step at 4096 envs/GPU, random-action rollout
-(BASELINE.json metric).  One process per GPU; for N > 1 the driver launches this file under torch.distributed.run.
+(BASELINE.json metric).  One process per GPU; for N > 1 the driver launches this file under torch.distributed.run -- and
+`python bench.py --gpus N` without a launcher starts those N ranks itself (child processes, before anything touches a GPU).
 
 A "step" is one env.step() of every environment of the rank (controller + forward dynamics + soft contact + sensors +
 reward + termination + auto-reset), actions drawn in-kernel from the counter-based stream of BASELINE.md section 4,
@@ -59,9 +60,26 @@ def cpu_baseline(workload, n_envs, budget_s=float(os.environ.get("USIM_CPU_BUDGE
                       f"{'-O3 -march=native' if native else '-O3'}"}
 
 
+def _self_launch(gpus, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, as CHILD processes of a parent that has
+    not touched a GPU (nothing above this line imports torch), exactly the way the driver would -- torch.distributed.run, one rank per GPU,
+    rendezvous on 127.0.0.1 -- and leave with the launcher's exit code.  (Never re-exec a process that has initialised the GPU.)"""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL / device-tensor sharing across processes needs it on this image
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks of this node (default: WORLD_SIZE of the launcher, else 1).  N > 1 without a launcher "
+                    "around it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` itself")
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--presteps", type=int, default=0, help="studies only: untimed steps between the synchronous reset and the warm-up (after one horizon the episodes of "
@@ -73,51 +91,66 @@ def main():
     ap.add_argument("--randomize", action="store_true", help="BASELINE configs[4]: per-env randomised stiffness/damping + probe friction")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--adaptive", action="store_true", help="N > 1: start every block with the collective-tolerant mapping only for as long as the previous "
-                    "block's all-gather took, then switch to the split kernel (default: the split kernel throughout)")
     ap.add_argument("--gather", choices=["rccl", "p2p"], default="rccl", help="N > 1: RCCL all-gather (resident workgroups on the CUs) or peer-to-peer copies "
                     "of the packed block (copy engines, no CUs; distributed.P2PRolloutGather)")
     ap.add_argument("--steps-per-launch", type=int, default=0, help="consecutive steps per kernel launch of the rollout (1 .. 64; default: the library's, 64)")
     ap.add_argument("--lanes-per-env", type=int, default=0, choices=[0, 1, 8, 16, 32, 64], help="kernel mapping: 16 lanes per environment (automatic), 8 (soft torso) or 1 (rigid torso)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    launched = "WORLD_SIZE" in os.environ or "RANK" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus is None:
+        args.gpus = world
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if not launched and args.gpus > 1:
+        sys.exit(_self_launch(args.gpus, sys.argv[1:]))
+    if world != args.gpus:
+        # a 1-GPU number labelled n_gpus 1 must never answer a request for N
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an AMD GPU: the simulator has no CPU path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+
+    import torch
+    import torch.distributed as dist
+    # USIM_BENCH_STUB=<module in tests/>: the N > 1 plumbing of this file (self-launch, rendezvous, sharding by env_offset, the gather of every block,
+    # max-over-ranks timing, the JSON line) on CPU tensors over gloo with a stand-in stepper -- tests/test_bench_launch.py; never a measurement
+    stub = os.environ.get("USIM_BENCH_STUB")
+    on_gpu = not stub
+    if on_gpu:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an AMD GPU: the simulator has no CPU path")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    else:
+        device = torch.device("cpu")
     use_dist = world > 1 or os.environ.get("USIM_BENCH_FORCE_GATHER") == "1"      # the env var exercises the RCCL path on one GPU
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        if on_gpu:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    ranks_seen = dist.get_world_size() if use_dist else 1
 
-    usim = importlib.import_module("robotic-ultrasound-imaging_amd")
-    from importlib import import_module
-    dmod = import_module("robotic-ultrasound-imaging_amd.distributed")
     n = args.envs_per_gpu
     extra = {"friction_randomization": 1} if args.randomize else {}
     with_gather = use_dist and not args.no_gather
-    # N > 1, soft torso.  The step kernel wants one 512-thread workgroup per CU with the whole register file; the resident workgroups of an
-    # overlapped RCCL all-gather take CUs away, and the displaced step workgroups then run in a second round (tools/gpu_interference.py, a
-    # stand-in of RCCL's footprint: 19.9 -> 30 us/step).  Default ("plain"): the same split kernel as for N = 1 and the RCCL all-gather on a
-    # side stream -- nothing tuned on measurements that could not be taken here (the pool has one GPU per box).  --adaptive: start every
-    # block with the two-waves-per-SIMD 16-lane mapping for as long as the previous gather took, then switch (round 2; the mappings compute
-    # the same bits).  --gather p2p: move the blocks with peer-to-peer copies instead of a collective kernel -- no CUs taken
-    # (distributed.P2PRolloutGather; validated with two processes on one GPU only).
-    adaptive = with_gather and args.adaptive and args.gather == "rccl" and args.workload == "soft" and args.lanes_per_env == 0 and n <= 4096
+    # N > 1.  One default: the same kernels as for N = 1 on every rank and the RCCL all-gather of each finished rollout block on a side stream while
+    # the next block is simulated.  One flag: --gather p2p moves the blocks with peer-to-peer copies into IPC-mapped buffers instead of a collective
+    # kernel (distributed.P2PRolloutGather: no workgroups on the CUs next to the step kernels; validated with two processes on one GPU only).
     if args.lanes_per_env:
         extra["lanes_per_env"] = args.lanes_per_env
-    env = usim.UltrasoundVecEnv(n, device=device, seed=3, env_offset=rank * n, torso=args.workload, **extra, **usim.default_robosuite_kwargs())
+    if on_gpu:
+        usim = importlib.import_module("robotic-ultrasound-imaging_amd")
+        env = usim.UltrasoundVecEnv(n, device=device, seed=3, env_offset=rank * n, torso=args.workload, **extra, **usim.default_robosuite_kwargs())
+    else:
+        env = importlib.import_module(stub).StubEnv(n, env_offset=rank * n)
+    dmod = importlib.import_module("robotic-ultrasound-imaging_amd.distributed")
     T = max(1, min(args.block, args.steps))
     blocks = [env.alloc_block(T), env.alloc_block(T)]      # double-buffered: gather block b while simulating b^1
-    gather = (dmod.P2PRolloutGather(device=device) if args.gather == "p2p" else dmod.RolloutGather(device=device)) if with_gather else None
+    gather = (dmod.P2PRolloutGather(device=device) if args.gather == "p2p" else dmod.RolloutGather(device=device if on_gpu else None)) if with_gather else None
     if args.steps_per_launch:
         env.set_steps_per_launch(args.steps_per_launch)
 
@@ -129,37 +162,35 @@ def main():
         env.rollout_random(step, k, blocks[0])
         step += k; done_p += k
     done_w = 0
-    adaptive_ms = []
-    if adaptive and args.warmup > 0:
-        env.set_mapping(16, 2)                             # the warm-up doubles as the measurement of the collective-tolerant build's step time
     while done_w < args.warmup:                            # untimed warm-up steps
         k = min(T, args.warmup - done_w)
-        if adaptive:
-            adaptive_ms.append(env.time_steps(step, k, blocks[0]))
-        else:
-            env.rollout_random(step, k, blocks[0])
+        env.rollout_random(step, k, blocks[0])
         step += k; done_w += k
-    if adaptive:
-        env.set_mapping(32, 0)
+    gathered = None
     if gather is not None:
-        gather.gather_async(blocks[0]); gather.wait()
+        gather.gather_async(blocks[0]); gathered = gather.wait()
 
     def slice_block(blk, lo, hi):
         return {key: t[lo:hi] for key, t in blk.items()}
 
-    robust_ms = (sum(adaptive_ms) / args.warmup) if adaptive_ms else 0.023
-
     def sync():
-        torch.cuda.synchronize(device)
+        if on_gpu:
+            torch.cuda.synchronize(device)
         if use_dist:
             dist.barrier()
-            torch.cuda.synchronize(device)
+            if on_gpu:
+                torch.cuda.synchronize(device)
+
+    class _NoEvent:                                        # stub run: no device, no device events
+        def record(self): pass
+        def elapsed_time(self, other): return 0.0
+    new_event = (lambda: torch.cuda.Event(enable_timing=True)) if on_gpu else _NoEvent
 
     # Everything the timed loop needs is built before the clock starts (events, the step-io blocks of every slice of both rollout blocks):
     # between the synchronise and the first launch the device is idle, and for a short run (the driver times 20 steps) every
     # microsecond of Python in there shows up in the result.
     n_blocks = (args.steps + T - 1) // T
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_blocks)]
+    evs = [(new_event(), new_event()) for _ in range(n_blocks)]
     for e0, e1 in evs:                                     # torch creates the HIP event at its first record(): do that now, not in the timed region
         e0.record(); e1.record()
     io_cache = {}
@@ -174,7 +205,7 @@ def main():
     sync()
     refill_ms0, refill_n0 = env.refill_time()
     t0 = time.perf_counter()
-    done_s, b, ib = 0, 0, 0
+    done_s, b, ib, n_gathers = 0, 0, 0, 0
     # kernel-duration leg of the roofline: HIP events around every block of step launches, recorded on the launch stream (the
     # simulator is launched on torch's current stream, so torch events are events of that stream); read after the timed region,
     # the host never blocks inside it
@@ -182,28 +213,23 @@ def main():
         k = min(T, args.steps - done_s)
         e0, e1 = evs[ib]
         e0.record()
-        m = 0
-        if adaptive:                                       # steps that run next to the gather of the previous block
-            m = k if gather.last_ms is None else min(k, int(gather.last_ms * 1.25 / robust_ms) + 1)
-            env.set_mapping(16, 2)
-            rollout(step, m, io=io_of(b, 0, m))
-            env.set_mapping(32, 0)
-        if k > m:
-            rollout(step + m, k - m, io=io_of(b, m, k))   # with the gather: simulate block b while block b^1 is in flight
+        rollout(step, k, io=io_of(b, 0, k))               # with the gather: simulate block b while block b^1 is in flight
         e1.record()
         if gather is not None:
-            gather.wait()                                  # block b^1 is gathered before the next iteration overwrites it
+            g = gather.wait()                              # block b^1 is gathered before the next iteration overwrites it
+            gathered = gathered if g is None else g
             gather.gather_async(blocks[b])
+            n_gathers += 1
         step += k; done_s += k; b ^= 1; ib += 1
     if gather is not None:
-        gather.wait()
+        gathered = gather.wait()
     sync()
     elapsed = time.perf_counter() - t0
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    dev_ms = sum(a.elapsed_time(b_) for a, b_ in evs)
+    dev_ms = sum(a.elapsed_time(b_) for a, b_ in evs) if on_gpu else elapsed * 1e3
     # the event brackets contain the step launches and, every 256 steps, one reset-bank refill launch: take its device time out, so that
     # avg_kernel_us is the step kernel's (what a rocprofv3 kernel trace reports for it)
     refill_ms1, refill_n1 = env.refill_time()
@@ -234,21 +260,23 @@ def main():
     spl = max(1, min(spl, T, args.steps))
     wl = "randomised" if (args.randomize and args.workload == "soft" and n == 8192) else args.workload
     if rank == 0:
-        total_steps = args.steps * n * world
+        total_steps = args.steps * n * ranks_seen
         out = {
             "metric": "env-steps/sec (whole node) at 4096 envs/GPU, random-action rollout",
-            "value": total_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": total_steps / elapsed, "unit": "env-steps/s", "n_gpus": ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOAD_NAME[wl], "envs_per_gpu": n, "global_envs": n * world,
+            "config": {"workload": WORKLOAD_NAME[wl], "envs_per_gpu": n, "global_envs": n * ranks_seen,
                        "controller": "OSC_POSE impedance_mode=tracking", "rollout_block": T,
-                       "presteps": args.presteps,           # untimed steps before the warm-up that de-synchronise the episodes after the synchronous reset (0: none) "domain_randomisation": "stiffness+damping" + ("+friction" if args.randomize else ""),
+                       "presteps": args.presteps,           # untimed steps before the warm-up that de-synchronise the episodes after the synchronous reset (0: none)
+                       "domain_randomisation": "stiffness+damping" + ("+friction" if args.randomize else ""),
                        "parallelism": f"env-shard x{world}" + ("" if gather is None else (" + RCCL all-gather of transition blocks" if args.gather == "rccl" else
                                                                  " + peer-to-peer copies of transition blocks (copy engines)")),
-                       "gather": None if gather is None else args.gather, "mapping_next_to_gather": None if gather is None else ("adaptive" if adaptive else "plain"),
-                       "steps_per_launch": spl,
-                       "lanes_per_env": lanes if not adaptive else "32, and 16 (two waves per SIMD) while the previous block is gathered",
-                       "waves_per_simd": int(extra.get("waves_per_simd", 0)) or "auto"},
+                       "steps_per_launch": spl, "lanes_per_env": lanes, "waves_per_simd": int(extra.get("waves_per_simd", 0)) or "auto"},
+            # what actually ran: the ranks the process group saw (never the --gpus argument), and the exchange step of the N > 1 path
+            "ranks_seen": ranks_seen,
+            "gather": None if gather is None else {"kind": args.gather, "backend": dist.get_backend(), "blocks_in_timed_region": n_gathers,
+                                                   "last_ms": gather.last_ms, "result_shape": None if gathered is None else list(gathered.shape)},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                          # HBM bytes per launch from the committed PMC profile (FETCH_SIZE with the guide's gfx950 x2 correction + WRITE_SIZE).  Far below the
                          # algorithmic bytes: inside a multi-step launch the state of the 4096 environments (7.8 MB) stays in the XCDs' L2 from one step
@@ -263,7 +291,7 @@ def main():
                          "valu_fp32_tflops": valu_tflops, "valu_frac": valu_tflops / FP32_VALU_PEAK_TFLOPS,
                          "note": "kernel is FP32-VALU/latency bound at 4096 envs (one or two waves per SIMD, serial per-environment chain), not HBM bound; see DESIGN.md section 5"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and on_gpu and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, n)
         result = json.dumps(out)
     else:

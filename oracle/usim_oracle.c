@@ -138,7 +138,7 @@ static const double PROBE_POS[3] = {-0.004, -0.063, 0.128};   /* ultrasound_prob
  * 60 x 20 mm.  The XML declares TWO colliding geoms on the mesh (uso_config.probe_geoms: `probe_visual` lacks
  * contype = conaffinity = 0, ultrasound_probe_gripper.xml:9), the second with MuJoCo's default friction 1.0 -- where the lateral forces and the
  * torque about the probe axis of the reference's reset rows come from.  Sizes calibrated with that contact law on all six force / torque
- * channels of the 192 decoded reset observations (tests/calib_probe.py, profiles/r03/calib_probe.txt; tests/test_oracle_env_formulas.py) */
+ * channels of the 192 decoded reset observations (tests/studies/calib_probe.py, profiles/r03/calib_probe.txt; tests/test_oracle_env_formulas.py) */
 static const double PROBE_COM[3] = {0.0013, 0.021, -0.043};
 static const double PROBE_INERTIA[3] = {1.6e-3, 1.6e-3, 2.0e-4};
 #define PROBE_RADIUS 0.010

@@ -68,10 +68,10 @@ typedef struct uso_config {
     double probe_radius2, probe_height;   /* ... radius of the upper edge of the flared blade and its height above the tip axis */
     int32_t substeps;             /* physics steps per env.step(): int(control_timestep / model_timestep) of robosuite MujocoEnv.step [RESTATED, SURVEY C.1];
                                    * control_dt is the CONTROL timestep (ultrasound.py:542), the physics step is control_dt / substeps (0 or 1: one) */
-    int32_t lattice_ramp;         /* STUDY switch, oracle only (tests/lattice_ramp_study.py): 1 = evaluate MuJoCo's impedance ramp d(r) of solimp (0.9 0.95 0.001 0.5 2)
+    int32_t lattice_ramp;         /* STUDY switch, oracle only (tests/studies/lattice_ramp_study.py): 1 = evaluate MuJoCo's impedance ramp d(r) of solimp (0.9 0.95 0.001 0.5 2)
                                    * on every lattice row (the lattice matrix is then assembled and factorised per step); 0 = the product's model, d fixed at
                                    * d_max = 0.95 so that the inverse is a constant */
-    double study_fix_tc;          /* STUDY switch, oracle only (tests/sustained_load_study.py): time constant of the joint-equality ("fix") rows of the lattice; 0 = MuJoCo's
+    double study_fix_tc;          /* STUDY switch, oracle only (tests/studies/sustained_load_study.py): time constant of the joint-equality ("fix") rows of the lattice; 0 = MuJoCo's
                                    * default solref time constant 0.02 s, which the product uses */
     double probe_friction2;       /* sliding friction of the probe's SECOND colliding geom, see probe_geoms (MuJoCo default 1.0) */
     int32_t probe_geoms;          /* 1: one probe geom collides; 2: two coincident ones (ultrasound_probe_gripper.xml:8-9: `probe_collision` AND `probe_visual` -- the

@@ -11,7 +11,17 @@ _IGNORED = {
     "env_id", "env_configuration", "use_camera_obs", "has_renderer", "has_offscreen_renderer", "render_camera",
     "render_collision_mesh", "render_visual_mesh", "render_gpu_device_id", "camera_names", "camera_heights",
     "camera_widths", "camera_depths", "reward_shaping", "reward_scale", "table_full_size", "table_friction",
-    "initialization_noise", "placement_initializer", "ignore_done", "hard_reset",
+    "initialization_noise",
+}
+# kwargs that change step()/reset() in the reference and are accepted at their default only (anything else raises; they used to be swallowed)
+_DEFAULT_ONLY = {
+    # robosuite MujocoEnv._post_action: done = timestep >= horizon and not ignore_done (ultrasound.py:121): True would silence the
+    # horizon part of `done`, which the device-side auto-reset and the trajectory parameter (ultrasound.py:528-529) are built on
+    "ignore_done": False,
+    # the torso is placed by _reset_internal itself (ultrasound.py:426-431); a sampler has nothing to place
+    "placement_initializer": None,
+    # hard_reset=False keeps the compiled model across resets, i.e. _load_model's stiffness / damping draw (ultrasound.py:289-297) would run once
+    "hard_reset": True,
 }
 # extensions of this build (not kwargs of the reference env)
 _NATIVE = {"torso", "friction_randomization", "torso_drop", "pgs_iters", "ik_iters", "lanes_per_env", "waves_per_simd", "stiffness", "damping",
@@ -106,6 +116,10 @@ def make_config(seed=3, env_offset=0, **kw):
     for k in ("stiffness", "damping", "elem_friction", "probe_friction", "probe_friction2", "probe_radius", "probe_halflen", "probe_radius2", "probe_height"):
         if k in kw:
             setattr(c, k, float(kw.pop(k)))
+    for k, default in _DEFAULT_ONLY.items():
+        if k in kw and kw[k] != default and not (default is None and kw[k] is None):
+            raise ValueError(f"{k}={kw[k]!r} is not implemented (only the reference's default {default!r}, ultrasound.py:99-132)")
+        kw.pop(k, None)
     for k in list(kw):
         if k in _IGNORED:
             kw.pop(k)

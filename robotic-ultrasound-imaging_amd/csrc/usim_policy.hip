@@ -514,6 +514,20 @@ int usim_policy_step_fused(const usim_policy_net* net, const usim_norm_stats* st
     if (!net || !st || !f || !obs_dev || !out || !out->act_env_dev || n <= 0 || act_dim < 1 || act_dim > 7 || !act_low_dev || !act_high_dev) return USIM_ERR_INVALID;
     if (!f->work_dev || (f->have_prev && (!f->rew_prev_dev || !f->done_prev_dev || !f->nrew_prev_dev))) return USIM_ERR_INVALID;
     if (n > USIM_POLICY_FUSED_MAX_ENVS) return USIM_ERR_UNSUPPORTED;          // every workgroup must be resident (see the kernel)
+    {
+        // The workgroups wait for one another inside an ordinary launch: that is only correct while the whole grid is resident at once.  Ask the
+        // runtime what this device (in its current partition mode / CU mask) holds instead of trusting the constant above; cached per device.
+        static int capacity[64];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return USIM_ERR_HIP;
+        if (capacity[dev] == 0) {
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, usim_policy_act_kernel<true>, 256, 0) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return USIM_ERR_HIP;
+            capacity[dev] = per_cu * cus > 0 ? per_cu * cus : -1;
+        }
+        if (2 * ((n + PL_TM - 1) / PL_TM) > capacity[dev]) return USIM_ERR_UNSUPPORTED;
+    }
     PolicyNet P{net->pi_w1, net->pi_b1, net->pi_w2, net->pi_b2, net->act_w, net->act_b, net->vf_w1, net->vf_b1, net->vf_w2, net->vf_b2, net->val_w, net->val_b, net->log_std};
     NormStats S{st->obs_mean, st->obs_var, st->obs_count, st->ret_mean, st->ret_var, st->ret_count, st->returns, st->clip_obs, st->clip_reward, st->gamma, st->epsilon};
     FusedArgs F{f->rew_prev_dev, f->done_prev_dev, f->nrew_prev_dev, f->raw_sum_dev, f->work_dev, f->update_obs, f->have_prev, f->norm_reward};

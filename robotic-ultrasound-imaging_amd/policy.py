@@ -287,7 +287,7 @@ def policy_rollout(env, policy, vecnorm, steps, deterministic=False, seed=0, fus
     Returns raw-observation running statistics (mean, var over all visited steps), mean reward per step, and episode stats.
     fused=True: normalisation, both MLPs, sampling and clipping by the library's policy kernel (usim_policy_step) instead of PyTorch modules."""
     dev = env.device
-    fr = FusedRollout(env, policy, vecnorm, DeviceRolloutBuffer(1, env.num_envs, 19, env.action_dim, device=dev), seed=seed, graph=False) if fused else None
+    fr = FusedRollout(env, policy, vecnorm, DeviceRolloutBuffer(1, env.num_envs, 19, env.action_dim, device=dev), seed=seed, graph=False, init_stats=False) if fused else None
     low = torch.as_tensor(env.action_space.low, device=dev)
     high = torch.as_tensor(env.action_space.high, device=dev)
     gen = torch.Generator(device=dev); gen.manual_seed(seed)
@@ -464,6 +464,7 @@ class GraphedCollector:
     def _record(self):
         vn, b = self.vecnorm, self.buffer
         obs, start = self.obs, self.episode_start
+        self.env.refill_bank()                 # first node of the recorded sequence as well as the last: a replay does not depend on what ran before it
         self.raw_reward_sum.zero_()
         done = None
         for t in range(b.buffer_size):
@@ -494,7 +495,7 @@ class FusedRollout:
     those objects is unchanged.  Differences from collect_rollouts: sums are ordered differently (agreement to rounding, not bit for bit) and the
     Gaussian noise comes from the library's counter-based stream (seed, environment, step), not from a torch generator."""
 
-    def __init__(self, env, policy, vecnorm, buffer, seed=0, graph=True, fused_stats=None):
+    def __init__(self, env, policy, vecnorm, buffer, seed=0, graph=True, fused_stats=None, init_stats=True):
         from . import _lib
         # fused_stats: VecNormalize's two updates inside the policy launch (usim_policy_step_fused: two launches per step instead of three).  Its workgroups wait
         # for one another, so all of them must be resident: by default only up to 4096 environments (256 workgroups, half of what the device holds -- room
@@ -531,7 +532,7 @@ class FusedRollout:
         self.obs = env.reset_tensor()                                                       # the env's own observation buffer: rewritten by every step
         self._prev_done = env._done                                                         # ... and its done flags: read by the policy kernel BEFORE the next step rewrites them
         self._prev_done.fill_(1)                                                            # every environment starts an episode
-        if vecnorm.training:                                                                # VecNormalize.reset(): the statistics see the reset observation
+        if vecnorm.training and init_stats:                                                 # VecNormalize.reset(): the statistics see the reset observation (init_stats=False: the caller's first act(training=1) does)
             self.act(self.obs, self._prev_done, counter=0, training=1, deterministic=True)
         self.graph = None
         if graph:
@@ -558,7 +559,7 @@ class FusedRollout:
         out = _lib.UsimPolicyOut(ptr(self._act_env), None if t is None else ptr(b.observations[t]), None if t is None else ptr(b.actions[t]),
                                  ptr(self._value) if t is None else ptr(b.values[t]), None if t is None else ptr(b.log_probs[t]), None if t is None else ptr(b.episode_starts[t]))
         self._check(self.lib.usim_policy_step(C.byref(self._net), C.byref(self._stats), ptr(obs), ptr(prev_done), env.num_envs, env.action_dim, ptr(self._low), ptr(self._high),
-                                              self.seed, int(counter) & 0xffffffff, ptr(self._ctr), int(getattr(env, "env_offset", 0)), int(training),
+                                              self.seed, int(counter) & 0xffffffff, ptr(self._ctr), int(env.env_offset), int(training),
                                               int(bool(deterministic)), C.byref(out), env._stream()))
         return self._act_env, (self._value if t is None else b.values[t])
 
@@ -580,7 +581,7 @@ class FusedRollout:
         f = self._fused(counter, rewards_out)
         self._check(self.lib.usim_policy_step_fused(C.byref(self._net), C.byref(self._stats), C.byref(f), ptr(obs), ptr(prev_done), env.num_envs, env.action_dim,
                                                     ptr(self._low), ptr(self._high), self.seed, int(counter) & 0xffffffff, ptr(self._ctr),
-                                                    int(getattr(env, "env_offset", 0)), int(bool(deterministic)), C.byref(out), env._stream()))
+                                                    int(env.env_offset), int(bool(deterministic)), C.byref(out), env._stream()))
 
     @property
     def wait_ran_out(self):
@@ -591,6 +592,7 @@ class FusedRollout:
         """one rollout with two launches per step: policy (+ the statistics of the observation it reads + the reward side of the step before), env"""
         env, b = self.env, self.buffer
         T, n = b.buffer_size, env.num_envs
+        env.refill_bank()                      # first node of the recorded sequence as well: a replay is valid whatever ran on the env since the last one
         self.raw_reward_sum.zero_()
         for t in range(T):
             self.act_fused(self.obs, self._prev_done, counter=t, rewards_out=b.rewards[t - 1] if t else None, t=t)
@@ -608,6 +610,7 @@ class FusedRollout:
             return self._record_fused()
         env, b, vn = self.env, self.buffer, self.vecnorm
         T, n = b.buffer_size, env.num_envs
+        env.refill_bank()                      # first node of the recorded sequence as well (usim.h: "the sequence starts and ends with it")
         self.raw_reward_sum.zero_()
         # The observation statistics follow VecNormalize's timing: RunningMeanStd.update(obs) when the environment RETURNS the observation (reset: once, in
         # __init__; step: in the launch that also does the reward side), so the policy kernel only normalises (training = 2) and the bootstrap value sees
@@ -623,13 +626,18 @@ class FusedRollout:
         self._ctr.add_(T + 1)
         env.refill_bank()
 
-    def collect(self):
-        """one rollout of buffer.buffer_size steps into the buffer (returns / advantages included)"""
+    def collect(self, check=True):
+        """one rollout of buffer.buffer_size steps into the buffer (returns / advantages included).  With the in-launch statistics exchange
+        (fused_stats) the status word of the exchange is read once per rollout (one host synchronisation; check=False leaves it to the caller):
+        a workgroup that gave up waiting for the others -- the device was shared with something that took its CUs -- has normalised with
+        partial sums, and the rollout must not be used."""
         if self.graph is not None:
             self.graph.replay()
         else:
-            self.env.refill_bank()
             self._record()
+        if check and self.fused_stats and self.wait_ran_out:
+            raise RuntimeError("usim_policy_step_fused: a workgroup ran out of its bounded wait for the other workgroups' statistics (device shared with "
+                               "another kernel?); this rollout's observation / return statistics are incomplete -- use FusedRollout(..., fused_stats=False)")
         self.counter += 1
         self.buffer.pos, self.buffer.full = self.buffer.buffer_size, True
         return self.obs, self._prev_done

@@ -79,6 +79,12 @@ class UltrasoundVecEnv:
         self._pending = False
         self.horizon = int(self.cfg.horizon)
 
+    @property
+    def env_offset(self):
+        """global index of this shard's environment 0: every per-environment stream of the library -- resets, synthetic actions, the policy's
+        exploration noise (usim_policy_step) -- is keyed (seed, env_offset + i)"""
+        return self._env_offset
+
     # ---- construction / teardown -------------------------------------------------------------------------------
     def _create(self, seed):
         if self._handle:

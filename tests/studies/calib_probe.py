@@ -2,9 +2,9 @@
 """Calibration of the probe stand-in (the probe mesh is missing from the reference snapshot) against the 192 decoded
 reset observations of the reference checkpoints (tests/golden/reference_pins.npz).
 
-    python tests/calib_probe.py                                   # reference statistics vs the current defaults
-    python tests/calib_probe.py probe_radius=0.01,0.012 probe_height=0.04,0.045    # sweep (cartesian product)
-    python tests/calib_probe.py --torque-fit                      # fixed-lever-arm fit of the reference torques
+    python tests/studies/calib_probe.py                                   # reference statistics vs the current defaults
+    python tests/studies/calib_probe.py probe_radius=0.01,0.012 probe_height=0.04,0.045    # sweep (cartesian product)
+    python tests/studies/calib_probe.py --torque-fit                      # fixed-lever-arm fit of the reference torques
 
 Runs the CPU oracle only (test infrastructure, which is why this script lives under tests/; it is not collected by pytest); the kernels use the
 same geometry (tests/test_gpu_parity.py).
@@ -15,7 +15,7 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT / "tests"))
 from oracle_lib import Oracle  # noqa: E402
 

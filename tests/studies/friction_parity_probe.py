@@ -1,7 +1,7 @@
 import importlib, sys
 import numpy as np, torch
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 usim = importlib.import_module("robotic-ultrasound-imaging_amd")
 from oracle_lib import Oracle

@@ -1,9 +1,9 @@
 """One-off record run (by hand, on the GPU box): the parity check of test_gpu_parity.py at BASELINE's full size -- 4096 environments x
 200 steps -- for every controller mode and both torso models, plus the randomised configuration; prints the razor-edge counts.
-Lives under tests/ because it uses the oracle.   python tests/gpu_parity_fullsize.py > profiles/<round>/parity_fullsize.txt"""
+Lives under tests/ because it uses the oracle.   python tests/studies/gpu_parity_fullsize.py > profiles/<round>/parity_fullsize.txt"""
 import importlib, os, sys, time
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 64)))
 import test_gpu_parity as T

@@ -1,11 +1,11 @@
 """What fixing the lattice rows' impedance at d_max leaves out (deviations): the oracle with MuJoCo's impedance ramp d(|r|) evaluated on every
 joint-equality and tendon row (uso_config.lattice_ramp = 1: the lattice matrix is assembled and factorised per step) against the product's model, on the same
 seeded episodes -- random actions, and the reference's trained `tracking` policy (weights / VecNormalize statistics from tests/golden).  Oracle only (CPU).
-usage: python tests/lattice_ramp_study.py [n_envs] [steps]  ->  profiles/r03/lattice_ramp_study.txt"""
+usage: python tests/studies/lattice_ramp_study.py [n_envs] [steps]  ->  profiles/r03/lattice_ramp_study.txt"""
 import json, sys
 from pathlib import Path
 import numpy as np
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT / "tests"))
 from oracle_lib import Oracle
 

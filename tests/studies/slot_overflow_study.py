@@ -1,10 +1,10 @@
 """What the eight contact slots leave out (deviations): the oracle built with 32 slots (every penetrating element keeps its contact, as
 in MuJoCo) against the regular build on the same seeded resets and random-action steps.  Oracle only (CPU).
-usage: python tests/slot_overflow_study.py [n_envs] [steps]  ->  profiles/r03/slot_overflow_study.txt"""
+usage: python tests/studies/slot_overflow_study.py [n_envs] [steps]  ->  profiles/r03/slot_overflow_study.txt"""
 import ctypes as C, subprocess, sys
 from pathlib import Path
 import numpy as np
-sys.path.insert(0, str(Path(__file__).resolve().parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from oracle_lib import Oracle, OracleConfig, ORACLE_DIR
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

@@ -2,11 +2,11 @@
 the reference's VecNormalize pickles).  Which single parameter of the restated model would have to change to close it?  The oracle replays the `wrench` policy
 (force-controlled: the cleanest probe of the torso's sustained stiffness) and the `tracking` policy with the time constant of the lattice's joint-equality rows
 varied (study switch uso_config.study_fix_tc; the instantaneous response -- the reset rows the probe stand-in is calibrated on -- does not depend on it).
-Oracle only (CPU).   usage: python tests/sustained_load_study.py [n_envs] [steps]"""
+Oracle only (CPU).   usage: python tests/studies/sustained_load_study.py [n_envs] [steps]"""
 import json, sys
 from pathlib import Path
 import numpy as np
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT / "tests"))
 from oracle_lib import Oracle
 

@@ -8,7 +8,7 @@ razor-edge environments are counted, must be rare, must be explained by a tiny m
 
 Since friction carries force (usim_config.probe_geoms = 2: the second colliding probe geom of the reference's XML, friction 1.0) the element
 velocities are the field where float32 shows first: the float32 BUILD OF THE ORACLE leaves the float64 build by 1.1e-4 .. 1e-3 of the batch's
-largest element velocity in the worst one or two of 256 environments (tests/friction_parity_probe.py), and so do the kernels.  The bar on the
+largest element velocity in the worst one or two of 256 environments (tests/studies/friction_parity_probe.py), and so do the kernels.  The bar on the
 lattice fields is therefore stated per environment: 1e-4 for 99 % of them, 1e-3 for the stragglers (as it already was at full size); the
 arm state (q, qd) keeps 1e-4 for every environment of a small batch."""
 import numpy as np
@@ -114,7 +114,7 @@ def _run_parity(usim, n, steps, torso, mode, **extra):
             assert fex.max() < 1 and tex.max() < 1, (k, d.max(0))
         else:       # full size: the bar for 99.9 % of the environments, ten times that for the stragglers (as for the state fields below).  With friction
             # carrying force the float32 build of the ORACLE leaves the float64 build by the same 0.1 - 0.6 N on 50 - 80 N in a handful of violently
-            # moving environments (`fixed` mode; tests/friction_parity_probe.py fixed 4096)
+            # moving environments (`fixed` mode; tests/studies/friction_parity_probe.py fixed 4096)
             assert np.quantile(fex, 0.999) < 1 and fex.max() < 10 and np.quantile(tex, 0.999) < 1 and tex.max() < 10, (k, d.max(0), fex.max(), tex.max())
         assert np.all(d[:, 9] < (1 if n <= 1024 else 10) * (3e-2 + 2e-3 * (fscale + np.abs(obs_o[alive][:, 9])))), (k, d.max(0))
         # reward = 5 exponentials; the two force terms are Lipschitz in the observed statistics with constants

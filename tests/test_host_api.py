@@ -88,6 +88,12 @@ def test_config_rejects_what_the_reference_rejects(usim):
         usim.make_config(**{**kw, "controller_configs": {**kw["controller_configs"], "impedance_mode": "variable"}})
     with pytest.raises(TypeError):
         usim.make_config(**{**kw, "no_such_option": 1})
+    # kwargs of Ultrasound.__init__ that change step()/reset() in the reference are accepted at their defaults only (ultrasound.py:110,121-122):
+    # ignore_done=True removes the horizon from `done` in robosuite's MujocoEnv._post_action
+    for k, bad in (("ignore_done", True), ("placement_initializer", object()), ("hard_reset", False)):
+        with pytest.raises(ValueError, match=k):
+            usim.make_config(**{**kw, k: bad})
+    usim.make_config(**{**kw, "ignore_done": False, "placement_initializer": None, "hard_reset": True, "reward_shaping": True})
     # control_freq below 500: physics substeps per control step (robosuite MujocoEnv.step); the env's own default 20 (ultrasound.py:119) = 25 of them
     c20 = usim.make_config(**{**kw, "control_freq": 20})
     assert c20.substeps == 25 and c20.control_dt == pytest.approx(0.05)

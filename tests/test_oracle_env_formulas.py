@@ -113,7 +113,7 @@ DEPTH_BINS = ((-0.030, -0.015), (-0.015, -0.005), (-0.005, 0.0), (0.0, 0.005), (
 def check_reset_rows_against_reference(obs, ref):
     """Shared by the oracle test below and its GPU twin (tests/test_gpu_properties.py): the six force / torque channels of a batch of
     reset observations against the 192 reset rows decoded from the reference checkpoints (calibration record
-    profiles/r03/calib_probe.txt, tests/calib_probe.py).  Bands: +-30 % on the spread of Fx, Fy, Fz, torque x, torque y, +-25 % + 2 N on
+    profiles/r03/calib_probe.txt, tests/studies/calib_probe.py).  Bands: +-30 % on the spread of Fx, Fy, Fz, torque x, torque y, +-25 % + 2 N on
     the binned force-depth curve.  Since the second colliding probe geom of the reference's XML is modelled (usim_config.probe_geoms = 2: friction 1.0,
     DESIGN.md section 2) the spread of Fy (reference 8.4 N; 3.8 N before, 8.6 N now) is inside the band.  KNOWN GAPS, asserted at their measured
     size so that they cannot grow silently: the spread of the torque about the probe axis (0.33 vs 0.18 N m; 0.09 before), and the tail of |Fx|

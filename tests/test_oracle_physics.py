@@ -266,7 +266,7 @@ def test_pgs_is_converged_at_default_sweeps():
     carry real force and projected Gauss-Seidel converges slowly on them, whatever the order of the sweeps (five plain full sweeps: no better): at the
     default the typical error is 0.001 - 0.02 N, 1 % of the environments are off by 0.6 - 0.9 N and the worst of 256 by 1 - 3 N on forces of 50 - 60 N; eight full
     sweeps (pgs_iters = 8): typical 2e-4 N, 1 %: 0.2 N, worst 1.3 N; 32: 1e-14 / 2e-3 / 3e-3 N.  Replays of the reference's trained policy are insensitive to it (reward per step 7.48 / 7.50 / 7.50 at
-    4 / 8 / 16 sweeps, tests/sustained_load_study.py), so the default stays at the cheaper schedule; both sides run the same one, which is what the
+    4 / 8 / 16 sweeps, tests/studies/sustained_load_study.py), so the default stays at the cheaper schedule; both sides run the same one, which is what the
     parity tests compare.  With mu = 0.01 (probe_geoms = 1) the old bound still holds."""
     n = 256
     for pre in (8, 40):

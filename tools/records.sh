@@ -17,7 +17,7 @@ tools/stats_only.sh ${TAG}_soft_spl1 --steps-per-launch 1 > /dev/null 2>&1
 python3 tools/split_timeline.py 200 4096 32 > "$G/${TAG}_timeline.txt" 2>&1
 USIM_PROFILE_NSUB=16 python3 tools/split_timeline.py 200 4096 32 > "$G/${TAG}_timeline_multi.txt" 2>&1
 USIM_PROFILE_NSUB=16 python3 tools/split_timeline.py 200 8192 64 > "$G/${TAG}_timeline_g8.txt" 2>&1
-python3 tests/gpu_parity_fullsize.py > "$G/${TAG}_parity_fullsize.txt" 2>&1
+python3 tests/studies/gpu_parity_fullsize.py > "$G/${TAG}_parity_fullsize.txt" 2>&1
 for m in tracking variable_z wrench; do python3 tools/gpu_policy_replay.py $m 2>&1 | grep -v amdgpu.ids; done > "$G/${TAG}_policy_replay.txt"
 python3 tools/replay_medians.py 1024 3000 2>&1 | grep -v amdgpu.ids > "$G/${TAG}_replay_medians.txt"
 python3 tools/collector_probe.py 4096 128 5 2>&1 | grep -v amdgpu.ids > "$G/${TAG}_collector_probe.txt"
