@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--gather", choices=["rccl", "p2p"], default="rccl", help="N > 1: RCCL all-gather (resident workgroups on the CUs) or peer-to-peer copies "
                     "of the packed block (copy engines, no CUs; distributed.P2PRolloutGather)")
+    ap.add_argument("--pgs-iters", type=int, default=0, help="studies only: sweeps of the contact solver (default: the library's, usim_config.pgs_iters)")
     ap.add_argument("--steps-per-launch", type=int, default=0, help="consecutive steps per kernel launch of the rollout (1 .. 64; default: the library's, 64)")
     ap.add_argument("--lanes-per-env", type=int, default=0, choices=[0, 1, 8, 16, 32, 64], help="kernel mapping: 16 lanes per environment (automatic), 8 (soft torso) or 1 (rigid torso)")
     args = ap.parse_args()
@@ -142,6 +143,8 @@ def main():
     # kernel (distributed.P2PRolloutGather: no workgroups on the CUs next to the step kernels; validated with two processes on one GPU only).
     if args.lanes_per_env:
         extra["lanes_per_env"] = args.lanes_per_env
+    if args.pgs_iters:
+        extra["pgs_iters"] = args.pgs_iters
     if on_gpu:
         usim = importlib.import_module("robotic-ultrasound-imaging_amd")
         env = usim.UltrasoundVecEnv(n, device=device, seed=3, env_offset=rank * n, torso=args.workload, **extra, **usim.default_robosuite_kwargs())
@@ -272,7 +275,8 @@ def main():
                        "domain_randomisation": "stiffness+damping" + ("+friction" if args.randomize else ""),
                        "parallelism": f"env-shard x{world}" + ("" if gather is None else (" + RCCL all-gather of transition blocks" if args.gather == "rccl" else
                                                                  " + peer-to-peer copies of transition blocks (copy engines)")),
-                       "steps_per_launch": spl, "lanes_per_env": lanes, "waves_per_simd": int(extra.get("waves_per_simd", 0)) or "auto"},
+                       "steps_per_launch": spl, "lanes_per_env": lanes, "waves_per_simd": int(extra.get("waves_per_simd", 0)) or "auto",
+                       "contact_solver_sweeps": int(extra.get("pgs_iters", 0)) or "default"},
             # what actually ran: the ranks the process group saw (never the --gpus argument), and the exchange step of the N > 1 path
             "ranks_seen": ranks_seen,
             "gather": None if gather is None else {"kind": args.gather, "backend": dist.get_backend(), "blocks_in_timed_region": n_gathers,

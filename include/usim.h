@@ -66,8 +66,12 @@ typedef struct usim_config {
     int32_t torso_solref_randomization;        /* rl_config.yaml:55 */
     int32_t initial_probe_pos_randomization;   /* rl_config.yaml:56 */
     int32_t friction_randomization;            /* BASELINE.json configs[4] */
-    int32_t torso_drop;                        /* reproduce the 4.7 mm spawn drop (ultrasound.py:313) */
-    int32_t pgs_iters;                         /* full contact sweeps per forward pass (default 4), interleaved with normal-only sweeps: N N F F N F F */
+    int32_t torso_drop;                        /* 0 (default since round 4): the torso base stays at its spawn height -- ultrasound.py:313 spawns the nominal bottom plane 4.7 mm
+                                                * above the table, but the caps of the tilted rim capsules of the bottom face reach 4.9 - 5.8 mm below that plane and carry
+                                                * the torso from the first step; 1: free fall over the 4.7 mm, then rest (rounds 1-3); 2: at rest 4.7 mm
+                                                * lower from the start */
+    int32_t pgs_iters;                         /* sweeps of the contact solver per forward pass (default 6): exact-cone block Gauss-Seidel on the dual of MuJoCo's convex
+                                                * contact problem -- per visit a ray update, then the friction QCQP with the normal fixed (what MuJoCo's PGS does for elliptic cones) */
     int32_t ik_iters;                          /* reset inverse-kinematics iterations */
     int32_t env_offset;                        /* global index of env 0 of this handle (multi-GPU shard) */
     int32_t lanes_per_env;                     /* kernel mapping: 0 automatic; 16 lanes per environment (arm mathematics distributed over the group); 64 (soft torso: the split
@@ -97,6 +101,9 @@ typedef struct usim_config {
                                                 * row has half the regulariser (two equal rows in parallel), whose friction rows are those of the high-friction contact (the other
                                                 * cone, mu = 0.01, saturates at once) and whose cone limit is (mu_1 + mu_2) / 2 of the total normal force.  1: a single probe geom */
     double probe_friction2;                    /* sliding friction of the second geom (MuJoCo default 1.0) */
+    double probe_halfwidth;                    /* round 4: half-width of the flat part of the probe's face ACROSS the blade -- the face is a flat 2 probe_halflen x 2 probe_halfwidth
+                                                * rectangle whose edges have the radius probe_radius (0: the blade of round 3, a tip capsule) */
+    double probe_tip;                          /* round 4: the lowest point of the probe lies this far beyond grip_site along the site's z axis (0: the tip is the site) */
 } usim_config;
 
 typedef struct usim_handle usim_handle;

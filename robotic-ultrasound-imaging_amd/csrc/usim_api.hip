@@ -270,10 +270,10 @@ int usim_default_config(usim_config* c) {
     std::memset(c, 0, sizeof *c);
     c->mode = USIM_MODE_TRACKING; c->torso = USIM_TORSO_TOP; c->horizon = 1000; c->early_termination = 1;
     c->deterministic_trajectory = 0; c->torso_solref_randomization = 1; c->initial_probe_pos_randomization = 1;
-    c->friction_randomization = 0; c->torso_drop = 1; c->pgs_iters = 4; c->ik_iters = 5; c->env_offset = 0; c->lanes_per_env = 0; c->torso_shape = 0; c->waves_per_simd = 0; c->robot = 0; c->seed = 3;
+    c->friction_randomization = 0; c->torso_drop = 0; c->pgs_iters = 4; c->ik_iters = 5; c->env_offset = 0; c->lanes_per_env = 0; c->torso_shape = 0; c->waves_per_simd = 0; c->robot = 0; c->seed = 3;
     c->control_dt = 0.002; c->substeps = 1; c->kp_fixed = 300; c->damping_ratio = 1; c->kp_min = 0; c->kp_max = 500; c->out_max_pos = 0.05; c->out_max_ori = 0.5;
     c->stiffness = 1324.17; c->damping = 17.59; c->elem_friction = 0.01; c->probe_friction = 1e-4; c->probe_friction2 = 1.0; c->probe_geoms = 2; c->probe_radius = 0.010; c->probe_halflen = 0.02;
-    c->probe_radius2 = 0.04; c->probe_height = 0.047; c->struct_size = (int32_t)sizeof(usim_config);
+    c->probe_radius2 = 0.04; c->probe_height = 0.047; c->probe_halfwidth = 0.0; c->probe_tip = 0.0; c->struct_size = (int32_t)sizeof(usim_config);
     return USIM_OK;
 }
 
@@ -281,6 +281,7 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
     if (!cfg || !out || n_envs <= 0) return USIM_ERR_INVALID;
     if (cfg->struct_size != (int32_t)sizeof(usim_config)) return USIM_ERR_INVALID;     // built against another layout of include/usim.h
     if (cfg->probe_radius2 <= 0 || !(cfg->probe_height > std::fabs(cfg->probe_radius2 - cfg->probe_radius))) return USIM_ERR_INVALID;
+    if (!(cfg->probe_halfwidth >= 0) || !(std::fabs(cfg->probe_tip) <= 0.02) || cfg->torso_drop < 0 || cfg->torso_drop > 2) return USIM_ERR_INVALID;
     if (cfg->mode < 0 || cfg->mode > 3 || cfg->torso < 0 || cfg->torso > 1 || cfg->horizon <= 0 || cfg->control_dt <= 0 ||
         cfg->probe_halflen < 1e-4 || cfg->probe_radius <= 0 || cfg->pgs_iters < 0 || cfg->ik_iters < 0 || cfg->torso_shape < 0 ||
         cfg->torso_shape > 1 || cfg->waves_per_simd < 0 || cfg->waves_per_simd > 2 || cfg->robot < 0 || cfg->robot > 1) return USIM_ERR_INVALID;
@@ -304,17 +305,21 @@ int usim_create(const usim_config* cfg, int n_envs, int device, usim_handle** ou
     C.kp_max = (float)cfg->kp_max; C.out_pos = (float)cfg->out_max_pos; C.out_ori = (float)cfg->out_max_ori; C.stiffness = (float)cfg->stiffness;
     C.damping = (float)cfg->damping; C.elem_fric = (float)cfg->elem_friction; C.probe_fric = (float)cfg->probe_friction;
     C.probe_geoms = cfg->probe_geoms == 2 ? 2 : 1; C.probe_fric2 = (float)cfg->probe_friction2; C.rn_scale = C.probe_geoms == 2 ? 0.5f : 1.0f;
-    C.probe_r = (float)cfg->probe_radius; C.probe_hl = (float)cfg->probe_halflen;
+    C.probe_r = (float)cfg->probe_radius; C.probe_hl = (float)cfg->probe_halflen; C.probe_hw = (float)cfg->probe_halfwidth; C.probe_tip = (float)cfg->probe_tip;
     {
         const double cb = (cfg->probe_radius - cfg->probe_radius2) / cfg->probe_height, ca = std::sqrt(1.0 - cb * cb);
         C.probe_r2 = (float)cfg->probe_radius2; C.probe_h = (float)cfg->probe_height; C.probe_ca = (float)ca; C.probe_cb = (float)cb;
         C.probe_cah = C.probe_ca * C.probe_h;
-        { const double cr = cfg->probe_radius + cfg->probe_height + 0.025 + 0.0075 + 1e-4; C.probe_cull2 = (float)(cr * cr); }
+        { const double cr = cfg->probe_radius + cfg->probe_height + cfg->probe_halfwidth + 0.025 + 0.0075 + 1e-4; C.probe_cull2 = (float)(cr * cr); }    // (sideways sweep: triangle inequality)
         C.probe_deep0 = (float)(cfg->probe_radius * (2.0 / 3.0)); C.probe_inv_band = (float)(1.0 / (cfg->probe_radius * (0.96 - 2.0 / 3.0)));
     }
     {
         const int shape = cfg->torso_shape ? 1 : 0;
         C.top_off = (float)kTopOff[shape]; C.y_range = (float)kYRange[shape]; C.drop = (float)(kTorsoZ[shape] - 0.0525 - 0.8);
+        // usim_config.torso_drop: 0 the base stays at the spawn height (it stands on the caps of its tilted rim capsules; default since round 4), 1 free fall over the
+        // spawn gap then rest (rounds 1-3), 2 at rest one gap lower from the start.  The kernels know "fall" (torso_drop) and the rest offset (drop).
+        if (cfg->torso_drop == 0) C.drop = 0.f;
+        C.torso_drop = cfg->torso_drop == 1 ? 1 : 0;
     }
     if (const char* spl = std::getenv("USIM_STEPS_PER_LAUNCH")) { const int v = std::atoi(spl); if (v >= 1 && v <= MAX_STEPS_PER_LAUNCH) h->steps_per_launch = v; }
     h->nfields = h->n_el ? F_TOTAL_TOP : F_NSCALAR;

@@ -67,7 +67,8 @@ struct DevCfg {
     uint32_t key0, key1;
     float dt, kp_fixed, damping_ratio, kp_min, kp_max, out_pos, out_ori;
     float stiffness, damping, elem_fric, probe_fric, probe_r, probe_hl;
-    float probe_cull2;                                           // broad phase: (probe_r + probe_h + ELEM_HL + ELEM_R + margin)^2 (collide_cull)
+    float probe_hw, probe_tip;                                   // half-width of the flat face across the blade, lowest point beyond the site (probe_sdf)
+    float probe_cull2;                                           // broad phase: (probe_r + probe_h + probe_hw + ELEM_HL + ELEM_R + margin)^2 (collide_cull)
     float probe_deep0, probe_inv_band;                           // direction field below the surface: blend band (probe_sdf)
     float probe_r2, probe_h, probe_ca, probe_cb, probe_cah;   // flared blade (usim_kernels.hip probe_sdf): upper radius, height, flank direction (ca, cb), ca * h
     float top_off, y_range, drop;       // trajectory height above the torso centre, half width of the waypoint grid, spawn gap

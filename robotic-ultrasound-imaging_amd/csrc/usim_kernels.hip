@@ -127,8 +127,10 @@ DI void torso_motion(const DevCfg& C, int tsim, float& dz, float& vz, float& az)
 // frame (site z points from the tip away from the probe body) and its gradient: the round-cone distance on the cross-section.
 DI float probe_sdf(const DevCfg& C, const f3 p, f3& g) {
     // (v_rsq_f32 is a quarter-rate instruction like v_sqrt_f32 / v_rcp_f32: every length and its reciprocal come from one of them)
-    const float py = -p.z - C.probe_r, e = fmaxf(fabsf(p.x) - C.probe_hl, 0.f);
-    const float px2 = fmaf(p.y, p.y, e * e);
+    // round 4: the cross-section is swept sideways by +-probe_hw as it is lengthways by +-probe_hl (a flat 2 hl x 2 hw face with edges of radius probe_r), and the
+    // lowest point lies probe_tip beyond the site along its z axis
+    const float py = C.probe_tip - p.z - C.probe_r, e = fmaxf(fabsf(p.x) - C.probe_hl, 0.f), el = fmaxf(fabsf(p.y) - C.probe_hw, 0.f);
+    const float px2 = fmaf(el, el, e * e);
     const bool pxok = px2 > 1e-18f;
     const float ipx = pxok ? rsq_(px2) : 0.f, px = px2 * ipx;
     const float kk = fmaf(py, C.probe_ca, -(px * C.probe_cb));
@@ -149,7 +151,7 @@ DI float probe_sdf(const DevCfg& C, const f3 p, f3& g) {
     const float rn = beta > 0.f ? rsq_(fmaf(bx, bx, by * by)) : 1.f;
     gx = bx * rn; gy = by * rn;
     const float gxi = gx * ipx;
-    g = mk(copysignf(gxi * e, p.x), pxok ? gxi * p.y : gx, -gy);
+    g = mk(copysignf(gxi * e, p.x), copysignf(gxi * el, p.y), -gy);
     return d;
 }
 
@@ -203,7 +205,7 @@ DI void collide_one(const float* lds, float* recs, const int i, const int gl, co
 DI bool collide_cull(const float* lds, const int e, const DevModel& M, const DevCfg& C, const float se, const float dz, const f3 Kx, const f3 Ksx, const f3 Ksz) {
     const f3 ax = mk(lds[TB_AXIS + 3 * e], lds[TB_AXIS + 3 * e + 1], lds[TB_AXIS + 3 * e + 2]);
     const f3 mid = mk(M.torso[0] + lds[TB_POS + 3 * e], M.torso[1] + lds[TB_POS + 3 * e + 1], M.torso[2] + lds[TB_POS + 3 * e + 2] + dz) + ax * (se - ELEM_R - ELEM_HL);
-    const f3 d = mid - (Kx - Ksz * (C.probe_r + C.probe_h));                       // from the centre of the upper axis (site z points away from the probe body)
+    const f3 d = mid - (Kx - Ksz * (C.probe_r + C.probe_h - C.probe_tip));         // from the centre of the upper axis (site z points away from the probe body)
     const f3 v = d - Ksx * clampf(dot(d, Ksx), -C.probe_hl, C.probe_hl);
     return dot(v, v) < C.probe_cull2;
 }
@@ -528,13 +530,13 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
     constexpr bool CLONE = (G == 16) && !PRE;
     const int cl = CLONE ? (gl & 7) : gl;
     const bool own = cl < nc;
-    float w[3][6], Liw[3][6], g[3], invD[3], Rd[3], f[3] = {0.f, 0.f, 0.f}, cres[3] = {0.f, 0.f, 0.f}, Km[MAXC];
+    float w[3][6], Liw[3][6], g[3], Rd[3], f[3] = {0.f, 0.f, 0.f}, cres[3] = {0.f, 0.f, 0.f}, Km[MAXC];
     if constexpr (PRE) {
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) Km[c] = P.Km[c];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        g[d] = P.g[d]; invD[d] = 0.f; Rd[d] = P.Rd[d];
+        g[d] = P.g[d]; Rd[d] = P.Rd[d];
 #pragma unroll
         for (int a = 0; a < 6; ++a) { w[d][a] = P.w[d][a]; Liw[d][a] = 0.f; }
     }
@@ -561,7 +563,7 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
     for (int c = 0; c < MAXC; ++c) Km[c] = 0.f;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        g[d] = 0.f; invD[d] = 0.f; Rd[d] = 0.f;
+        g[d] = 0.f; Rd[d] = 0.f;
 #pragma unroll
         for (int a = 0; a < 6; ++a) { w[d][a] = 0.f; Liw[d][a] = 0.f; }
     }
@@ -617,7 +619,8 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
     //      Lane k publishes Lambda^-1 w^k (18 words) and g^k (3) once in the environment's LDS block (the right-hand-side / staging area is
     //      free by now); every lane then reads contact k's record with six 16-byte broadcast reads -- a quarter of the issue slots the 21 DPP
     //      broadcasts took --, the reads of contact k + 1 in flight while the block of contact k is formed.
-    float B[MAXC][3][3];            // B[k] is written and read only under k < ncmax
+    const int ncr = ncmax == 5 ? 6 : (ncmax == 7 ? 8 : ncmax);     // the sweeps run the code of 6 / 8 contacts for 5 / 7 (below): those blocks are formed too (from the zero rows of a lane without a contact)
+    float B[MAXC][3][3];            // B[k] is written and read only under k < ncr
     static_assert(MAXC * 24 <= GE_SD, "Delassus records overlay the rhs / staging area");
     if (gl < MAXC) {
         float4* pub = reinterpret_cast<float4*>(&EB(gl * 24));
@@ -640,7 +643,7 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (j < ncmax) {
+            if (j < ncr) {
                 const float Kmj = hi ? Km[4 + j] : Km[j];
                 const float Lk[3][6] = {{rk[0].x, rk[0].y, rk[0].z, rk[0].w, rk[1].x, rk[1].y}, {rk[1].z, rk[1].w, rk[2].x, rk[2].y, rk[2].z, rk[2].w},
                                         {rk[3].x, rk[3].y, rk[3].z, rk[3].w, rk[4].x, rk[4].y}};
@@ -663,13 +666,13 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (j < ncmax) {
+            if (j < ncr) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
 #pragma unroll
                     for (int dd = 0; dd < 3; ++dd) B[j][d][dd] = X[j][d][dd];
             }
-            if (4 + j < ncmax) {
+            if (4 + j < ncr) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
 #pragma unroll
@@ -678,9 +681,9 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
         }
 #pragma unroll
         for (int k = 0; k < MAXC; ++k) {
-            if (k < ncmax && gl == k && own) {      // lanes without a contact keep invD = 0: their solve below yields zeros
+            if (k < ncr && gl == k && own) {
 #pragma unroll
-                for (int d = 0; d < 3; ++d) { B[k][d][d] += Rd[d]; invD[d] = rcp_(B[k][d][d]); }
+                for (int d = 0; d < 3; ++d) B[k][d][d] += Rd[d];
             }
         }
     } else {
@@ -692,7 +695,7 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
     }
 #pragma unroll
     for (int k = 0; k < MAXC; ++k) {
-        if (k < ncmax) {
+        if (k < ncr) {
             const float Lk[3][6] = {{rk[0].x, rk[0].y, rk[0].z, rk[0].w, rk[1].x, rk[1].y}, {rk[1].z, rk[1].w, rk[2].x, rk[2].y, rk[2].z, rk[2].w},
                                     {rk[3].x, rk[3].y, rk[3].z, rk[3].w, rk[4].x, rk[4].y}};
             const float gk[3] = {rk[4].z * Km[k], rk[4].w * Km[k], rk[5].x * Km[k]};
@@ -710,66 +713,83 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
                     B[k][d][dd] = fmaf(g[d], gk[dd], r1 + r2);
                 }
             }
-            if (gl == k && own) {            // lanes without a contact keep invD = 0: their solve below yields zeros
+            if (gl == k && own) {
 #pragma unroll
-                for (int d = 0; d < 3; ++d) { B[k][d][d] += Rd[d]; invD[d] = rcp_(B[k][d][d]); }
+                for (int d = 0; d < 3; ++d) B[k][d][d] += Rd[d];
             }
         }
     }
     }
     USIM_CSTAMP(dbg, 2);
-    // ---- projected Gauss-Seidel on the dual over the contact rows (fixed sweeps, cold start).  Contacts are visited in
-    //      ascending order.  The owner relaxes its three rows in order (normal, t1, t2; the earlier rows' updates enter
-    //      through its own block), projects on the cone and shares the three force increments; every lane then moves its
-    //      residuals by its block for that contact. ----
-    //      Schedule: C.pgs_iters FULL sweeps interleaved with NORMAL-ONLY sweeps (the owner relaxes its normal row alone: 8 instructions per
-    //      visit instead of 31), two up front and one between pairs of full sweeps -- 4 -> N N F F N F F.  The normal rows carry the strong
-    //      coupling; for the same fixed point this is closer to it than six full sweeps, at 4/5 of the work.
+    // ---- exact-cone block Gauss-Seidel on the dual  min 1/2 f'(A + R) f + b'f,  f_k in {|f_t| <= mu f_n}  (fixed number of sweeps, cold start; what MuJoCo's
+    //      PGS does for elliptic cones, oracle: constrained_forward, cone_solver 1).  Contacts are visited in ascending order; a visit of contact k works on
+    //      lane k's own 3 x 3 block (B[k] of lane k) and its running residual cres = ((A + R) f + b)_k:
+    //        (1) ray: exact line minimisation along the current force, f <- (1 + x) f, x >= -1 -- normal and friction move together along the cone; a contact
+    //            without force starts along (1, 0, 0) or, when friction alone makes a force pay (r_n < mu |r_t|), along (1, -mu r_t / |r_t|);
+    //        (2) friction with the normal fixed: the minimiser of the tangential 2 x 2 problem on the disc |t| <= mu f_n, t = -(B_tt + lambda I)^-1 r~, one
+    //            Newton step per visit on the secular equation 1 / |t(lambda)| = 1 / lim from the contact's lambda of the sweep before (0 in the first: the
+    //            iteration approaches the root monotonically from the left; a start to its right falls back to >= 0), radial clamp.  The multiplier converges with the sweeps: the fixed point is the optimum of the convex problem (MuJoCo's Newton solver's).
+    //      Every lane runs the visit on its own registers (no divergence); only lane k's increments are shared (three row broadcasts) and kept, and every lane
+    //      then moves its residuals by its block for contact k.  Rounds 1-3 relaxed the three rows one by one and scaled the friction radially: that iteration
+    //      rests at a different point (2.6 N median on the net force right after a reset, tests/studies/solver_study.py).
     // (one straight-line instantiation of the sweeps per wave-uniform contact count: no test per visit)
+    float lamc = 0.f;                       // multiplier of this lane's friction disc, carried from sweep to sweep
     auto sweeps = [&](auto NCM_) {
         constexpr int NCM = decltype(NCM_)::value;
         for (int it = 0; it < C.pgs_iters; ++it) {
-            const int n_normal = (it == 0) ? 2 : (((it & 1) == 0) ? 1 : 0);
-            for (int pass = 0; pass < n_normal; ++pass) {
-#pragma unroll
-                for (int k = 0; k < NCM; ++k) {
-                    const float f0n = fmaxf(fmaf(-cres[0], invD[0], f[0]), 0.f);
-                    float d0 = f0n - f[0];
-                    f[0] = (gl == k) ? f0n : f[0];
-                    d0 = group_bcast<G>(d0, k);
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) cres[d] = fmaf(B[k][d][0], d0, cres[d]);
-                }
-            }
 #pragma unroll
             for (int k = 0; k < NCM; ++k) {
-                // every lane runs the solve on its own rows (no divergence); only lane k's increments are shared and kept
-                const float f0n = fmaxf(fmaf(-cres[0], invD[0], f[0]), 0.f);
-                float d0 = f0n - f[0];
-                const float d1u = -fmaf(B[k][1][0], d0, cres[1]) * invD[1];
-                const float d2u = -fmaf(B[k][2][1], d1u, fmaf(B[k][2][0], d0, cres[2])) * invD[2];
-                float t1 = f[1] + d1u, t2 = f[2] + d2u;
-                // elliptic cone: |f_t| <= mu f_n
-                const float ft2 = fmaf(t1, t1, t2 * t2), lim = mu * f0n;
-                const float sc = fminf(lim * rsq_(ft2), 1.0f);          // lim / |f_t| where that is below one (v_min keeps the number when ft2 = 0 makes the product inf or NaN)
-                t1 *= sc; t2 *= sc;
-                float d1 = t1 - f[1], d2 = t2 - f[2];
+                const float b00 = B[k][0][0], b01 = B[k][0][1], b02 = B[k][0][2], b11 = B[k][1][1], b12 = B[k][1][2], b22 = B[k][2][2];
+                float r0 = cres[0], r1 = cres[1], r2 = cres[2];
+                // (1) ray
+                const bool pos = f[0] > 0.f;
+                const float rt2 = fmaf(r1, r1, r2 * r2);
+                const float irt = rsq_(rt2), rtn = rt2 * irt;
+                const float sl = (rt2 > 0.f && r0 < mu * rtn) ? -mu * irt : 0.f;
+                const float v0 = pos ? f[0] : 1.f, v1 = pos ? f[1] : sl * r1, v2 = pos ? f[2] : sl * r2;
+                const float Bv0 = fmaf(b02, v2, fmaf(b01, v1, b00 * v0)), Bv1 = fmaf(b12, v2, fmaf(b11, v1, b01 * v0)), Bv2 = fmaf(b22, v2, fmaf(b12, v1, b02 * v0));
+                const float vr = fmaf(v2, r2, fmaf(v1, r1, v0 * r0)), vBv = fmaf(v2, Bv2, fmaf(v1, Bv1, v0 * Bv0));
+                const float x = fmaxf(-vr * rcp_(vBv), pos ? -1.f : 0.f);
+                const float n0 = fmaf(x, v0, f[0]), n1 = fmaf(x, v1, f[1]), n2 = fmaf(x, v2, f[2]);
+                r1 = fmaf(x, Bv1, r1); r2 = fmaf(x, Bv2, r2);
+                // (2) friction on the disc |t| <= mu n0
+                const float lim = mu * n0;
+                const bool haslim = lim > 0.f;
+                const float ilim = haslim ? rcp_(lim) : 0.f;
+                const float q1 = r1 - fmaf(b12, n2, b11 * n1), q2 = r2 - fmaf(b22, n2, b12 * n1);
+                float lam = lamc;
+                float m11 = b11 + lam, m22 = b22 + lam, idet = rcp_(fmaf(m11, m22, -(b12 * b12)));
+                float t1 = -fmaf(m22, q1, -(b12 * q2)) * idet, t2 = -fmaf(m11, q2, -(b12 * q1)) * idet;
+                {
+                    const float tt = fmaf(t1, t1, t2 * t2);
+                    const float qd = fmaf(m11 * t2, t2, fmaf(m22 * t1, t1, -2.f * b12 * t1 * t2)) * idet;
+                    const float tn = tt * rsq_(fmaxf(tt, 1e-30f));
+                    lam = fmaxf(fmaf(fmaf(tn, ilim, -1.f) * tt, rcp_(fmaxf(qd, 1e-30f)), lam), 0.f);
+                }
+                m11 = b11 + lam; m22 = b22 + lam; idet = rcp_(fmaf(m11, m22, -(b12 * b12)));
+                t1 = -fmaf(m22, q1, -(b12 * q2)) * idet; t2 = -fmaf(m11, q2, -(b12 * q1)) * idet;
+                {
+                    const float tt = fmaf(t1, t1, t2 * t2);
+                    const float sc = haslim ? fminf(lim * rsq_(tt), 1.0f) : 0.f;     // lim / |t| where that is below one (v_min keeps the number when tt = 0 makes the product inf or NaN)
+                    t1 *= sc; t2 *= sc;
+                }
                 const bool mine = gl == k;
-                f[0] = mine ? f0n : f[0]; f[1] = mine ? t1 : f[1]; f[2] = mine ? t2 : f[2];
+                float d0 = (mine && own) ? n0 - f[0] : 0.f, d1 = (mine && own) ? t1 - f[1] : 0.f, d2 = (mine && own) ? t2 - f[2] : 0.f;
+                f[0] += d0; f[1] += d1; f[2] += d2;
+                lamc = (mine && haslim) ? lam : lamc;
                 d0 = group_bcast<G>(d0, k); d1 = group_bcast<G>(d1, k); d2 = group_bcast<G>(d2, k);
 #pragma unroll
                 for (int d = 0; d < 3; ++d) cres[d] = fmaf(B[k][d][2], d2, fmaf(B[k][d][1], d1, fmaf(B[k][d][0], d0, cres[d])));
             }
         }
     };
-    switch (ncmax) {
+    // (counts 5 and 7 run the code of 6 and 8: a visit of a slot without a contact shares zeros; two instantiations less of a 150-instruction visit)
+    switch (ncr) {
         case 1: sweeps(std::integral_constant<int, 1>{}); break;
         case 2: sweeps(std::integral_constant<int, 2>{}); break;
         case 3: sweeps(std::integral_constant<int, 3>{}); break;
         case 4: sweeps(std::integral_constant<int, 4>{}); break;
-        case 5: sweeps(std::integral_constant<int, 5>{}); break;
-        case 6: sweeps(std::integral_constant<int, 6>{}); break;
-        case 7: sweeps(std::integral_constant<int, 7>{}); break;
+        case 5: case 6: sweeps(std::integral_constant<int, 6>{}); break;
         default: sweeps(std::integral_constant<int, 8>{}); break;
     }
     USIM_STAMP(dbg, 10);

@@ -1,0 +1,73 @@
+"""Independent checker for the contact solver (test infrastructure): reads the dual cone QP of an environment's forward pass from the oracle's study hook
+(uso_debug_dual) and solves it to machine precision with a method that shares nothing with the product's iteration -- accelerated projected gradient with
+restarts and the closed-form Euclidean projection onto the friction cone.  The optimum of this strictly convex problem is what MuJoCo's Newton solver
+converges to [RESTATED: MuJoCo documentation, "Computation / Solver"]."""
+import ctypes as C
+
+import numpy as np
+
+from oracle_lib import _ptr
+
+MAXC, ROW = 8, 10
+SIZE = 2 + 36 + MAXC * 3 * ROW + MAXC * MAXC
+
+
+def dual_problem(o, i, act):
+    """min 1/2 f'(A + R) f + b'f over f_c in {|f_t| <= mu f_n}: dict with Q = A + R, b, mu, the row Jacobians W (3 nc x 6, site space)"""
+    out = np.zeros(SIZE)
+    o.lib.uso_debug_dual.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    a = np.ascontiguousarray(act, dtype=np.float64)
+    nc = o.lib.uso_debug_dual(o.h, i, _ptr(a), _ptr(out))
+    if nc <= 0:
+        return None
+    Li = out[2:38].reshape(6, 6)
+    rows = out[38:38 + MAXC * 3 * ROW].reshape(MAXC * 3, ROW)[:3 * nc]
+    Lm = out[38 + MAXC * 3 * ROW:].reshape(MAXC, MAXC)[:nc, :nc]
+    W, g, R, b = rows[:, :6], rows[:, 6], rows[:, 7], rows[:, 8]
+    G = np.zeros((3 * nc, nc))
+    for c in range(nc):
+        G[3 * c:3 * c + 3, c] = g[3 * c:3 * c + 3]
+    A = W @ Li @ W.T + G @ Lm @ G.T
+    return {"nc": nc, "mu": out[1], "W": W, "A": A, "R": R, "Q": A + np.diag(R), "b": b}
+
+
+def project_cone(f, mu):
+    f = f.copy()
+    for c in range(len(f) // 3):
+        n, t = f[3 * c], f[3 * c + 1:3 * c + 3]
+        tn = np.linalg.norm(t)
+        if tn <= mu * n:
+            continue
+        if mu * tn <= -n:
+            f[3 * c:3 * c + 3] = 0
+            continue
+        nn = (n + mu * tn) / (1 + mu * mu)
+        f[3 * c] = nn
+        f[3 * c + 1:3 * c + 3] = t * (mu * nn / tn)
+    return f
+
+
+def solve_exact(P, iters=200000, tol=1e-13):
+    Q, b, mu = P["Q"], P["b"], P["mu"]
+    L = np.linalg.eigvalsh(Q)[-1]
+    f = np.zeros_like(b); y = f.copy(); t = 1.0
+    for it in range(iters):
+        fn = project_cone(y - (Q @ y + b) / L, mu)
+        if (fn - f) @ (y - fn) > 0:
+            t = 1.0; y = fn.copy()
+        else:
+            tn = 0.5 * (1 + np.sqrt(1 + 4 * t * t)); y = fn + (t - 1) / tn * (fn - f); t = tn
+        done = np.abs(fn - f).max() < tol and it > 50
+        f = fn
+        if done:
+            break
+    return f
+
+
+def kkt_residual(P, f):
+    """|f - Proj_K(f - grad)|: zero exactly at the optimum"""
+    return np.abs(f - project_cone(f - (P["Q"] @ f + P["b"]), P["mu"])).max()
+
+
+def net_force(P, f):
+    return (P["W"].T @ f)[:3]

@@ -1,0 +1,86 @@
+"""Contact-solver study (CPU, oracle): dump the dual cone QPs  min 1/2 f'(A+R)f + b'f, f_c in K_mu  of a realistic batch and compare candidate
+fixed-cost iterations against the exact optimum.   python tests/studies/solver_study.py [n_envs] [pre_steps]"""
+import ctypes as C, sys, pickle
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT / "tests"))
+from oracle_lib import Oracle
+
+from cone_qp import dual_problem as dump, project_cone as proj_cone, solve_exact as exact          # the independent checker the tests use
+
+
+def pgs_radial(P, sched):
+    """the product's iteration: row-by-row Gauss-Seidel, normal row clamped, friction rows scaled radially onto the cone.  sched: string of N / F"""
+    Q, b, mu, nc = P["Q"], P["b"], P["mu"], P["nc"]
+    f = np.zeros_like(b)
+    for ch in sched:
+        for c in range(nc):
+            for d in range(1 if ch == "N" else 3):
+                i = 3 * c + d
+                fn = f[i] - (Q[i] @ f + b[i]) / Q[i, i]
+                if d == 0 and fn < 0:
+                    fn = 0
+                f[i] = fn
+            if ch == "N":
+                continue
+            ft = np.hypot(f[3 * c + 1], f[3 * c + 2]); lim = mu * f[3 * c]
+            if ft > lim:
+                sc = lim / ft if ft > 0 else 0
+                f[3 * c + 1] *= sc; f[3 * c + 2] *= sc
+    return f
+
+
+def net(P, f):
+    return P["W"].T @ f            # site wrench
+
+
+def cone_pgs(P, sweeps):
+    """the product's iteration since round 4 (oracle: constrained_forward, cone_solver 1): per visit a ray update, then the friction QCQP with one warm-started Newton step"""
+    Q, b, mu, nc = P["Q"], P["b"], P["mu"], P["nc"]
+    f = np.zeros_like(b); lamc = np.zeros(nc)
+    for s in range(sweeps):
+        for c in range(nc):
+            i = slice(3 * c, 3 * c + 3); B = Q[i, i]; res = Q[i] @ f + b[i]; fc = f[i].copy()
+            if fc[0] <= 0:
+                rtn = np.hypot(res[1], res[2])
+                v = np.array([1.0, -mu * res[1] / rtn, -mu * res[2] / rtn]) if (rtn > 0 and res[0] < mu * rtn) else np.array([1.0, 0, 0]); xmin = 0.0
+            else:
+                v = fc; xmin = -1.0
+            x = max(xmin, -(v @ res) / (v @ B @ v)); new = fc + x * v
+            res = res + B @ (new - fc); fc = new
+            lim = mu * fc[0]; t = np.zeros(2)
+            if lim > 0:
+                a, cc, d = B[1, 1], B[1, 2], B[2, 2]; q = res[1:] - B[1:, 1:] @ fc[1:]
+                def ev(lam):
+                    m11, m22 = a + lam, d + lam; idet = 1 / (m11 * m22 - cc * cc)
+                    t = -np.array([m22 * q[0] - cc * q[1], m11 * q[1] - cc * q[0]]) * idet
+                    return t, t @ t, (m22 * t[0] ** 2 - 2 * cc * t[0] * t[1] + m11 * t[1] ** 2) * idet
+                t, tt, qd = ev(lamc[c])
+                if tt > 0:
+                    lamc[c] = max(0.0, lamc[c] + (np.sqrt(tt) / lim - 1) * tt / qd)
+                t, tt, qd = ev(lamc[c])
+                if tt > lim * lim:
+                    t = t * lim / np.sqrt(tt)
+            f[i] = np.array([fc[0], t[0], t[1]])
+    return f
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    pre = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    o = Oracle(n); o.reset()
+    for k in range(pre):
+        o.step(o.random_actions(k))
+    act = o.random_actions(pre)
+    probs = [dump(o, i, act[i]) for i in range(n)]
+    probs = [p for p in probs if p is not None]
+    pickle.dump(probs, open(f"/tmp/probs_{n}_{pre}.pkl", "wb"))
+    print(len(probs), "problems; contact counts:", np.bincount([p["nc"] for p in probs]))
+    ex = [exact(p) for p in probs]
+    pickle.dump(ex, open(f"/tmp/exact_{n}_{pre}.pkl", "wb"))
+    print("net-force error against the exact optimum of the convex problem (N):")
+    for name, fn in [("rounds 1-3: N N F F N F F, radial scaling", lambda p: pgs_radial(p, "NNFFNFF")), ("rounds 1-3: 600 full sweeps (its fixed point)", lambda p: pgs_radial(p, "F" * 600))] + \
+            [(f"round 4: exact-cone block Gauss-Seidel, {k} sweeps", (lambda k: lambda p: cone_pgs(p, k))(k)) for k in (2, 3, 4, 5, 6, 8, 10, 16, 30)]:
+        e = np.array([np.abs(net(p, fn(p)) - net(p, x))[:3].max() for p, x in zip(probs, ex)])
+        print(f"  {name:52s} median {np.median(e):.1e}  q90 {np.quantile(e, .9):.1e}  q99 {np.quantile(e, .99):.1e}  max {e.max():.1e}")
