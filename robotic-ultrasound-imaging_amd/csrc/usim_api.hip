@@ -272,8 +272,9 @@ int usim_default_config(usim_config* c) {
     c->deterministic_trajectory = 0; c->torso_solref_randomization = 1; c->initial_probe_pos_randomization = 1;
     c->friction_randomization = 0; c->torso_drop = 0; c->pgs_iters = 4; c->ik_iters = 5; c->env_offset = 0; c->lanes_per_env = 0; c->torso_shape = 0; c->waves_per_simd = 0; c->robot = 0; c->seed = 3;
     c->control_dt = 0.002; c->substeps = 1; c->kp_fixed = 300; c->damping_ratio = 1; c->kp_min = 0; c->kp_max = 500; c->out_max_pos = 0.05; c->out_max_ori = 0.5;
-    c->stiffness = 1324.17; c->damping = 17.59; c->elem_friction = 0.01; c->probe_friction = 1e-4; c->probe_friction2 = 1.0; c->probe_geoms = 2; c->probe_radius = 0.010; c->probe_halflen = 0.02;
-    c->probe_radius2 = 0.04; c->probe_height = 0.047; c->probe_halfwidth = 0.0; c->probe_tip = 0.0; c->struct_size = (int32_t)sizeof(usim_config);
+    c->stiffness = 1324.17; c->damping = 17.59; c->elem_friction = 0.01; c->probe_friction = 1e-4; c->probe_friction2 = 1.0; c->probe_geoms = 2; c->probe_radius = 0.021; c->probe_halflen = 0.0065;
+    c->probe_radius2 = 0.035; c->probe_height = 0.020; c->probe_halfwidth = 0.0; c->probe_tip = -0.0005;      // round-4 fit (oracle: PROBE_*; profiles/r04/probe_fit.txt)
+    c->struct_size = (int32_t)sizeof(usim_config);
     return USIM_OK;
 }
 

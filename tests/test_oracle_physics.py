@@ -296,7 +296,7 @@ def test_contact_solver_rests_at_the_optimum_of_the_convex_problem():
         assert np.median(e) < typical and np.quantile(e, 0.99) < q99 and e.max() < worst, (iters, np.median(e), np.quantile(e, 0.99), e.max())
     old = error(cone_solver=0, pgs_iters=300)
     assert np.median(old) > 0.5 and np.quantile(old, 0.99) > 5.0            # the rounds 1-3 iteration rests somewhere else
-    # a single low-friction probe geom (mu = 0.01): next to no friction to get wrong -- both iterations agree with the optimum
+    # a single low-friction probe geom (mu = 0.01): next to no friction to get wrong -- the default is converged to 1e-3 N there, and even the old iteration is close
     ref1 = Oracle(n, probe_geoms=1); ref1.reset()
     for k in range(pre):
         ref1.step(ref1.random_actions(k))
@@ -304,9 +304,9 @@ def test_contact_solver_rests_at_the_optimum_of_the_convex_problem():
     probs1 = [dual_problem(ref1, i, act1[i]) for i in range(n)]
     live1 = [i for i, p in enumerate(probs1) if p is not None]
     want1 = np.array([net_force(probs1[i], solve_exact(probs1[i])) for i in live1])
-    for cfg in (dict(pgs_iters=8), dict(cone_solver=0, pgs_iters=8)):
+    for cfg, bound in ((dict(pgs_iters=4), 1e-3), (dict(pgs_iters=8), 1e-7), (dict(cone_solver=0, pgs_iters=8), 0.6)):
         d = Oracle(n, probe_geoms=1, **cfg); d.reset(); d.set_state(st1)
-        assert np.abs(d.step(act1, auto_reset=False)[0][live1, :3] - want1).max() < 0.3
+        assert np.abs(d.step(act1, auto_reset=False)[0][live1, :3] - want1).max() < bound, cfg
 
 
 def test_explicit_pair_of_coincident_contacts_against_the_merged_contact():
