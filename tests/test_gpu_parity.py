@@ -6,11 +6,12 @@ bit-exact.  A thresholded decision (contact distance < 0, pos_error > 1, ori_err
 can differ between fp32 and fp64 only when the oracle's own margin to that threshold is within the state tolerance; such
 razor-edge environments are counted, must be rare, must be explained by a tiny margin, and are excluded from then on.
 
-Since friction carries force (usim_config.probe_geoms = 2: the second colliding probe geom of the reference's XML, friction 1.0) the element
-velocities are the field where float32 shows first: the float32 BUILD OF THE ORACLE leaves the float64 build by 1.1e-4 .. 1e-3 of the batch's
-largest element velocity in the worst one or two of 256 environments (tests/studies/friction_parity_probe.py), and so do the kernels.  The bar on the
-lattice fields is therefore stated per environment: 1e-4 for 99 % of them, 1e-3 for the stragglers (as it already was at full size); the
-arm state (q, qd) keeps 1e-4 for every environment of a small batch."""
+Round 3 had to state the bars on the lattice fields per quantile (1e-4 for 99 % of the environments, 1e-3 for the stragglers) and those on the observation channels in
+two tiers at full size.  With the contact solve of round 4 -- an iteration whose fixed point is the optimum of the convex problem, hence continuous in its inputs, instead of
+row relaxations with a radial scaling that were not converged -- the float32 path holds 1e-4 on EVERY state field of EVERY environment at every batch size that is run here
+(256, 4096 and 8192 environments, four controller modes: largest per-environment difference 7e-5 of the field's scale, tests/studies/parity_report.py,
+profiles/r04/parity_report.txt), and the tiers are gone: the bars below are BASELINE.json's, for every environment.  Razor edges: at most 1 % of the environments
+(observed 0.4 - 0.8 % at 4096 over 200 steps)."""
 import numpy as np
 import pytest
 import torch
@@ -49,7 +50,10 @@ def _razor_edge(inf, i):
             abs(inf["ori_err"][i] - 0.10) < MARGIN["ori"] or abs(inf["joint_margin"][i]) < MARGIN["joint"])
 
 
-def _run_parity(usim, n, steps, torso, mode, **extra):
+REPORT = None                # a study script sets this to a dict to collect the per-environment state errors instead of asserting the state bars
+
+
+def _run_parity(usim, n, steps, torso, mode, state_rtol=STATE_RTOL, **extra):
     env, ora = _mk(usim, n, torso, mode, **extra)
     og, oo = env.reset(), ora.reset()
     assert np.allclose(og[:, 12:19], oo[:, 12:19], atol=2e-6)          # pose channels at reset
@@ -98,25 +102,14 @@ def _run_parity(usim, n, steps, torso, mode, **extra):
         # mode drives the arm at up to ~1 m/s and its contact dynamics amplify rounding fastest)
         vtol = 3e-5 + 1.5 * STATE_RTOL * np.abs(obs_o[alive][:, 6:9]).max()
         vd = d[:, 6:9].max(1)
-        if n <= 1024:
-            assert vd.max() < vtol, (k, d.max(0), vtol)
-        else:       # full size: the bar for 99.9 % of the environments, ten times that for the stragglers (as for the final state below)
-            assert np.quantile(vd, 0.999) < vtol and vd.max() < 10 * vtol, (k, d.max(0), vtol)
-        if n <= 1024:
-            assert d[:, 11:19].max() < 2e-5, (k, d.max(0))
-        else:       # full size: 2e-5 for 99.9 % of the environments, ten times that for the stragglers (same rule as for every other channel)
-            assert np.quantile(d[:, 11:19].max(1), 0.999) < 2e-5 and d[:, 11:19].max() < 2e-4, (k, d.max(0))
+        assert vd.max() < vtol, (k, d.max(0), vtol)
+        assert d[:, 11:19].max() < 2e-5, (k, d.max(0))
         # force / torque channels: absolute floor plus 1e-3 of the environment's own contact force (eight strongly coupled contacts right
         # after a deep reset: float32 rounding alone, GPU or float32 oracle, moves a 90 N force by a few mN)
         fscale = np.abs(obs_o[alive][:, 0:3]).max(1)
-        fex, tex = d[:, 0:3].max(1) / (3e-2 + 2e-3 * fscale), d[:, 3:6].max(1) / (3e-3 + 2e-4 * fscale)
-        if n <= 1024:
-            assert fex.max() < 1 and tex.max() < 1, (k, d.max(0))
-        else:       # full size: the bar for 99.9 % of the environments, ten times that for the stragglers (as for the state fields below).  With friction
-            # carrying force the float32 build of the ORACLE leaves the float64 build by the same 0.1 - 0.6 N on 50 - 80 N in a handful of violently
-            # moving environments (`fixed` mode; tests/studies/friction_parity_probe.py fixed 4096)
-            assert np.quantile(fex, 0.999) < 1 and fex.max() < 10 and np.quantile(tex, 0.999) < 1 and tex.max() < 10, (k, d.max(0), fex.max(), tex.max())
-        assert np.all(d[:, 9] < (1 if n <= 1024 else 10) * (3e-2 + 2e-3 * (fscale + np.abs(obs_o[alive][:, 9])))), (k, d.max(0))
+        fex, tex = d[:, 0:3].max(1) / (2e-2 + 1e-3 * fscale), d[:, 3:6].max(1) / (2e-3 + 1e-4 * fscale)
+        assert fex.max() < 1 and tex.max() < 1, (k, d.max(0), fex.max(), tex.max())
+        assert np.all(d[:, 9] < 2e-2 + 1e-3 * (fscale + np.abs(obs_o[alive][:, 9]))), (k, d.max(0))
         # reward = 5 exponentials; the two force terms are Lipschitz in the observed statistics with constants
         # 3*0.7*sqrt(2/e) = 1.8 per N (channel 9) and 2*0.01*sqrt(2/e) = 0.0172 per N/s (channel 10), so the
         # admissible reward difference follows from the admissible force difference
@@ -130,29 +123,21 @@ def _run_parity(usim, n, steps, torso, mode, **extra):
         assert np.all(rd < tol), (k, int(np.argmax(rd - tol)), rd.max(), d[np.argmax(rd - tol)])
         for i, info in enumerate(infos):
             if done_g[i] and alive[i]:
-                assert np.allclose(info["terminal_observation"][6:9], term_o[i][6:9], atol=vtol if n <= 1024 else 10 * vtol)      # same bar as the live velocity channels
+                assert np.allclose(info["terminal_observation"][6:9], term_o[i][6:9], atol=vtol)      # same bar as the live velocity channels
     sg, so = env.get_state(), ora.get_state()
     for key in ("q", "qd", "s", "sd"):
         if np.asarray(sg[key]).size:
             # per environment: largest difference over the field's components, relative to the largest magnitude of the field in the batch
             a_, b_ = np.asarray(sg[key], dtype=np.float64)[alive], so[key][alive]
             per_env = np.abs(a_ - b_).reshape(len(a_), -1).max(1) / max(np.abs(b_).max(), 1e-12)
-            if n <= 1024 and key in ("q", "qd"):
-                assert per_env.max() < STATE_RTOL, (key, per_env.max())
-            elif n <= 1024:
-                # lattice fields: see the module docstring (float32 resolution of the element velocities once friction carries force)
-                assert np.quantile(per_env, 0.99) < STATE_RTOL and per_env.max() < 10 * STATE_RTOL, (key, np.quantile(per_env, 0.99), per_env.max())
-            else:
-                # full size (4096 .. 8192 environments): lattice displacements are |s| <= ~1 cm, and the float32 kinematics place the probe to ~3e-7 m -- the elements under
-                # it follow (the float32 build of the oracle differs from the float64 build by the same amount, test_residual_is_precision...).
-                # 1e-4 of 1 cm is 1e-6 m: held by 99.9 % of the environments; the stragglers (contact dynamics amplify the rounding in a few
-                # violently moving environments: `fixed` mode for the lattice, the open-loop `wrench` mode for the joint velocities) stay within 1e-3
-                qq = 0.999 if key in ("q", "qd") else 0.99          # (lattice fields: 99 %, as for the small batches)
-                assert np.quantile(per_env, qq) < STATE_RTOL and per_env.max() < 10 * STATE_RTOL, (key, np.quantile(per_env, qq), per_env.max())
+            if REPORT is not None:
+                REPORT[key] = per_env; REPORT[key + "_scale"] = np.abs(b_).max()
+                continue
+            assert per_env.max() < state_rtol, (key, per_env.max(), int((per_env > state_rtol).sum()))       # every environment, every batch size
     for key in ("t", "episode", "has_touched"):
         assert np.array_equal(np.asarray(sg[key])[alive].astype(int), so[key][alive].astype(int)), key
-    # razor edges: rare (3 % bar for small batches, where one environment is 0.4 ..1.5 %; 1.5 % at full size)
-    assert alive.mean() >= (0.985 if n >= 1024 else 0.97), f"{(~alive).sum()} of {n} environments hit a razor edge"
+    # razor edges: at most 1 % of the environments (small batches: at most 3 environments -- one of 67 is already 1.5 %)
+    assert (~alive).sum() <= max(3, 0.01 * n), f"{(~alive).sum()} of {n} environments hit a razor edge"
     env.close()
     return explained, int((~alive).sum())
 
@@ -210,7 +195,7 @@ def test_residual_is_precision_not_logic(usim):
     (what is left are razor edges of either precision, not logic), and the float32 oracle itself leaves the float64 oracle by the same
     orders of magnitude as the kernels do."""
     _, excl64 = _run_parity(usim, 256, 200, "soft", "tracking")
-    _, excl32 = _run_parity(usim, 256, 200, "soft", "tracking", precision="f32")
+    _, excl32 = _run_parity(usim, 256, 200, "soft", "tracking", precision="f32", state_rtol=2 * STATE_RTOL)       # two float32 paths: their distances from float64 add
     assert excl64 <= 4 and excl32 <= 4, (excl64, excl32)
     a, b = Oracle(256, precision="f64"), Oracle(256, precision="f32")
     a.reset(); b.reset()
@@ -224,8 +209,8 @@ def test_residual_is_precision_not_logic(usim):
     for key in ("q", "qd", "s", "sd"):
         a_, b_ = sa[key][same], sb[key][same]
         per_env = np.abs(a_ - b_).reshape(len(a_), -1).max(1) / np.abs(a_).max()
-        # float32 vs float64 on the CPU: the same bars as for the kernels (arm state 1e-4 everywhere; lattice fields 1e-4 for 99 %, 1e-3 for the rest), not zero
-        assert 1e-8 < per_env.max() and np.quantile(per_env, 0.99) < STATE_RTOL and per_env.max() < (STATE_RTOL if key in ("q", "qd") else 10 * STATE_RTOL), (key, per_env.max())
+        # float32 vs float64 on the CPU: the same bar as for the kernels (1e-4 on every field of every environment), not zero
+        assert 1e-8 < per_env.max() < STATE_RTOL, (key, per_env.max())
 
 
 def test_domain_randomisation_config5_parity_200_steps(usim):
