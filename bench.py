@@ -247,7 +247,7 @@ def main():
     valu_tflops = ALGO_FLOPS[args.workload] * n / avg_kernel_s / 1e12
 
     traffic_step = None
-    tfile = next((f for f in (ROOT / "profiles" / r / "traffic.json" for r in ("r03", "r02", "r01")) if f.exists()), ROOT / "profiles" / "r03" / "traffic.json")
+    tfile = next((f for f in (ROOT / "profiles" / r / "traffic.json" for r in ("r04", "r03", "r02", "r01")) if f.exists()), ROOT / "profiles" / "r04" / "traffic.json")
     if tfile.exists() and n == 4096:
         try:
             tj = json.loads(tfile.read_text()).get(args.workload)

@@ -265,9 +265,12 @@ typedef struct {
     real goal_rot[9];                               /* rotmat of goal_quat */
     /* lattice */
     int n_el;                                       /* dynamic elements */
-    int el_shell_id[N_TOP];                         /* shell id of dynamic element k */
-    real el_pos[N_TOP][3], el_axis[N_TOP][3];       /* nominal surface point (rel. torso centre) and slide axis */
-    int el_nnbr[N_TOP], el_nbr[N_TOP][4];           /* neighbours: index into dynamic list or -1 = pinned */
+    int el_shell_id[N_SHELL];                       /* shell id of dynamic element k */
+    real el_pos[N_SHELL][3], el_axis[N_SHELL][3];   /* nominal surface point (rel. torso centre) and slide axis */
+    int el_nnbr[N_SHELL], el_nbr[N_SHELL][4];       /* neighbours: index into dynamic list or -1 = pinned */
+    /* full torso (USO_TORSO_FULL): the 270 elements on a free body; K = inverse of the torso's acceleration-space Hessian in the BODY frame (6 + 270) */
+    double* full_K; double full_mtot, full_Ib[9];
+    real invw_table;                                /* regulariser scale of an element-table contact */
     real* lat_L;                                    /* Cholesky factor of the lattice normal matrix (n_el x n_el) */
     real* lat_Linv;                                 /* explicit inverse (for contact Delassus entries) */
     real w_fix, w_ten;
@@ -286,10 +289,14 @@ typedef struct {
     int sub;                    /* physics substep of the running env.step() (0 .. substeps-1) */
     real goal_pos[3], goal_rot[9];   /* 'fixed' mode: the goal set_goal() anchored at the policy step (first substep), held for the others */
     real ep_return;
-    real s[N_TOP], sd[N_TOP];
+    real s[N_SHELL], sd[N_SHELL];
+    real tb_p[3], tb_q[4], tb_v[3], tb_w[3];        /* full torso: pose of the free body (base-centred world axes, quaternion w x y z), linear velocity (world), angular velocity (body frame) */
     int ncon, con_el[USO_MAXC];
+    int warm_n, warm_el[USO_MAXC];            /* STUDY (uso_config.warm_start): contact forces of the previous physics step by element, the solver's initial guess */
+    real warm_f[USO_MAXC][3], warm_lam[USO_MAXC];
     int status;
     double info[8];                                 /* diagnostics of the last step (uso_last_info) */
+    double info_table[2];                           /* full torso: element-table contacts and their net normal force in the last forward pass */
 } Env;
 
 typedef struct {
@@ -429,7 +436,7 @@ static void build_model(Sim* S) {
         if (b == LAT_NY - 1) { top_of[a][c] = k; k++; }
     }
     m->n_shell_edges = nedge;
-    m->n_el = (S->cfg.torso == USO_TORSO_TOP) ? N_TOP : 0;
+    m->n_el = (S->cfg.torso == USO_TORSO_TOP) ? N_TOP : 0;      /* (USO_TORSO_FULL: set below) */
     for (int a = 0; a < LAT_NX; a++) for (int c = 0; c < LAT_NZ; c++) {
         int e = top_of[a][c], b = LAT_NY - 1;
         double loc[3] = {(a - 0.5 * (LAT_NX - 1)) * LAT_SPACING, (b - 0.5 * (LAT_NY - 1)) * LAT_SPACING, (c - 0.5 * (LAT_NZ - 1)) * LAT_SPACING};
@@ -460,6 +467,34 @@ static void build_model(Sim* S) {
         for (int p = 0; p < npinned; p++) m->el_nbr[e][nn++] = -1;
         m->el_nnbr[e] = nn;
     }
+    if (S->cfg.torso == USO_TORSO_FULL) {
+        /* every shell element dynamic, in shell-id (creation) order; neighbours = the 6-neighbourhood restricted to the shell (536 edges, degree <= 4) */
+        m->n_el = N_SHELL;
+        int e = 0;
+        for (int a = 0; a < LAT_NX; a++) for (int b = 0; b < LAT_NY; b++) for (int c = 0; c < LAT_NZ; c++) {
+            if (!is_shell(a, b, c)) continue;
+            double loc[3] = {(a - 0.5 * (LAT_NX - 1)) * LAT_SPACING, (b - 0.5 * (LAT_NY - 1)) * LAT_SPACING, (c - 0.5 * (LAT_NZ - 1)) * LAT_SPACING};
+            if (cyl) {
+                const double sx = 0.5 * (LAT_NX - 1) * LAT_SPACING, sy = 0.5 * (LAT_NY - 1) * LAT_SPACING;
+                double xn = loc[0] / sx, yn = loc[1] / sy, l0 = fmax(fabs(xn), fabs(yn)), nn = sqrt(xn * xn + yn * yn);
+                if (nn > 0) { loc[0] = sx * l0 * xn / nn; loc[1] = sy * l0 * yn / nn; }
+            }
+            double nl = sqrt(loc[0] * loc[0] + loc[1] * loc[1] + loc[2] * loc[2]);
+            for (int i = 0; i < 3; i++) {
+                double p = Rt[3 * i] * loc[0] + Rt[3 * i + 1] * loc[1] + Rt[3 * i + 2] * loc[2];
+                m->el_pos[e][i] = (real)p; m->el_axis[e][i] = (real)(p / nl);
+            }
+            m->el_shell_id[e] = e;
+            int nn = 0;
+            const int d3[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+            for (int d = 0; d < 6; d++) if (is_shell(a + d3[d][0], b + d3[d][1], c + d3[d][2])) {
+                if (nn >= 4) { fprintf(stderr, "usim_oracle: shell node of degree > 4\n"); abort(); }
+                m->el_nbr[e][nn++] = shell_id_of(a + d3[d][0], b + d3[d][1], c + d3[d][2]);
+            }
+            m->el_nnbr[e] = nn;
+            e++;
+        }
+    }
     /* soft-equality weights: R = (1-d)/d * A_ii with d = dmax (constant; DESIGN.md deviation),
      * A_ii = 1/m (joint row) or 2/m (tendon row) => weights relative to m: d/(1-d) and d/(2(1-d)) */
     m->w_fix = (real)(SOLIMP_DMAX / (1.0 - SOLIMP_DMAX));
@@ -480,6 +515,51 @@ static void build_model(Sim* S) {
             for (int i = 0; i < n; i++) m->lat_Linv[i * n + j] = col[i];
         }
         free(col);
+    }
+    if (S->cfg.torso == USO_TORSO_FULL) {
+        /* The torso as MuJoCo has it (ultrasound.py:426-431): a free body carrying the 270 sliders.  Generalised accelerations in the BODY frame: linear (3),
+         * angular (3), sliders (270).  With radial slide axes an element's mass moves along the line through the body origin: the sliders couple to the body's
+         * translation (m n_e) but not to its rotation, and the box is symmetric (COM at the origin).  The soft equality rows (270 joint rows, 536 tendon rows, as in
+         * the top-face model) enter the Hessian of the convex problem as m (L - I) on the slider block:
+         *     H = [ M_tot I   0    m N ]        N = [n_1 ... n_270]  (3 x 270)
+         *         [ 0        I_b   0   ]        L = (1 + w_fix) I + w_ten Laplacian(shell graph)
+         *         [ m N'      0    m L ]
+         * constant in the body frame (the composite inertia is taken at s = 0; velocity-product terms of the torso body are neglected: it barely moves).
+         * K = H^-1 once per model.  Mass: 270 elements + the composite's centre geom, 0.01 kg each [RESTATED: user_composite.cc MakeBox]. */
+        const int nt = 6 + N_SHELL;
+        double* H = (double*)calloc((size_t)nt * nt, sizeof(double));
+        double mt = 0, Ib[9] = {0};
+        for (int e = 0; e < N_SHELL; e++) {
+            double cpos[3]; for (int a = 0; a < 3; a++) cpos[a] = (double)m->el_pos[e][a] - (ELEM_RADIUS + ELEM_HALFLEN) * (double)m->el_axis[e][a];   /* capsule centre */
+            mt += ELEM_MASS;
+            double dd = cpos[0] * cpos[0] + cpos[1] * cpos[1] + cpos[2] * cpos[2];
+            for (int a = 0; a < 3; a++) for (int b2 = 0; b2 < 3; b2++) Ib[3 * a + b2] += ELEM_MASS * ((a == b2 ? dd : 0.0) - cpos[a] * cpos[b2]);
+        }
+        mt += ELEM_MASS;                                   /* centre geom */
+        m->full_mtot = mt; memcpy(m->full_Ib, Ib, sizeof Ib);
+        for (int a = 0; a < 3; a++) { H[a * nt + a] = mt; for (int b2 = 0; b2 < 3; b2++) H[(3 + a) * nt + 3 + b2] = Ib[3 * a + b2]; }
+        for (int e = 0; e < N_SHELL; e++) {
+            for (int a = 0; a < 3; a++) { H[a * nt + 6 + e] = ELEM_MASS * (double)m->el_axis[e][a]; H[(6 + e) * nt + a] = ELEM_MASS * (double)m->el_axis[e][a]; }
+            H[(6 + e) * nt + 6 + e] = ELEM_MASS * (1.0 + (double)m->w_fix + (double)m->w_ten * m->el_nnbr[e]);
+            for (int d = 0; d < m->el_nnbr[e]; d++) H[(6 + e) * nt + 6 + m->el_nbr[e][d]] = -ELEM_MASS * (double)m->w_ten;
+        }
+        /* Cholesky in double, then the explicit inverse */
+        for (int j = 0; j < nt; j++) {
+            double d = H[j * nt + j]; for (int k2 = 0; k2 < j; k2++) d -= H[j * nt + k2] * H[j * nt + k2];
+            if (!(d > 0)) { fprintf(stderr, "usim_oracle: torso Hessian not SPD\n"); abort(); }
+            d = sqrt(d); H[j * nt + j] = d;
+            for (int i = j + 1; i < nt; i++) { double sacc = H[i * nt + j]; for (int k2 = 0; k2 < j; k2++) sacc -= H[i * nt + k2] * H[j * nt + k2]; H[i * nt + j] = sacc / d; }
+        }
+        m->full_K = (double*)calloc((size_t)nt * nt, sizeof(double));
+        double* colk = (double*)malloc(sizeof(double) * nt);
+        for (int j = 0; j < nt; j++) {
+            for (int i = 0; i < nt; i++) colk[i] = (i == j);
+            for (int i = 0; i < nt; i++) { double sacc = colk[i]; for (int k2 = 0; k2 < i; k2++) sacc -= H[i * nt + k2] * colk[k2]; colk[i] = sacc / H[i * nt + i]; }
+            for (int i = nt - 1; i >= 0; i--) { double sacc = colk[i]; for (int k2 = i + 1; k2 < nt; k2++) sacc -= H[k2 * nt + i] * colk[k2]; colk[i] = sacc / H[i * nt + i]; }
+            for (int i = 0; i < nt; i++) m->full_K[i * nt + j] = colk[i];
+        }
+        free(colk); free(H);
+        m->invw_table = (real)((1.0 / ELEM_MASS + 2.0 / (N_SHELL * ELEM_MASS)) / 3.0);      /* element alone: the table is static (invweight 0) */
     }
     /* contact regulariser scale: translational inverse weights of the two bodies [RESTATED: MuJoCo
      * body_invweight0], probe at init_qpos, element = (1/m + 2/M_torso)/3 */
@@ -660,14 +740,18 @@ static void osc_torque(const Sim* S, const KinDyn* k, const real* q, const real*
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
     real qacc[NJ];
-    real ael[N_TOP];
+    real ael[N_SHELL];
+    real ab[6];                 /* full torso: acceleration of the free body (linear, angular; body frame) */
+    int ntable;                 /* full torso: element-table contacts of this pass */
+    real ftable[3];             /* ... and their net force on the torso (world axes) */
     int ncon, con_el[USO_MAXC];
     real con_dist[USO_MAXC];
-    real el_dist[N_TOP];        /* signed probe distance of every element (diagnostics) */
+    real el_dist[N_SHELL];        /* signed probe distance of every element (diagnostics) */
     real fc[3];                 /* cfrc_ext[probe][3:6]: net contact force on the probe, world axes */
     real tq_sensor[3];          /* torque sensor at ft_frame, site frame */
     real min_margin;            /* smallest |dist| among near-contact candidate pairs (threshold diagnostics) */
     real con_f[USO_MAXC][3], con_n[USO_MAXC][3], con_t[USO_MAXC];   /* diagnostics: contact-frame forces, normals, position along the shaft */
+    real con_lam[USO_MAXC];
     int overflow;
 } Fwd;
 
@@ -741,11 +825,13 @@ static double* g_dual_dump = 0;
 #define DUAL_ROW 10
 #define DUAL_SIZE (2 + 36 + USO_MAXC * 3 * DUAL_ROW + USO_MAXC * USO_MAXC)
 
+static void constrained_forward_full(const Sim* S, const Env* E, const KinDyn* k, const real* tau, Fwd* out);
 static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, const real* tau, Fwd* out) {
     const Model* m = &S->m;
     const real dt = (real)S->cfg.control_dt; (void)dt;
     memset(out, 0, sizeof *out);
     out->min_margin = (real)1e9;
+    if (S->cfg.torso == USO_TORSO_FULL) { constrained_forward_full(S, E, k, tau, out); return; }
     /* smooth acceleration of the arm: M qacc_s = tau - bias - D qd */
     real qs[NJ];
     for (int i = 0; i < NJ; i++) qs[i] = tau[i] - k->bias[i] - (real)JOINT_DAMPING * E->qd[i];
@@ -1015,6 +1101,14 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
                     res[i] = bb;
                 }
                 real lamc[2 * USO_MAXC] = {0};       /* multiplier of every contact's friction disc, carried from sweep to sweep */
+                if (S->cfg.warm_start && !explicit_pairs && E->warm_n > 0) {
+                    /* STUDY: start from the forces the same elements carried in the previous physics step (MuJoCo warm-starts its solver too) */
+                    for (int c = 0; c < nc; c++) for (int k2 = 0; k2 < E->warm_n; k2++) if (E->warm_el[k2] == out->con_el[c]) {
+                        for (int a = 0; a < 3; a++) fv[c][a] = E->warm_f[k2][a];
+                        lamc[c] = E->warm_lam[k2];
+                    }
+                    for (int i = 0; i < nr; i++) for (int j = 0; j < nr; j++) res[i] += Q[i][j] * fv[j / 3][j % 3];
+                }
                 for (int it = 0; it < S->cfg.pgs_iters; it++) for (int c = 0; c < nv; c++) {
                     const real mu = muv[c];
                     const int o = 3 * c;
@@ -1056,6 +1150,7 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
                     for (int i = 0; i < nr; i++) res[i] += Q[i][o] * df[0] + Q[i][o + 1] * df[1] + Q[i][o + 2] * df[2];
                 }
                 for (int c = 0; c < nc; c++) for (int d = 0; d < 3; d++) f[c][d] = fv[c][d] + (explicit_pairs ? fv[nc + c][d] : 0);
+                for (int c = 0; c < nc; c++) out->con_lam[c] = lamc[c];
             }
             for (int c = 0; c < nc; c++) { for (int d = 0; d < 3; d++) { out->con_f[c][d] = f[c][d]; out->con_n[c][d] = cn[c][d]; } }
             for (int c = 0; c < nc; c++) {
@@ -1080,6 +1175,233 @@ static void constrained_forward(const Sim* S, const Env* E, const KinDyn* k, con
         out->tq_sensor[0] = W[3]; out->tq_sensor[1] = W[4]; out->tq_sensor[2] = W[5];
         free(ramp_buf);
     }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * FULL torso (USO_TORSO_FULL, round 4): the rest of SURVEY.md section 8 row a3 -- all 270 shell elements dynamic, the free torso body
+ * (ultrasound.py:426-431) and its contacts with the table (ultrasound_arena.py:55-58: friction 1) -- solved as ONE convex problem with
+ * the arm: min 1/2 |a - a_s|^2_H + sum_contacts s_c(J_c a - a_ref,c), contacts = probe-element pairs (as in the top-face model, but the
+ * element now also rides on the body) and element-table pairs.  Dual form over all contact rows, dense Delassus matrix from
+ * Lambda^-1 (arm, site space) and K = H^-1 (torso, body frame), the same exact-cone block Gauss-Seidel.
+ * Deviations (documented in DESIGN.md): velocity-product terms of the torso body neglected, composite inertia at s = 0, one table
+ * contact per element (the lower end sphere of its capsule; MuJoCo's capsule-plane collider yields a second one when the capsule lies
+ * nearly flat), no volume-preserving tendon, lattice impedance fixed at d_max (as the top-face model).
+ * ---------------------------------------------------------------------------------------------- */
+#define USO_MAXT 160                      /* element-table contacts kept per pass (all penetrating elements in ascending id; 270 possible, ~50 occur) */
+static void quat_to_rot(const real* q, real* R) {
+    double qq[4] = {(double)q[0], (double)q[1], (double)q[2], (double)q[3]};
+    quat_wxyz_to_mat(R, qq);
+}
+/* exact-cone block Gauss-Seidel on a dense dual problem (the iteration of constrained_forward, cone_solver 1): nv contacts, Q row-major with leading dimension ld */
+static void cone_pgs_dense(int nv, const real* Q, int ld, real* res, const real* muv, int iters, real (*fv)[3], real* lamc) {
+    const int nr = 3 * nv;
+    for (int it = 0; it < iters; it++) for (int c = 0; c < nv; c++) {
+        const real mu = muv[c];
+        const int o = 3 * c;
+        real B[3][3], r[3], fo[3], fc[3], v[3], Bv[3];
+        for (int a = 0; a < 3; a++) { for (int bq = 0; bq < 3; bq++) B[a][bq] = Q[(size_t)(o + a) * ld + o + bq]; r[a] = res[o + a]; fo[a] = fc[a] = fv[c][a]; }
+        real xmin;
+        if (fc[0] > 0) { v3cpy(v, fc); xmin = -1; }
+        else {
+            const real rtn = (real)sqrt((double)(r[1] * r[1] + r[2] * r[2]));
+            if (rtn > 0 && r[0] < mu * rtn) v3set(v, 1, -mu * r[1] / rtn, -mu * r[2] / rtn); else v3set(v, 1, 0, 0);
+            xmin = 0;
+        }
+        for (int a = 0; a < 3; a++) Bv[a] = B[a][0] * v[0] + B[a][1] * v[1] + B[a][2] * v[2];
+        real x = -v3dot(v, r) / v3dot(v, Bv); if (x < xmin) x = xmin;
+        for (int a = 0; a < 3; a++) { fc[a] += x * v[a]; r[a] += x * Bv[a]; }
+        const real lim = mu * fc[0];
+        real t1 = 0, t2 = 0;
+        if (lim > 0) {
+            const real a11 = B[1][1], a12 = B[1][2], a22 = B[2][2];
+            const real q1 = r[1] - a11 * fc[1] - a12 * fc[2], q2 = r[2] - a12 * fc[1] - a22 * fc[2];
+            real lam = lamc[c];
+            for (int kq = 0; kq <= USO_QCQP_NEWTON; kq++) {
+                const real m11 = a11 + lam, m22 = a22 + lam, idet = 1 / (m11 * m22 - a12 * a12);
+                t1 = -(m22 * q1 - a12 * q2) * idet; t2 = -(m11 * q2 - a12 * q1) * idet;
+                if (kq == USO_QCQP_NEWTON) break;
+                const real tt = t1 * t1 + t2 * t2, qq = (m22 * t1 * t1 - 2 * a12 * t1 * t2 + m11 * t2 * t2) * idet;
+                if (!(tt > 0)) break;
+                lam += ((real)sqrt((double)tt) / lim - 1) * tt / qq; if (lam < 0) lam = 0;
+            }
+            lamc[c] = lam;
+            const real tt = t1 * t1 + t2 * t2;
+            if (tt > lim * lim) { const real sc = lim / (real)sqrt((double)tt); t1 *= sc; t2 *= sc; }
+        }
+        fc[1] = t1; fc[2] = t2;
+        const real df[3] = {fc[0] - fo[0], fc[1] - fo[1], fc[2] - fo[2]};
+        for (int a = 0; a < 3; a++) fv[c][a] = fc[a];
+        for (int i = 0; i < nr; i++) res[i] += Q[(size_t)i * ld + o] * df[0] + Q[(size_t)i * ld + o + 1] * df[1] + Q[(size_t)i * ld + o + 2] * df[2];
+    }
+}
+static void frisvad(const real* n, real* t1, real* t2) {
+    const real aa = -1 / (1 + n[2]), bb = n[0] * n[1] * aa;
+    v3set(t1, 1 + n[0] * n[0] * aa, bb, -n[0]); v3set(t2, bb, 1 + n[1] * n[1] * aa, -n[1]);
+}
+static void constrained_forward_full(const Sim* S, const Env* E, const KinDyn* k, const real* tau, Fwd* out) {
+    const Model* m = &S->m;
+    const int n = N_SHELL, nt = 6 + N_SHELL;
+    const double* K = m->full_K;
+    real qs[NJ];
+    for (int i = 0; i < NJ; i++) qs[i] = tau[i] - k->bias[i] - (real)JOINT_DAMPING * E->qd[i];
+    chol_solve(k->Lm, NJ, qs);
+    real Rb[9]; quat_to_rot(E->tb_q, Rb);
+    const real ztab = (real)(0.8 - BASE_WORLD[2]);
+    /* ---- smooth + equality accelerations of the torso: a~ = K rhs (body frame) ---- */
+    const real dmax = (real)SOLIMP_DMAX;
+    const real kfix = (real)(1.0 / (SOLIMP_DMAX * SOLREF_TC * SOLREF_TC)), bfix = (real)(2.0 / (SOLIMP_DMAX * SOLREF_TC));
+    const real kten = E->kt_stiff / dmax, bten = E->kt_damp / dmax;
+    real gb[3]; { real gw[3] = {0, 0, -(real)GRAV}; m3tmulv(gb, Rb, gw); }
+    double* rhs = (double*)calloc((size_t)nt, sizeof(double));
+    double* at = (double*)calloc((size_t)nt, sizeof(double));
+    for (int a = 0; a < 3; a++) rhs[a] = m->full_mtot * (double)gb[a];
+    for (int e = 0; e < n; e++) {
+        real r = v3dot(m->el_axis[e], gb) + m->w_fix * (-bfix * E->sd[e] - kfix * E->s[e]);
+        for (int d = 0; d < m->el_nnbr[e]; d++) { const int j = m->el_nbr[e][d]; r += m->w_ten * (-bten * (E->sd[e] - E->sd[j]) - kten * (E->s[e] - E->s[j])); }
+        rhs[6 + e] = ELEM_MASS * (double)r;
+    }
+    for (int i = 0; i < nt; i++) { double sacc = 0; const double* Ki = K + (size_t)i * nt; for (int j = 0; j < nt; j++) sacc += Ki[j] * rhs[j]; at[i] = sacc; }
+    /* body-frame velocities */
+    real vb[3], wb[3]; m3tmulv(vb, Rb, E->tb_v); v3cpy(wb, E->tb_w);
+    /* ---- collision: probe vs every element capsule (ascending shell id; slots as in the top-face model), then every element vs the table plane ---- */
+    int ncand = 0, cand_el[USO_MAXCAND]; real cn[USO_MAXCAND][3], cp[USO_MAXCAND][3], cdist[USO_MAXCAND], ctt[USO_MAXCAND];
+    int nt_c = 0, tel[USO_MAXT]; real tp[USO_MAXT][3], tdist[USO_MAXT];
+    for (int e = 0; e < n; e++) {
+        real loc[3], tip[3], axw[3];
+        for (int a = 0; a < 3; a++) loc[a] = m->el_pos[e][a] + (E->s[e] - (real)ELEM_RADIUS) * m->el_axis[e][a];
+        m3mulv(tip, Rb, loc); v3add(tip, tip, E->tb_p); m3mulv(axw, Rb, m->el_axis[e]);
+        /* table: the lower of the capsule's two end spheres */
+        {
+            real cz0 = tip[2], cz1 = tip[2] - (real)(2 * ELEM_COLL_HALFLEN) * axw[2];
+            const int inner = cz1 < cz0;
+            real cx[3]; v3addscl(cx, tip, axw, inner ? -(real)(2 * ELEM_COLL_HALFLEN) : 0);
+            const real dist = cx[2] - (real)ELEM_RADIUS - ztab;
+            if (dist < 0 && nt_c < USO_MAXT) { tel[nt_c] = e; tdist[nt_c] = dist; v3set(tp[nt_c], cx[0], cx[1], ztab + (real)0.5 * dist); nt_c++; }
+        }
+        /* probe: cheap bound first (the probe lies within probe_radius + probe_height + probe_halflen + probe_halfwidth of its site) */
+        {
+            real rel[3]; v3sub(rel, tip, k->x);
+            const real bound = (real)(S->cfg.probe_radius + S->cfg.probe_height + S->cfg.probe_halflen + S->cfg.probe_halfwidth + 2 * ELEM_COLL_HALFLEN + 2 * ELEM_RADIUS);
+            out->el_dist[e] = (real)1e3;
+            if (v3dot(rel, rel) > bound * bound) continue;
+            real p0[3], us[3], uw[3], g0[3], g1[3], gs[3], ps[3], gw[3], c2[3], nrm[3], tt;
+            m3tmulv(p0, k->Rs, rel);
+            v3set(uw, -axw[0] * (real)(2 * ELEM_COLL_HALFLEN), -axw[1] * (real)(2 * ELEM_COLL_HALFLEN), -axw[2] * (real)(2 * ELEM_COLL_HALFLEN));
+            m3tmulv(us, k->Rs, uw); v3add(ps, p0, us);
+            (void)probe_sdf(S, p0, g0); (void)probe_sdf(S, ps, g1);
+            real s0 = v3dot(g0, us), s1 = v3dot(g1, us), curv = s1 - s0; if (curv < 0) curv = 0;
+            tt = -s0 / (curv + (real)SHAFT_EPS); if (tt < 0) tt = 0; if (tt > 1) tt = 1;
+            v3addscl(ps, p0, us, tt);
+            const real dist = probe_sdf(S, ps, gs) - (real)ELEM_RADIUS;
+            m3mulv(gw, k->Rs, gs); v3addscl(c2, tip, uw, tt); v3set(nrm, -gw[0], -gw[1], -gw[2]);
+            const real am = (real)fabs((double)dist); if (am < out->min_margin) out->min_margin = am;
+            out->el_dist[e] = dist;
+            if (dist < 0) {
+                if (ncand >= USO_MAXC) out->overflow = 1;
+                if (ncand >= USO_MAXCAND) continue;
+                v3cpy(cn[ncand], nrm);
+                for (int a = 0; a < 3; a++) cp[ncand][a] = c2[a] + nrm[a] * ((real)ELEM_RADIUS + (real)0.5 * dist);
+                cdist[ncand] = dist; cand_el[ncand] = e; ctt[ncand] = tt; ncand++;
+            }
+        }
+    }
+    int nc = 0;
+    {
+        int alive[USO_MAXCAND]; for (int c = 0; c < ncand; c++) alive[c] = 1;
+        for (int drop = ncand - USO_MAXC; drop > 0; drop--) { int worst = -1; for (int c = 0; c < ncand; c++) if (alive[c] && (worst < 0 || cdist[c] >= cdist[worst])) worst = c; alive[worst] = 0; }
+        for (int c = 0; c < ncand; c++) if (alive[c]) {
+            if (nc != c) { v3cpy(cn[nc], cn[c]); v3cpy(cp[nc], cp[c]); cdist[nc] = cdist[c]; ctt[nc] = ctt[c]; }
+            out->con_t[nc] = ctt[nc]; out->con_el[nc] = cand_el[c]; out->con_dist[nc] = cdist[nc]; nc++;
+        }
+    }
+    out->ncon = nc; out->ntable = nt_c;
+    const int nv = nc + nt_c, nr = 3 * nv;
+    real W[6] = {0, 0, 0, 0, 0, 0};
+    if (nv > 0) {
+        /* arm side: Lambda^-1, site acceleration and velocity */
+        real MiJt[NJ][6], Li[36], alpha[6], vsite[6];
+        for (int a = 0; a < 6; a++) { real col[NJ]; for (int i = 0; i < NJ; i++) col[i] = k->J[a][i]; chol_solve(k->Lm, NJ, col); for (int i = 0; i < NJ; i++) MiJt[i][a] = col[i]; }
+        for (int a = 0; a < 6; a++) for (int b2 = 0; b2 < 6; b2++) { real sacc = 0; for (int i = 0; i < NJ; i++) sacc += k->J[a][i] * MiJt[i][b2]; Li[a * 6 + b2] = sacc; }
+        for (int a = 0; a < 6; a++) { real sacc = 0, u = 0; for (int i = 0; i < NJ; i++) { sacc += k->J[a][i] * qs[i]; u += k->J[a][i] * E->qd[i]; } alpha[a] = sacc; vsite[a] = u; }
+        /* rows: w (arm, probe contacts only), jt (torso: 6 body entries + the slider of the row's element), reference acceleration, regulariser */
+        real (*w)[6] = (real (*)[6])calloc((size_t)nr, sizeof(real[6]));
+        real (*jt)[7] = (real (*)[7])calloc((size_t)nr, sizeof(real[7]));
+        real (*KJ)[7] = (real (*)[7])calloc((size_t)nr * 0 + 1, sizeof(real[7])); (void)KJ;
+        int* rel_el = (int*)calloc((size_t)nv, sizeof(int));
+        real* Rr = (real*)calloc((size_t)nr, sizeof(real));
+        real* res = (real*)calloc((size_t)nr, sizeof(real));
+        real* muv = (real*)calloc((size_t)nv, sizeof(real));
+        real* lamc = (real*)calloc((size_t)nv, sizeof(real));
+        real (*fv)[3] = (real (*)[3])calloc((size_t)nv, sizeof(real[3]));
+        real* Q = (real*)calloc((size_t)nr * nr, sizeof(real));
+        const real bcon = (real)(2.0 / (SOLIMP_DMAX * SOLREF_TC));
+        const double mu_table = 1.0 > S->cfg.elem_friction ? 1.0 : S->cfg.elem_friction;     /* table friction (1, 0.005, 0.0001), ultrasound_arena.py:21-23 */
+        for (int v = 0; v < nv; v++) {
+            const int probe = v < nc, e = probe ? out->con_el[v] : tel[v - nc];
+            rel_el[v] = e;
+            real dir[3][3], cpos[3], dist;
+            if (probe) { v3cpy(dir[0], cn[v]); v3cpy(cpos, cp[v]); dist = cdist[v]; }
+            else { v3set(dir[0], 0, 0, 1); v3cpy(cpos, tp[v - nc]); dist = tdist[v - nc]; }
+            frisvad(dir[0], dir[1], dir[2]);
+            real xx = -dist / (real)SOLIMP_WIDTH; if (xx > 1) xx = 1;
+            const real y = xx < (real)0.5 ? 2 * xx * xx : 1 - 2 * (1 - xx) * (1 - xx);
+            const real dimp = (real)SOLIMP_D0 + y * (real)(SOLIMP_DMAX - SOLIMP_D0);
+            const real kk = dimp / (real)(SOLIMP_DMAX * SOLIMP_DMAX * SOLREF_TC * SOLREF_TC);
+            const real Rn = (1 - dimp) / dimp * (probe ? m->invw_contact : m->invw_table);
+            muv[v] = probe ? E->mu : (real)mu_table;
+            real rb[3], rw[3]; v3sub(rw, cpos, E->tb_p); m3tmulv(rb, Rb, rw);
+            real rs[3]; v3sub(rs, cpos, k->x);
+            for (int d = 0; d < 3; d++) {
+                const int i = 3 * v + d;
+                real db[3], rx[3]; m3tmulv(db, Rb, dir[d]); v3cross(rx, rb, db);
+                const real sg = probe ? -1 : 1;                 /* probe contact: relative motion = probe point - element point */
+                for (int a = 0; a < 3; a++) { jt[i][a] = sg * db[a]; jt[i][3 + a] = sg * rx[a]; }
+                jt[i][6] = sg * v3dot(db, m->el_axis[e]);
+                if (probe) { real rxs[3]; v3cross(rxs, rs, dir[d]); for (int a = 0; a < 3; a++) { w[i][a] = dir[d][a]; w[i][3 + a] = rxs[a]; } }
+                real vrel = 0, acc0 = 0;
+                for (int a = 0; a < 6; a++) { vrel += w[i][a] * vsite[a]; acc0 += w[i][a] * alpha[a]; }
+                for (int a = 0; a < 3; a++) { vrel += jt[i][a] * vb[a] + jt[i][3 + a] * wb[a]; acc0 += jt[i][a] * (real)at[a] + jt[i][3 + a] * (real)at[3 + a]; }
+                vrel += jt[i][6] * E->sd[e]; acc0 += jt[i][6] * (real)at[6 + e];
+                const real aref = -bcon * vrel - (d == 0 ? kk * dist : 0);
+                Rr[i] = d == 0 ? ((probe && S->cfg.probe_geoms == 2) ? (real)0.5 * Rn : Rn) : Rn / (real)IMPRATIO;
+                res[i] = acc0 - aref;
+            }
+        }
+        /* Delassus: arm part (probe rows) + jt_i K jt_j' */
+        for (int i = 0; i < nr; i++) {
+            const int vi = i / 3, ei = rel_el[vi];
+            /* u = K restricted to the row's 7 torso coordinates, times jt_i: first gather z_i = K[:, idx_i] jt_i on the coordinates any row can touch */
+            for (int j = 0; j < nr; j++) {
+                const int vj = j / 3, ej = rel_el[vj];
+                double q = 0;
+                const int idi[7] = {0, 1, 2, 3, 4, 5, 6 + ei}, idj[7] = {0, 1, 2, 3, 4, 5, 6 + ej};
+                for (int a = 0; a < 7; a++) { double sacc = 0; for (int b2 = 0; b2 < 7; b2++) sacc += K[(size_t)idi[a] * nt + idj[b2]] * (double)jt[j][b2]; q += (double)jt[i][a] * sacc; }
+                if (vi < nc && vj < nc) for (int a = 0; a < 6; a++) { real sacc = 0; for (int b2 = 0; b2 < 6; b2++) sacc += Li[a * 6 + b2] * w[j][b2]; q += (double)(w[i][a] * sacc); }
+                Q[(size_t)i * nr + j] = (real)q + (i == j ? Rr[i] : 0);
+            }
+        }
+        cone_pgs_dense(nv, Q, nr, res, muv, S->cfg.pgs_iters, fv, lamc);
+        /* accelerations: torso a = a~ + K sum jt' f ; arm: site wrench of the probe contacts */
+        double* gt = (double*)calloc((size_t)nt, sizeof(double));
+        for (int v = 0; v < nv; v++) for (int d = 0; d < 3; d++) {
+            const int i = 3 * v + d; const real f = fv[v][d];
+            for (int a = 0; a < 6; a++) gt[a] += (double)(jt[i][a] * f);
+            gt[6 + rel_el[v]] += (double)(jt[i][6] * f);
+            if (v < nc) for (int a = 0; a < 6; a++) W[a] += w[i][a] * f;
+        }
+        for (int i = 0; i < nt; i++) { double sacc = 0; const double* Ki = K + (size_t)i * nt; for (int j = 0; j < nt; j++) sacc += Ki[j] * gt[j]; at[i] += sacc; }
+        for (int v = 0; v < nc; v++) for (int d = 0; d < 3; d++) { out->con_f[v][d] = fv[v][d]; out->con_n[v][d] = cn[v][d]; }
+        for (int v = nc; v < nv; v++) out->ftable[2] += fv[v][0];
+        free(gt); free(w); free(jt); free(KJ); free(rel_el); free(Rr); free(res); free(muv); free(lamc); free(fv); free(Q);
+    }
+    for (int i = 0; i < NJ; i++) { real sacc = 0; for (int a = 0; a < 6; a++) sacc += k->J[a][i] * W[a]; out->qacc[i] = sacc; }
+    chol_solve(k->Lm, NJ, out->qacc);
+    for (int i = 0; i < NJ; i++) out->qacc[i] += qs[i];
+    for (int a = 0; a < 6; a++) out->ab[a] = (real)at[a];
+    for (int e = 0; e < n; e++) out->ael[e] = (real)at[6 + e];
+    v3set(out->fc, W[0], W[1], W[2]);
+    out->tq_sensor[0] = W[3]; out->tq_sensor[1] = W[4]; out->tq_sensor[2] = W[5];
+    free(rhs); free(at);
 }
 
 /* torque sensor at ft_frame [RESTATED: MuJoCo mj_rnePostConstraint cfrc_int of the probe body expressed in
@@ -1260,6 +1582,8 @@ static void reset_env(Sim* S, int i, const double* ex /* explicit draws or NULL 
     for (int a = 0; a < 3; a++) { E->traj_start[a] = (real)start[a]; E->traj_end[a] = (real)end[a]; }
     E->u0 = (real)u0; E->kt_stiff = (real)stiff; E->kt_damp = (real)damp; E->mu = (real)mu;
     E->has_touched = 0;                       /* ultrasound.py:434 */
+    for (int a = 0; a < 3; a++) E->tb_p[a] = m->torso_c[a];      /* free joint written at reset (ultrasound.py:430): spawn position, no velocity; the box's */
+    E->tb_q[0] = 1; E->tb_q[1] = E->tb_q[2] = E->tb_q[3] = 0;    /* orientation quat (0.5, 0.5, -0.5, -0.5) is already in el_pos / el_axis (the matrix Rt) */
     /* initial pose: IK to (traj_pt + noise, goal_quat) from init_qpos (ultrasound.py:812-844).  The
      * reference runs roboticstoolbox ikine_min on a DH Panda with empirical offsets; the net effect seen in
      * the decoded fixtures is eef = target + INIT_POS_BIAS.  Restated as fixed-count damped least squares. */
@@ -1320,7 +1644,21 @@ static void step_env(Sim* S, int i, const double* act_d, double* obs, double* re
         chol(Md, NJ); chol_solve(Md, NJ, rhs);
         for (int a = 0; a < NJ; a++) { E->qd[a] += dt * rhs[a]; E->dq[a] += dt * E->qd[a]; E->q[a] = E->q0[a] + E->dq[a]; }
         for (int e = 0; e < m->n_el; e++) { E->sd[e] += dt * P.f.ael[e]; E->s[e] += dt * E->sd[e]; }
+        if (c->torso == USO_TORSO_FULL) {
+            /* free body, semi-implicit Euler: linear part in world axes, angular velocity in the body frame, quaternion by the exponential of dt w / 2 */
+            real Rb[9], aw[3]; quat_to_rot(E->tb_q, Rb); m3mulv(aw, Rb, P.f.ab);
+            for (int a = 0; a < 3; a++) { E->tb_v[a] += dt * aw[a]; E->tb_p[a] += dt * E->tb_v[a]; E->tb_w[a] += dt * P.f.ab[3 + a]; }
+            const double wx = (double)E->tb_w[0], wy = (double)E->tb_w[1], wz = (double)E->tb_w[2], wn = sqrt(wx * wx + wy * wy + wz * wz), h = 0.5 * (double)dt * wn;
+            const double sh = wn > 1e-12 ? sin(h) / wn : 0.5 * (double)dt, ch = cos(h);
+            const double q0 = E->tb_q[0], q1 = E->tb_q[1], q2 = E->tb_q[2], q3 = E->tb_q[3], dx = wx * sh, dy = wy * sh, dz2 = wz * sh;
+            double r0 = q0 * ch - q1 * dx - q2 * dy - q3 * dz2, r1 = q0 * dx + q1 * ch + q2 * dz2 - q3 * dy, r2 = q0 * dy - q1 * dz2 + q2 * ch + q3 * dx, r3 = q0 * dz2 + q1 * dy - q2 * dx + q3 * ch;
+            const double rn = sqrt(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
+            E->tb_q[0] = (real)(r0 / rn); E->tb_q[1] = (real)(r1 / rn); E->tb_q[2] = (real)(r2 / rn); E->tb_q[3] = (real)(r3 / rn);
+        }
         if (P.f.overflow) E->status |= 1;
+        E->info_table[0] = P.f.ntable; E->info_table[1] = (double)P.f.ftable[2];
+        E->warm_n = P.f.ncon;
+        for (int cix = 0; cix < P.f.ncon; cix++) { E->warm_el[cix] = P.f.con_el[cix]; E->warm_lam[cix] = P.f.con_lam[cix]; for (int a = 0; a < 3; a++) E->warm_f[cix][a] = P.f.con_f[cix][a]; }
     }
     E->sub = 0;
     /* sensors read mj_step's data: kinematics/contacts from before the integration, qvel from after
@@ -1410,7 +1748,7 @@ void* uso_create(const uso_config* c, int n) {
     S->env = (Env*)calloc((size_t)n, sizeof(Env));
     return S;
 }
-void uso_destroy(void* h) { Sim* S = (Sim*)h; if (!S) return; free(S->m.lat_L); free(S->m.lat_Linv); free(S->env); free(S); }
+void uso_destroy(void* h) { Sim* S = (Sim*)h; if (!S) return; free(S->m.lat_L); free(S->m.lat_Linv); free(S->m.full_K); free(S->env); free(S); }
 int uso_action_dim(void* h) { return ((Sim*)h)->adim; }
 int uso_num_elements(void* h) { return ((Sim*)h)->m.n_el; }
 int uso_shell_edges(void* h) { return ((Sim*)h)->m.n_shell_edges; }
@@ -1460,6 +1798,27 @@ int uso_set_state(void* h, const double* sc, const double* lat) {
         E->kt_stiff = (real)o[32]; E->kt_damp = (real)o[33]; E->mu = (real)o[34];
         E->t = (int)o[35]; E->has_touched = (int)o[36]; E->episode = (int)o[37]; E->ep_return = (real)o[38]; E->status = (int)o[39];
         if (lat) for (int e = 0; e < n_el; e++) { E->s[e] = (real)lat[((size_t)i * n_el + e) * 2]; E->sd[e] = (real)lat[((size_t)i * n_el + e) * 2 + 1]; }
+    }
+    return 0;
+}
+/* full torso: pose and velocity of the free body, n x 13 = position (world), quaternion w x y z, linear velocity (world), angular velocity (body frame); and per env the
+ * number of element-table contacts and their net normal force in the last forward pass (diag: n x 2) */
+int uso_get_torso(void* h, double* out, double* diag) {
+    Sim* S = (Sim*)h;
+    for (int i = 0; i < S->n; i++) {
+        const Env* E = &S->env[i]; double* o = out + (size_t)i * 13;
+        for (int a = 0; a < 3; a++) { o[a] = (double)E->tb_p[a] + BASE_WORLD[a]; o[7 + a] = (double)E->tb_v[a]; o[10 + a] = (double)E->tb_w[a]; }
+        for (int a = 0; a < 4; a++) o[3 + a] = (double)E->tb_q[a];
+        if (diag) { diag[2 * i] = E->info_table[0]; diag[2 * i + 1] = E->info_table[1]; }
+    }
+    return 0;
+}
+int uso_set_torso(void* h, const double* in) {
+    Sim* S = (Sim*)h;
+    for (int i = 0; i < S->n; i++) {
+        Env* E = &S->env[i]; const double* o = in + (size_t)i * 13;
+        for (int a = 0; a < 3; a++) { E->tb_p[a] = (real)(o[a] - BASE_WORLD[a]); E->tb_v[a] = (real)o[7 + a]; E->tb_w[a] = (real)o[10 + a]; }
+        for (int a = 0; a < 4; a++) E->tb_q[a] = (real)o[3 + a];
     }
     return 0;
 }

@@ -37,7 +37,7 @@ extern "C" {
 /* impedance_mode of the OSC controller (rl_config.yaml:41, main.py:33, utils/plot.py:203-211,303-313) */
 enum { USO_MODE_TRACKING = 0, USO_MODE_FIXED = 1, USO_MODE_VARIABLE_Z = 2, USO_MODE_WRENCH = 3 };
 /* torso model: 0 = rigid/absent (BASELINE config #2), 1 = 99 top-face elements dynamic (config #3) */
-enum { USO_TORSO_NONE = 0, USO_TORSO_TOP = 1 };
+enum { USO_TORSO_NONE = 0, USO_TORSO_TOP = 1, USO_TORSO_FULL = 2 };   /* 2: all 270 shell elements on the free torso body, element-table contacts (round 4) */
 enum { USO_ROBOT_PANDA = 0, USO_ROBOT_UR5E = 1 };
 
 typedef struct uso_config {
@@ -86,7 +86,7 @@ typedef struct uso_config {
     double probe_halfwidth;       /* round 4: half-width of the flat part of the probe's face across the blade (the face is a 2 probe_halflen x 2 probe_halfwidth rectangle
                                    * with edges of radius probe_radius; 0 = the blade of round 3) */
     int32_t pair_model;           /* STUDY switch, oracle only (tests/studies/solver_study.py): 1 = the two coincident contacts of probe_geoms = 2 as two contacts instead of the merged one */
-    int32_t reserved3_;
+    int32_t warm_start;           /* STUDY switch, oracle only: 1 = the contact solver starts from the forces of the previous physics step (matched by element) */
     double probe_tip;             /* round 4: the probe's lowest point lies this far beyond grip_site along the site's z axis (0: the tip is the site) */
 } uso_config;
 

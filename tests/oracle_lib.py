@@ -11,7 +11,7 @@ ROOT = Path(__file__).resolve().parent.parent
 ORACLE_DIR = ROOT / "oracle"
 OBS_DIM, MAXC, NSCALAR = 19, 8, 40
 MODE = {"tracking": 0, "fixed": 1, "variable_z": 2, "wrench": 3}
-TORSO = {"none": 0, "top": 1}
+TORSO = {"none": 0, "top": 1, "full": 2}
 ROBOT = {"Panda": 0, "UR5e": 1}
 
 SCALAR_FIELDS = {  # name -> slice in the uso_get_state scalar block
@@ -28,7 +28,7 @@ class OracleConfig(C.Structure):
         [("seed", C.c_uint64)] + [(n, C.c_double) for n in (
             "control_dt", "kp_fixed", "damping_ratio", "kp_min", "kp_max", "out_max_pos", "out_max_ori", "stiffness",
             "damping", "elem_friction", "probe_friction", "probe_radius", "probe_halflen", "probe_radius2", "probe_height")] + \
-        [("substeps", C.c_int32), ("lattice_ramp", C.c_int32), ("study_fix_tc", C.c_double), ("probe_friction2", C.c_double), ("probe_geoms", C.c_int32), ("cone_solver", C.c_int32), ("probe_halfwidth", C.c_double), ("pair_model", C.c_int32), ("reserved3_", C.c_int32), ("probe_tip", C.c_double)]
+        [("substeps", C.c_int32), ("lattice_ramp", C.c_int32), ("study_fix_tc", C.c_double), ("probe_friction2", C.c_double), ("probe_geoms", C.c_int32), ("cone_solver", C.c_int32), ("probe_halfwidth", C.c_double), ("pair_model", C.c_int32), ("warm_start", C.c_int32), ("probe_tip", C.c_double)]
 
 
 def build_oracle(native=False):
@@ -135,6 +135,13 @@ class Oracle:
             sc[:, v] = st[k]
         lat[:, : self.n_el, 0] = st["s"]; lat[:, : self.n_el, 1] = st["sd"]
         self.lib.uso_set_state(self.h, _ptr(sc), _ptr(lat))
+
+    def get_torso(self):
+        """full torso: pose / velocity of the free body (n x 13) and (table contacts, their net normal force) of the last forward pass"""
+        out = np.zeros((self.n, 13)); diag = np.zeros((self.n, 2))
+        self.lib.uso_get_torso.argtypes = [C.c_void_p, _dp, _dp]
+        self.lib.uso_get_torso(self.h, _ptr(out), _ptr(diag))
+        return {"pos": out[:, 0:3], "quat": out[:, 3:7], "vel": out[:, 7:10], "omega": out[:, 10:13], "table_contacts": diag[:, 0].astype(int), "table_force": diag[:, 1]}
 
     def random_actions(self, step):
         a = np.zeros((self.n, self.adim))

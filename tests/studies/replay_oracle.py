@@ -19,6 +19,7 @@ def med(o):
 
 
 def replay(mode, n, T, deterministic=False, **kw):
+    kw = dict(kw)
     metas = json.loads((ROOT / "tests/golden/reference_pins.json").read_text())
     pins = np.load(ROOT / "tests/golden/reference_pins.npz")
     meta = metas[mode]
@@ -33,7 +34,7 @@ def replay(mode, n, T, deterministic=False, **kw):
         mu = h @ W["action_net.weight"].T + W["action_net.bias"]
         return np.clip(mu if deterministic else mu + np.exp(W["log_std"]) * rng.standard_normal(mu.shape), lo, hi)
 
-    o = Oracle(n, omp=True, mode=MODE[mode], torso="top", seed=3, torso_solref_randomization=1, initial_probe_pos_randomization=1, early_termination=1, **kw)
+    o = Oracle(n, omp=True, mode=MODE[mode], torso=kw.pop("torso", "top"), seed=3, torso_solref_randomization=1, initial_probe_pos_randomization=1, early_termination=1, **kw)
     rng = np.random.default_rng(0); obs = o.reset(); keep = []; rew = 0.0
     ep_len = np.zeros(n); lens = []; causes = np.zeros(32, int)
     for k in range(T):
@@ -54,7 +55,7 @@ if __name__ == "__main__":
     kw = {}
     for a in sys.argv[4:]:
         k, v = a.split("=")
-        kw[k] = int(v) if v.lstrip("-").isdigit() else float(v)
+        kw[k] = v if k == "torso" else (int(v) if v.lstrip("-").isdigit() else float(v))
     for m in modes:
         t0 = time.time()
         r = replay(m, n, T, **kw)

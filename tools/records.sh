@@ -1,6 +1,6 @@
 #!/bin/bash
 # Every record of profiles/<round>/ from ONE box and one gpurun call: tools/records.sh <round tag, e.g. r03>   (then tools/records_collect.sh <tag> here)
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 G=$ROOT/gpurun_out; mkdir -p "$G"
 cd "$ROOT"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # copies what tools/records.sh left in gpurun_out/ into profiles/<tag>/ under the names the documents cite
-TAG=${1:-r03}; cd "$(dirname "$0")/.."; G=gpurun_out; P=profiles/$TAG; mkdir -p $P
+TAG=${1:-r04}; cd "$(dirname "$0")/.."; G=gpurun_out; P=profiles/$TAG; mkdir -p $P
 cp $G/bench_matrix.txt $P/bench_matrix.txt
 cp $G/${TAG}_bench_soft.json $P/bench_soft.json; cp $G/${TAG}_bench_driver.json $P/bench_soft_driver_style.json
 cp $G/${TAG}_bench_rigid.json $P/bench_rigid.json; cp $G/${TAG}_bench_config5.json $P/bench_config5_8192_randomised.json
@@ -9,7 +9,7 @@ cp $G/prof_${TAG}_rigid/stats/stats_kernel_stats.csv $P/rocprofv3_rigid_4096_ker
 cp $G/prof_${TAG}_config5/stats/stats_kernel_stats.csv $P/rocprofv3_config5_8192_kernel_stats.csv
 cp $G/prof_${TAG}_soft_spl1/stats/stats_kernel_stats.csv $P/rocprofv3_soft_4096_single_step_launches_kernel_stats.csv
 cp $G/${TAG}_timeline.txt $P/timeline_split_soft.txt; cp $G/${TAG}_timeline_multi.txt $P/timeline_split_soft_multi_step.txt; cp $G/${TAG}_timeline_g8.txt $P/timeline_split_soft_8lane_groups_8192.txt
-cp $G/${TAG}_parity_fullsize.txt $P/parity_fullsize.txt
+cp $G/${TAG}_parity_fullsize.txt $P/parity_fullsize.txt; cp $G/${TAG}_parity_report.txt $P/parity_report.txt
 cp $G/${TAG}_policy_replay.txt $P/policy_replay.txt; cp $G/${TAG}_replay_medians.txt $P/replay_medians.txt; cp $G/${TAG}_collector_probe.txt $P/collector_probe.txt
 cp $G/${TAG}_prof_collector.txt $P/rocprofv3_fused_collector_4096_summary.txt; cp $G/${TAG}_ppo_fused.txt $P/ppo_demo_fused_collector.txt; cp $G/${TAG}_soak.txt $P/soak.txt
 python3 tools/make_traffic.py $G/prof_${TAG}_soft $G/prof_${TAG}_rigid > $P/traffic.json
