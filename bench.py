@@ -21,11 +21,8 @@ for p in (str(ROOT), str(ROOT / "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0              # MI355X HBM3E peak (guides/MI355X_MICROARCH.md)
-FP32_VALU_PEAK_TFLOPS = 157.3
 # algorithmic bytes per env-step: compulsory fp32 state read+write with state resident in HBM
 ALGO_BYTES = {"rigid": 316, "soft": 1912}
-# algorithmic flops per env-step of this build's step
-ALGO_FLOPS = {"rigid": 9.0e3, "soft": 5.5e4}
 WORKLOAD_NAME = {"rigid": "configs[1]: 4096 envs/GPU, rigid torso (contact solver off), OSC controller only",
                  "soft": "configs[2]: 4096 envs/GPU, soft-torso contact + force/velocity-tracking reward",
                  "randomised": "configs[4]: 8192 envs/GPU with domain-randomised torso stiffness/damping + probe friction"}
@@ -244,7 +241,6 @@ def main():
     kern_steps = args.steps
     avg_kernel_s = dev_ms * 1e-3 / kern_steps
     achieved_gbs = ALGO_BYTES[args.workload] * n / avg_kernel_s / 1e9
-    valu_tflops = ALGO_FLOPS[args.workload] * n / avg_kernel_s / 1e12
 
     traffic_step = None
     tfile = next((f for f in (ROOT / "profiles" / r / "traffic.json" for r in ("r04", "r03", "r02", "r01")) if f.exists()), ROOT / "profiles" / "r04" / "traffic.json")
@@ -256,6 +252,14 @@ def main():
                 traffic_step = (tj.get("fetch_kb_x2", 2 * tj["fetch_kb"]) + tj["write_kb"]) * 1024.0
         except Exception:
             traffic_step = None
+
+    issue = None
+    ifile = tfile.parent / "issue.json"
+    if ifile.exists() and n == 4096:
+        try:
+            issue = json.loads(ifile.read_text()).get(args.workload)
+        except Exception:
+            issue = None
 
     # the mapping usim_create picks (csrc/usim_api.hip): soft torso -> the split kernel, 16-lane groups (32) up to 4096 envs, 8-lane groups (64) beyond
     lanes = int(extra.get("lanes_per_env", 0)) or ((32 if n <= 4096 else 64) if (args.workload == "soft" and not extra.get("waves_per_simd")) else 16)
@@ -292,8 +296,11 @@ def main():
                          "steps_per_launch": spl, "avg_launch_us": avg_kernel_s * 1e6 * spl,
                          "refill_launches": refill_n, "refill_us_per_step": refill_ms * 1e3 / args.steps, "block_us_per_step": block_ms * 1e3 / args.steps,
                          "avg_kernel_us": avg_kernel_s * 1e6, "kernel": {32: "usim_step32_kernel", 64: "usim_step32_kernel (8-lane groups)", 16: "usim_step16_kernel"}.get(lanes, "usim_step_kernel") + ("<multi-step>" if spl > 1 else ""),
-                         "valu_fp32_tflops": valu_tflops, "valu_frac": valu_tflops / FP32_VALU_PEAK_TFLOPS,
-                         "note": "kernel is FP32-VALU/latency bound at 4096 envs (one or two waves per SIMD, serial per-environment chain), not HBM bound; see DESIGN.md section 5"},
+                         # what binds the kernel, from the committed PMC profile of this command (tools/profile.sh -> profiles/<round>/issue.json): vector instructions
+                         # issued per wave and step, and the share of the waves' cycles in which one issues -- the kernel is instruction-issue bound, not HBM bound
+                         "issue": issue,
+                         "note": "kernel is bound by VALU instruction issue at 4096 envs (two waves per SIMD, a serial per-environment chain; the state of a multi-step launch "
+                                 "lives in registers and L2), not by HBM; see DESIGN.md section 5"},
         }
         if world == 1 and on_gpu and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, n)

@@ -421,3 +421,45 @@ def test_contact_slot_overflow_keeps_the_deepest_elements():
     # the status word reports it for the rest of the episode
     o.step(np.full((n, 6), 0.5), auto_reset=False)
     assert (o.get_state()["status"].astype(int) & 1).sum() >= seen_overflow
+
+
+def test_full_torso_stands_on_the_table_and_agrees_with_the_top_face_model():
+    """torso="full" (oracle; SURVEY.md section 8 row a3 in full: 270 shell elements on the free torso body of ultrasound.py:426-431, element-table contacts with the
+    table's friction 1): (1) released at the spawn pose the torso does NOT fall through the 4.7 mm gap of ultrasound.py:313 -- the caps of its tilted rim capsules
+    already reach the table --: it settles within a quarter of a millimetre of the spawn height on ~50 element-table contacts that carry its weight (271 x 0.01 kg);
+    (2) what the probe feels is what the top-face model (99 dynamic elements on a static base at the spawn height: the product's model) gives: same contact lists,
+    contact forces within a few per cent over a pressed-in rollout."""
+    o = Oracle(2, torso="full", pgs_iters=20); o.reset()
+    assert o.n_el == 270
+    st = o.get_state(); st["q"][:] = np.array([0.0, np.pi / 16, 0.0, -np.pi / 2 - np.pi / 3, 0.0, np.pi - 0.2, np.pi / 4]); st["qd"][:] = 0; o.set_state(st)   # arm away
+    for k in range(150):
+        o.step(np.zeros((2, 6)), auto_reset=False)
+    t = o.get_torso()
+    weight = 271 * 0.01 * 9.81
+    assert np.all(np.abs(t["pos"][:, 2] - 0.8572) < 2.5e-4) and np.all(np.abs(t["vel"]) < 1e-3)
+    assert np.all(t["table_contacts"] >= 36) and np.all(t["table_contacts"] <= 99)
+    assert np.allclose(t["table_force"], weight, rtol=0.01)
+    assert np.all(np.abs(t["quat"][:, 0] - 1) < 1e-6)                                    # no tumbling
+    # probe side: the same seeded episodes on both models
+    n = 6
+    a, b = Oracle(n, torso="top", pgs_iters=8), Oracle(n, torso="full", pgs_iters=8)
+    oa, ob = a.reset(), b.reset()
+    assert np.allclose(oa[:, 12:19], ob[:, 12:19], atol=1e-12)
+    on = oa[:, 2] > 1.0
+    # reset observation (the probe is spawned up to 3 cm deep: forces of 100 N within one step): the free body gives way -- its inverse mass 1 / 2.71 kg adds to the
+    # ~2.6 / kg of element + arm in a contact's normal row --, so the INSTANTANEOUS force is 10 - 20 % below the static-base model's.  (The probe head of the product is
+    # fitted to the reference's reset rows with the static base, i.e. has absorbed this.)
+    ratio = ob[on, 2] / oa[on, 2]
+    assert on.sum() >= 3 and np.all((ratio > 0.75) & (ratio < 1.01)), ratio
+    fa, fb, same = [], [], 0
+    for k in range(60):
+        act = a.random_actions(k)
+        ra, rb = a.step(act, auto_reset=False), b.step(act, auto_reset=False)
+        # contact lists: shell ids of the top-face elements (top model) vs of all elements (full model) -- the same numbering (creation order)
+        same += int((ra[4][:, 0] == rb[4][:, 0]).sum())
+        fa.append(ra[0][:, :3]); fb.append(rb[0][:, :3])
+    fa, fb = np.array(fa), np.array(fb)
+    assert same >= 0.9 * 60 * n
+    big = np.abs(fa[..., 2]) > 2.0
+    rel = np.abs(fa - fb).max(-1)[big] / np.abs(fa[..., 2])[big]
+    assert big.sum() > 100 and np.median(rel) < 0.03 and np.quantile(rel, 0.9) < 0.15, (np.median(rel), np.quantile(rel, 0.9))

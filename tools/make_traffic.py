@@ -34,3 +34,30 @@ out["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KB), separate passes (t
                "the correction applies to the former, is uncalibrated for the latter -- fetch_kb_x2 is the upper bound, and the figure to compare "
                "with the algorithmic bytes. WRITE_SIZE is uncalibrated (reported raw). bench.py reports fetch_kb_x2 + write_kb.")
 print(json.dumps(out, indent=1))
+
+
+def counter_mean(root, sub, counter):
+    vals = []
+    for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if "usim_step" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    vals.append(float(r["Counter_Value"]))
+    if not vals:
+        return None
+    med = sorted(vals)[len(vals) // 2]
+    sel = [v for v in vals if 0.5 * med < v < 2.0 * med]
+    return sum(sel) / len(sel)
+
+
+# issue.json (4th argument: its path): instruction-issue figures of the step kernel per launch, from the SQ passes of tools/profile.sh
+if len(sys.argv) > 4:
+    iss = {}
+    for tag, root, waves in (("soft", sys.argv[1], 2048), ("rigid", sys.argv[2], 1024)):
+        valu, wc = counter_mean(root, "pmc_sq1", "SQ_INSTS_VALU"), counter_mean(root, "pmc_sq1", "SQ_WAVE_CYCLES")
+        act, lds, conf = counter_mean(root, "pmc_sq2", "SQ_ACTIVE_INST_VALU"), counter_mean(root, "pmc_sq2", "SQ_ACTIVE_INST_LDS"), counter_mean(root, "pmc_sq2", "SQ_LDS_BANK_CONFLICT")
+        if valu and wc:
+            iss[tag] = {"valu_inst_per_wave_step": valu / (waves * spl), "valu_active_share_of_wave_cycles": None if not act else act / wc,
+                        "lds_bank_conflict_cycles_per_lds_active_cycle": None if not (lds and conf) else conf / lds, "waves": waves, "steps_per_launch": spl,
+                        "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES / SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT (tools/profile.sh), mean over the full step launches"}
+    open(sys.argv[4], "w").write(json.dumps(iss, indent=1))
