@@ -653,7 +653,7 @@ const char* usim_last_hip_error(const usim_handle* h) { return h ? h->hip_err.c_
 #ifndef USIM_SRC_HASH
 #define USIM_SRC_HASH "unhashed"
 #endif
-const char* usim_version(void) { return "usim 0.3 (gfx950) src " USIM_SRC_HASH; }
+const char* usim_version(void) { return "usim 0.4 (gfx950) src " USIM_SRC_HASH; }
 
 }  // extern "C"
 

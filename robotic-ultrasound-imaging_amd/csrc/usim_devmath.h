@@ -158,7 +158,7 @@ DI void sincos_(float x, float& s, float& c) {
 
 // INLINE_TRIG: the branch-free sincos_ above (one environment per lane, where registers are plentiful); otherwise the library
 // sincosf, whose internal branches keep the scheduling regions -- and with them the register pressure -- of the grouped kernels small
-// (negative result v)
+// (docs/DESIGN_rounds_1-3.md section 7, negative result v)
 template <bool INLINE_TRIG>
 DI void fk(const DevModel& M, const float* q, Kin& K) {
     f3 px = mk(1.f, 0.f, 0.f), py = mk(0.f, 1.f, 0.f), pz = mk(0.f, 0.f, 1.f), po = mk(0.f, 0.f, 0.f);

@@ -112,7 +112,8 @@ DI float group_bcast(float v, int k) {
 #define USIM_CSTAMP(dbg, k) do { if ((dbg) && blockIdx.x == 0 && threadIdx.x == 256) (dbg)[40 + (k)] = __builtin_readcyclecounter(); } while (0)
 #endif
 
-// prescribed torso base motion: free fall over the 4.7 mm spawn gap, then rest (ultrasound.py:313)
+// prescribed torso base motion (usim_config.torso_drop): none since round 4 (drop = 0: the torso stands on its rim capsules at the spawn height);
+// torso_drop = 1: free fall over the 4.7 mm spawn gap of ultrasound.py:313, then rest
 DI void torso_motion(const DevCfg& C, int tsim, float& dz, float& vz, float& az) {
     dz = -C.drop; vz = 0.f; az = 0.f;
     if (C.torso_drop) {

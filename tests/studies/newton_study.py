@@ -1,0 +1,79 @@
+"""What a Newton solver would cost and buy (study for DESIGN.md section 9): MuJoCo's own default solver, restated on the REDUCED primal problem of this model -- unknowns: the
+site-space acceleration of the probe (6) and the accelerations of the contacted elements (<= 8); cost: 1/2 |a - a_s|^2 in the metric blockdiag(Lambda, m (L^-1_cc)^-1) plus the
+three-zone contact penalties in the R metric (top: no force; bottom: sticking; middle: on the cone) -- with an exact line search, on the dual problems the oracle exports.
+Result (profiles/r04/solver_study.txt): cold start needs 6 iterations for 1e-2 N at the 99th percentile (4: 1 N, 5: 0.1 N), each a (6 + nc)-dimensional factorisation plus a line
+search; without the line search the iteration cycles between two active sets in 10 - 50 % of the environments.   usage: python tests/studies/newton_study.py"""
+import sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT / "tests")); sys.path.insert(0, str(ROOT / "tests" / "studies"))
+import numpy as np
+from cone_qp import net_force, solve_exact
+from oracle_lib import Oracle
+import ctypes as C
+from oracle_lib import _ptr
+
+
+def zone(y, R, mu):
+    """per contact: force f = argmin_{K} 1/2 f'Rf + f'y, cost s, H = -df/dy.  R = (Rn, Rt, Rt)"""
+    Rn, Rt = R[0], R[1]
+    mt = mu*np.sqrt(Rt/Rn)
+    yn, yt = -y[0]/np.sqrt(Rn), -y[1:]/np.sqrt(Rt)
+    T = np.linalg.norm(yt)
+    if T <= mt*yn:
+        f = np.array([yn/np.sqrt(Rn), yt[0]/np.sqrt(Rt), yt[1]/np.sqrt(Rt)]); H = np.diag(1/R); s = 0.5*(yn*yn+T*T)
+    elif mt*T <= -yn:
+        f = np.zeros(3); H = np.zeros((3,3)); s = 0.0
+    else:
+        p = (yn + mt*T)/(1+mt*mt); e = yt/T
+        f = np.array([p, mt*p*e[0], mt*p*e[1]])/np.sqrt(R); s = 0.5*(yn + mt*T)**2/(1+mt*mt)
+        gp = np.array([1.0, mt*e[0], mt*e[1]]); Ht = np.outer(gp,gp)/(1+mt*mt); Ht[1:,1:] += (p*mt/T)*(np.eye(2)-np.outer(e,e))
+        D = np.diag(1/np.sqrt(R)); H = D@Ht@D
+    return f, s, H, 0
+
+
+MAXC, ROW = 8, 10; SIZE = 2 + 36 + MAXC*3*ROW + MAXC*MAXC
+def dump(o,i,act):
+    out=np.zeros(SIZE); o.lib.uso_debug_dual.argtypes=[C.c_void_p,C.c_int,C.POINTER(C.c_double),C.POINTER(C.c_double)]
+    a=np.ascontiguousarray(act,dtype=np.float64); nc=o.lib.uso_debug_dual(o.h,i,_ptr(a),_ptr(out))
+    if nc<=0: return None
+    Li=out[2:38].reshape(6,6); rows=out[38:38+MAXC*3*ROW].reshape(MAXC*3,ROW)[:3*nc]; Lm=out[38+MAXC*3*ROW:].reshape(MAXC,MAXC)[:nc,:nc]
+    W,g,R,b=rows[:,:6],rows[:,6],rows[:,7],rows[:,8]; G=np.zeros((3*nc,nc))
+    for c in range(nc): G[3*c:3*c+3,c]=g[3*c:3*c+3]
+    A=W@Li@W.T+G@Lm@G.T
+    return dict(nc=nc,mu=out[1],Li=Li,W=W,G=G,R=R,b=b,Lm=Lm,A=A,Q=A+np.diag(R))
+
+
+def newton_ls(P, iters, ls_evals=30, init='zero'):
+    nc=P['nc']; W=P['W']; G=P['G']; b=P['b']; R=P['R']; mu=P['mu']
+    Lam=np.linalg.inv(P['Li']); mK=np.linalg.inv(P['Lm'])
+    M=np.zeros((6+nc,6+nc)); M[:6,:6]=Lam; M[6:,6:]=mK
+    J=np.hstack([W,G]); z=np.zeros(6+nc)
+    def cg(z, want_H=True):
+        y=J@z+b; C=0.5*z@M@z; g=M@z; H=M.copy() if want_H else None; F=np.zeros(3*nc)
+        for c in range(nc):
+            i=slice(3*c,3*c+3); f,s,Hc,_=zone(y[i],R[i],mu); C+=s; g-=J[i].T@f; F[i]=f
+            if want_H: H+=J[i].T@Hc@J[i]
+        return C,g,H,F
+    nev=0
+    for it in range(iters):
+        C,g,H,F=cg(z); dz=-np.linalg.solve(H,g)
+        # exact line search by bisection on the directional derivative (convex 1-D function)
+        d1=lambda t: cg(z+t*dz,False)[1]@dz
+        lo,hi=0.0,1.0
+        while d1(hi)<0 and hi<64: hi*=2; nev+=1
+        for k in range(ls_evals):
+            mid=0.5*(lo+hi)
+            if d1(mid)<0: lo=mid
+            else: hi=mid
+        z=z+0.5*(lo+hi)*dz
+    return cg(z,False)[3]
+if __name__=='__main__':
+    for n,pre in ((192,8),(192,300)):
+        o=Oracle(n); o.reset()
+        for k in range(pre): o.step(o.random_actions(k))
+        act=o.random_actions(pre); probs=[dump(o,i,act[i]) for i in range(n)]; probs=[p for p in probs if p]; ex=[solve_exact(p) for p in probs]
+        print(f'{len(probs)} problems {pre} steps after a synchronous reset')
+        for k in (2,3,4,5,6,8):
+            e=np.array([np.abs(net_force(p,newton_ls(p,k))-net_force(p,x)).max() for p,x in zip(probs,ex)])
+            print(f'  reduced primal Newton, {k} iterations, exact line search: median {np.median(e):.1e} q90 {np.quantile(e,.9):.1e} q99 {np.quantile(e,.99):.1e} max {e.max():.1e} N')

@@ -1,0 +1,58 @@
+"""Joint fit of the probe stand-in (the mesh is missing from the reference snapshot) to BOTH regimes the reference's data show: the 192 decoded reset rows (contact onset by
+height, force by depth, spreads of the lateral forces and torques) and the end-of-training statistics of the `tracking` / `variable_z` checkpoints (riding height, reward per
+step, episode length), on the CPU oracle.  Random local search over (probe_radius, probe_halfwidth, probe_halflen, probe_radius2, probe_height, probe_tip); every evaluation is
+appended to a JSON-lines log.   usage: python tests/studies/probe_fit.py <seed> <log.jsonl> <evaluations> [r,hw,h,r2,H,tip]      record: profiles/r04/probe_fit.txt"""
+import sys, time, json
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT / "tests" / "studies")); sys.path.insert(0, str(ROOT / "tests"))
+import numpy as np
+from replay_oracle import replay
+from calib_probe import stats, REF
+from oracle_lib import Oracle
+BINS2=((13,15),(11,13),(8,11))
+zr=REF[:,14]*1e3; cr=REF[:,2]>0
+REF_ONSET=np.array([cr[(zr>=lo)&(zr<hi)].mean() for lo,hi in ((15,18),(13,15),(11,13),(8,11))])
+REF_FZ2=np.array([REF[(zr>=lo)&(zr<hi)&cr,2].mean() for lo,hi in BINS2])
+RS=stats(REF)
+NAMES=['probe_radius','probe_halfwidth','probe_halflen','probe_radius2','probe_height','probe_tip']
+def evaluate(x, base, full=True):
+    kw=dict(base); kw.update(dict(zip(NAMES,[float(v) for v in x])))
+    O=Oracle(3072, **kw).reset()
+    if (O[:,2]>0.5).sum()<50: return 1e9,dict(x=[float(a) for a in x],L=1e9)
+    v=stats(O)
+    z=O[:,14]*1e3; c=O[:,2]>0
+    onset=np.array([c[(z>=lo)&(z<hi)].mean() for lo,hi in ((15,18),(13,15),(11,13),(8,11))])
+    fz2=np.array([O[(z>=lo)&(z<hi)&c,2].mean() if (c&(z>=lo)&(z<hi)).any() else 0 for lo,hi in BINS2])
+    if c.sum()<50: return 1e9,dict(x=[float(a) for a in x],L=1e9)
+    L_on=4*((onset-REF_ONSET)**2).sum()
+    L_b=(((v['bins']-RS['bins'])/RS['bins'])**2).sum()+0.5*(((fz2-REF_FZ2)/REF_FZ2)**2).sum()
+    L_lat=0.5*((((v['Fs']-RS['Fs'])/RS['Fs'])**2).sum()+(((v['Ts']-RS['Ts'])/RS['Ts'])**2).sum()+(((v['q99']-RS['q99'])/RS['q99'])**2).sum())+ (v['cxz']-RS['cxz'])**2
+    rec=dict(x=[float(a) for a in x],onset=onset.round(2).tolist(),fz2=fz2.round(1).tolist(),bins=v['bins'].round(0).tolist(),Fs=v['Fs'].round(1).tolist(),Ts=v['Ts'].round(2).tolist(),q99=v['q99'].round(0).tolist(),cxz=round(float(v['cxz']),2),L_on=round(float(L_on),3),L_b=round(float(L_b),3),L_lat=round(float(L_lat),3))
+    L=L_on+L_b+L_lat
+    if full:
+        r=replay('tracking',96,2000,**kw)
+        h=float(r['med'].split('height')[1].split('mm')[0])
+        L_r=((h-10.6)/3)**2+((r['reward_per_step']-8.12)/0.3)**2+((r['ep_len']-727)/150)**2
+        r2=replay('variable_z',96,2000,**kw)
+        h2=float(r2['med'].split('height')[1].split('mm')[0])
+        L_r+=((h2-11.6)/3)**2+((r2['reward_per_step']-8.03)/0.3)**2+((r2['ep_len']-718)/150)**2
+        rec.update(rew=round(r['reward_per_step'],2),len=round(r['ep_len']),height=h,med=r['med'],vz_rew=round(r2['reward_per_step'],2),vz_len=round(r2['ep_len']),vz_height=h2,L_r=round(float(L_r),3)); L+=L_r
+    rec['L']=round(float(L),3)
+    return L,rec
+if __name__=='__main__':
+    base=dict(pgs_iters=4)
+    x=np.array([0.010,0.0,0.020,0.040,0.047,0.0]) if len(sys.argv)<5 else np.array([float(v) for v in sys.argv[4].split(',')])
+    step=np.array([0.002,0.003,0.004,0.008,0.008,0.0007])
+    lo=np.array([0.002,0.0,0.003,0.01,0.012,-0.002]); hi=np.array([0.03,0.03,0.03,0.06,0.07,0.005])
+    rng=np.random.default_rng(int(sys.argv[1]) if len(sys.argv)>1 else 0)
+    log=open(sys.argv[2] if len(sys.argv)>2 else '/tmp/probe_fit_log.jsonl','a')
+    best,rec=evaluate(x,base); print('start',json.dumps(rec),flush=True); log.write(json.dumps(rec)+'\n'); log.flush()
+    for it in range(int(sys.argv[3]) if len(sys.argv)>3 else 60):
+        # random direction: perturb 1-2 coordinates
+        y=x.copy(); idx=rng.choice(len(x),size=rng.integers(1,3),replace=False)
+        y[idx]+=step[idx]*rng.choice([-1,1],size=len(idx))*rng.uniform(0.5,1.5,size=len(idx)); y=np.clip(y,lo,hi)
+        if y[3]<=y[0]: continue
+        L,r=evaluate(y,base); log.write(json.dumps(r)+'\n'); log.flush()
+        if L<best: best,x,rec=L,y,r; print(it,'BEST',json.dumps(r),flush=True)
+        else: print(it,'    ',round(L,3),[round(float(a),4) for a in y],flush=True)

@@ -112,12 +112,11 @@ DEPTH_BINS = ((-0.030, -0.015), (-0.015, -0.005), (-0.005, 0.0), (0.0, 0.005), (
 
 def check_reset_rows_against_reference(obs, ref):
     """Shared by the oracle test below and its GPU twin (tests/test_gpu_properties.py): the six force / torque channels of a batch of
-    reset observations against the 192 reset rows decoded from the reference checkpoints (calibration record
-    profiles/r03/calib_probe.txt, tests/studies/calib_probe.py).  Bands: +-30 % on the spread of Fx, Fy, Fz, torque x, torque y, +-25 % + 2 N on
-    the binned force-depth curve.  Since the second colliding probe geom of the reference's XML is modelled (usim_config.probe_geoms = 2: friction 1.0,
-    DESIGN.md section 2) the spread of Fy (reference 8.4 N; 3.8 N before, 8.6 N now) is inside the band.  KNOWN GAPS, asserted at their measured
-    size so that they cannot grow silently: the spread of the torque about the probe axis (0.33 vs 0.18 N m; 0.09 before), and the tail of |Fx|
-    (99th percentile 53 N against 38 N: friction adds to the push of the wedge's flanks)."""
+    reset observations against the 192 reset rows decoded from the reference checkpoints (fit record profiles/r04/probe_fit.txt,
+    tests/studies/probe_fit.py).  Bands: +-30 % on the spread of Fx, Fy, Fz, torque x, torque y, +-25 % + 2 N on the binned
+    force-depth curve, +-0.2 on the fraction of rows in contact by height (new in round 4: the reference goes from no contact to contact in every row within
+    3 mm -- a blunt face; round 3's 10 mm blade, which could sink between two rows of caps, needed 8 mm).  KNOWN GAPS, asserted at their measured size so
+    that they cannot grow silently: the spread of the torque about the probe axis (0.33 N m in the reference, 0.16 here), the spread of Fz (-21 %)."""
     z, fz = obs[:, 14], obs[:, 2]
     rz, rfz = ref[:, 14], ref[:, 2]
     # onset: first contact where the eef site reaches the nominal top surface (torso centre + 0.0525 -> z_err 0.0135);
@@ -125,6 +124,10 @@ def check_reset_rows_against_reference(obs, ref):
     assert rz[rfz > 0].max() < 0.0185
     assert 0.0125 < np.quantile(z[fz > 0], 0.995) < 0.0185 and z[fz > 0].max() < 0.0200
     assert np.all(fz[z > 0.0200] == 0)
+    # fraction of rows in contact by height above the trajectory: reference 0.11 / 0.57 / 1.00 / 1.00 (here 0.14 / 0.62 / 0.82 / 0.98; round 3: 0.25 / 0.62 / 0.77 / 0.93)
+    for (lo, hi), slack in zip(((0.015, 0.018), (0.013, 0.015), (0.011, 0.013), (0.008, 0.011)), (0.15, 0.2, 0.22, 0.1)):
+        m, r = (z >= lo) & (z < hi), (rz >= lo) & (rz < hi)
+        assert r.sum() >= 6 and m.sum() >= 30 and abs((fz[m] > 0).mean() - (rfz[r] > 0).mean()) < slack, (lo, hi, (fz[m] > 0).mean(), (rfz[r] > 0).mean())
     # binned force-depth curve, including the deep rows (reference: 167 N at 15 .. 30 mm below the trajectory height)
     for lo, hi in DEPTH_BINS:
         m, r = (z >= lo) & (z < hi), (rz >= lo) & (rz < hi)
@@ -140,16 +143,16 @@ def check_reset_rows_against_reference(obs, ref):
     ratio_F, ratio_T = F.std(0) / RF.std(0), T.std(0) / RT.std(0)
     assert 0.70 < ratio_F[0] < 1.30 and 0.70 < ratio_F[1] < 1.30 and 0.70 < ratio_F[2] < 1.30, ratio_F     # Fx 13.2 N, Fy 8.4 N, Fz 38.3 N
     assert 0.70 < ratio_T[0] < 1.30 and 0.70 < ratio_T[1] < 1.30, ratio_T     # torque x 0.29, y 0.27 N m
-    assert 0.45 < ratio_T[2] < 1.30, ratio_T                                  # known gap: torque z 0.33 N m (here 0.18)
+    assert 0.40 < ratio_T[2] < 1.30, ratio_T                                  # known gap: torque z 0.33 N m (here 0.16)
     # the systematic part: the torso pushes the probe towards its centre line, x is sampled off-centre (ultrasound.py:787) => mean Fx < 0,
     # the more so the deeper; Fy has no preferred sign
-    assert -1.6 * 5.59 < F[:, 0].mean() < -0.6 * 5.59 and abs(F[:, 1].mean() - 1.96) < 1.5      # reference (-5.59, 1.96); here (-7.7, 1.6)
+    assert -1.6 * 5.59 < F[:, 0].mean() < -0.6 * 5.59 and abs(F[:, 1].mean() - 1.96) < 1.5      # reference (-5.59, 1.96); here (-6.2, 1.5)
     assert -0.80 < np.corrcoef(F[:, 0], F[:, 2])[0, 1] < -0.40                # reference -0.58
     assert abs(F[:, 2].mean() - RF[:, 2].mean()) < 0.2 * RF[:, 2].mean()
     lat, rlat = np.hypot(F[:, 0], F[:, 1]) / F[:, 2], np.hypot(RF[:, 0], RF[:, 1]) / RF[:, 2]
     assert 0.75 < np.median(lat) / np.median(rlat) < 1.25                     # reference 0.38
     q99, rq99 = np.quantile(np.abs(F[:, :2]), 0.99, axis=0), np.quantile(np.abs(RF[:, :2]), 0.99, axis=0)
-    assert 0.7 < q99[0] / rq99[0] < 1.55 and 0.7 < q99[1] / rq99[1] < 1.4     # lateral |Fx| up to 35-44 N (known excess: 1.42), |Fy| up to 27 N
+    assert 0.7 < q99[0] / rq99[0] < 1.35 and 0.7 < q99[1] / rq99[1] < 1.3     # lateral |Fx| up to 38 N (here 42; round 3's blade: 53), |Fy| up to 27 N (22)
     # (not pinned: the torque channels WITHOUT contact, reference (0.091, -0.033, -0.007) N m at reset while the arm sags under zero control;
     #  the stand-in centre of mass of the probe is chosen for the torque under the tracking policy instead)
 
