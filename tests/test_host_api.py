@@ -154,7 +154,7 @@ def test_config_of_another_layout_is_refused_before_any_write(usim):
     h = C.c_void_p()
     assert lib.usim_create(C.byref(cfg), 4, 0, C.byref(h)) == -1 and not h
     cfg = usim.make_config()
-    cfg.probe_height = 0.03                                       # hull of the two capsules degenerates: height <= |r2 - r1|
+    cfg.probe_height = 0.01                                       # hull of the two capsules degenerates: height <= |r2 - r1| (14 mm at the defaults)
     assert lib.usim_create(C.byref(cfg), 4, 0, C.byref(h)) == -1 and not h
 
 
