@@ -109,6 +109,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL / device-tensor sharing across processes on this image); set before torch loads HIP
     import torch
     import torch.distributed as dist
     # USIM_BENCH_STUB=<module in tests/>: the N > 1 plumbing of this file (self-launch, rendezvous, sharding by env_offset, the gather of every block,

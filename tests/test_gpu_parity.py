@@ -226,6 +226,14 @@ def test_domain_randomisation_config5_full_size_8192_envs(usim):
     _run_parity(usim, 8192, 200, "soft", "tracking", omp=True, friction_randomization=1, elem_friction=0.0, probe_friction=0.3)
 
 
+@pytest.mark.parametrize("extra", [dict(probe_halfwidth=0.006, probe_tip=0.0015, probe_radius=0.012, probe_halflen=0.015), dict(torso_drop=1), dict(torso_drop=2), dict(pgs_iters=8)],
+                         ids=["flat-face-and-tip-offset", "spawn-fall", "settled-low", "eight-sweeps"])
+def test_round4_model_options_parity(usim, extra):
+    """The options round 4 added, through the full parity check: a probe face with a flat strip and a tip below the site (probe_sdf's sideways sweep and offset, the
+    wider broad phase), the torso base following the 4.7 mm free fall of rounds 1-3 or resting one gap lower (usim_config.torso_drop), more solver sweeps."""
+    _run_parity(usim, 256, 200, "soft", "tracking", **extra)
+
+
 def test_cylinder_torso_parity(usim):
     """use_box_torso=False (soft_human_torso.xml): elliptic cross-section, y_range 0.05, trajectory 0.041 above the centre"""
     n = 128
