@@ -226,7 +226,7 @@ def test_domain_randomisation_config5_full_size_8192_envs(usim):
     _run_parity(usim, 8192, 200, "soft", "tracking", omp=True, friction_randomization=1, elem_friction=0.0, probe_friction=0.3)
 
 
-@pytest.mark.parametrize("extra", [dict(probe_halfwidth=0.006, probe_tip=0.0015, probe_radius=0.012, probe_halflen=0.015), dict(torso_drop=1), dict(torso_drop=2), dict(pgs_iters=8)],
+@pytest.mark.parametrize("extra", [dict(probe_halfwidth=0.006, probe_tip=0.0015, probe_radius=0.018, probe_halflen=0.015), dict(torso_drop=1), dict(torso_drop=2), dict(pgs_iters=8)],
                          ids=["flat-face-and-tip-offset", "spawn-fall", "settled-low", "eight-sweeps"])
 def test_round4_model_options_parity(usim, extra):
     """The options round 4 added, through the full parity check: a probe face with a flat strip and a tip below the site (probe_sdf's sideways sweep and offset, the
