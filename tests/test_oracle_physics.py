@@ -291,7 +291,8 @@ def test_contact_solver_rests_at_the_optimum_of_the_convex_problem():
         return np.abs(d.step(act, auto_reset=False)[0][live, :3] - want).max(1)
     e = error(pgs_iters=30)
     assert e.max() < 1e-6, e.max()
-    for iters, typical, q99, worst in ((4, 3e-2, 0.8, 2.0), (8, 1e-4, 6e-2, 0.3), (16, 1e-9, 3e-4, 2e-3)):
+    # (10 sweeps: the bar the round-3 review set for a converged solve -- 99 % within 1e-2 N, worst within 5e-2 N)
+    for iters, typical, q99, worst in ((4, 3e-2, 0.8, 2.0), (8, 1e-4, 6e-2, 0.3), (10, 1e-5, 1e-2, 5e-2), (16, 1e-9, 3e-4, 2e-3)):
         e = error(pgs_iters=iters)
         assert np.median(e) < typical and np.quantile(e, 0.99) < q99 and e.max() < worst, (iters, np.median(e), np.quantile(e, 0.99), e.max())
     old = error(cone_solver=0, pgs_iters=300)
