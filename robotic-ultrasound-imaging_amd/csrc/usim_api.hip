@@ -240,8 +240,9 @@ static int launch(usim_handle* h, DevIO io, int flags, long long rstep, hipStrea
     // 16 lanes per environment: the kernels with the distributed arm mathematics (usim_step16.h); the 8-lane / one-lane mappings run the
     // kernels of usim_kernels.hip
     if (h->lpe == 64 && MODE == 0) {
-        // split kernel with 8-lane groups: 32 environments per workgroup
-        dim3 grid((h->n + 31) / 32), block(512);
+        // split kernel with 8-lane groups: 32 environments per workgroup (8 per wave pair)
+        constexpr int EPB8 = 8 * wpr<8>();
+        dim3 grid((h->n + EPB8 - 1) / EPB8), block(128 * wpr<8>());
         if (io.nsub > 1 || h->C.substeps > 1) hipLaunchKernelGGL((usim_step32_kernel<true, 8>), grid, block, h->lds64_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
         else hipLaunchKernelGGL((usim_step32_kernel<false, 8>), grid, block, h->lds64_bytes, s, h->M, h->C, h->state, h->n, h->npad, io, flags, rstep);
         e = hipGetLastError();

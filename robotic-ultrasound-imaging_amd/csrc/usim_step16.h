@@ -245,7 +245,10 @@ constexpr int X16_RIGID_STRIDE = 84;                  // rigid-torso launches: o
 #ifndef USIM_ROLE_FLIP_BIT
 #define USIM_ROLE_FLIP_BIT -1
 #endif
-template <int G> constexpr int wpr() { return G == 16 ? USIM_WPR16 : 4; }
+#ifndef USIM_WPR8
+#define USIM_WPR8 4
+#endif
+template <int G> constexpr int wpr() { return G == 16 ? USIM_WPR16 : USIM_WPR8; }
 template <int G> constexpr int x2_base() { return TB_WORDS + (64 * wpr<G>() / G) * GE_STRIDE; }
 // 64 transpose scratch | 12 pose (+ the arm side's hit count in word 9) | 64 op-space (6 x 8 Lambda^-1, alpha 6, vs 6) | 16 wrench + contacts | the arm side's contact records
 // 16-lane groups: 64 transpose scratch | 12 pose | 64 op-space | 16 wrench + contacts | 17 x 8 arm-side contact records | 100 queue.
