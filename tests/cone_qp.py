@@ -71,3 +71,20 @@ def kkt_residual(P, f):
 
 def net_force(P, f):
     return (P["W"].T @ f)[:3]
+
+
+def primal_force(y, R, mu):
+    """MuJoCo's primal view of one elliptic-cone contact [RESTATED: MuJoCo documentation, "Computation / Friction cones"]: the force as a function of the
+    constraint-space acceleration y = J a - a_ref, f(y) = argmin_{f in K} 1/2 f'R f + f'y, in closed form by the three zones of the cone in R-scaled
+    coordinates -- top (f = 0), bottom (inside the cone: f = -R^-1 y), middle (on its surface).  R = (Rn, Rt, Rt).  Returns (force, zone)."""
+    Rn, Rt = R[0], R[1]
+    mt = mu * np.sqrt(Rt / Rn)                                  # cone slope in the scaled coordinates
+    yn, yt = -y[0] / np.sqrt(Rn), -y[1:] / np.sqrt(Rt)
+    T = np.linalg.norm(yt)
+    if T <= mt * yn:
+        return np.array([yn / np.sqrt(Rn), yt[0] / np.sqrt(Rt), yt[1] / np.sqrt(Rt)]), "bottom"
+    if mt * T <= -yn:
+        return np.zeros(3), "top"
+    p = (yn + mt * T) / (1 + mt * mt)
+    e = yt / T
+    return np.array([p, mt * p * e[0], mt * p * e[1]]) / np.sqrt(R), "middle"

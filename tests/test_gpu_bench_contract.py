@@ -37,6 +37,10 @@ def test_bench_json_contract_default_workload():
     assert rf["algorithmic_bytes_per_launch"] == 1912 * 4096 * rf["steps_per_launch"] and 1 <= rf["steps_per_launch"] <= 64
     assert abs(rf["avg_launch_us"] - rf["avg_kernel_us"] * rf["steps_per_launch"]) < 1e-6 * rf["avg_launch_us"]
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / rf["avg_launch_us"] * 1e-3) < 1e-6 * rf["achieved"]
+    assert out["ranks_seen"] == 1 and out["gather"] is None and out["config"]["domain_randomisation"] == "stiffness+damping"
+    iss = rf["issue"]                                      # measured issue figures of the committed PMC profile (profiles/<round>/issue.json), not a flop guess
+    assert iss is None or (1e3 < iss["valu_inst_per_wave_step"] < 1e4 and 0 < iss["valu_active_share_of_wave_cycles"] < 1)
+    assert "valu_frac" not in rf
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "env-steps/s" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
 

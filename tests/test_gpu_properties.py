@@ -424,3 +424,33 @@ def test_split_kernel_roles_execute_the_same_number_of_barriers(usim, tmp_path):
     assert len(rows) == 9
     for n, k, arm, lat in rows:
         assert arm == lat == 5, (n, k, arm, lat)                  # table copy + hand-offs (1)-(4)
+
+
+def test_kernel_contact_forces_rest_at_the_optimum_of_the_convex_problem(usim):
+    """The kernels' contact solve, run to convergence (pgs_iters = 30), against the optimum of the convex contact problem computed by the independent solver of
+    tests/cone_qp.py from the dual problem the oracle exports at the same state: the HIP iteration rests where MuJoCo's Newton solver would (to float32), and at
+    the default it is as far from that point as the oracle's own iteration (tests/test_oracle_physics.py)."""
+    from oracle_lib import Oracle
+    from cone_qp import dual_problem, solve_exact, net_force
+    n, pre = 128, 8
+    ora = Oracle(n, pgs_iters=30); ora.reset()
+    for k in range(pre):
+        ora.step(ora.random_actions(k))
+    st, act = ora.get_state(), ora.random_actions(pre)
+    probs = [dual_problem(ora, i, act[i]) for i in range(n)]
+    live = [i for i, p in enumerate(probs) if p is not None]
+    want = np.array([net_force(probs[i], solve_exact(probs[i])) for i in live])
+    errs = {}
+    for iters in (30, 4):
+        env = _env(usim, n, pgs_iters=iters)
+        env.reset()
+        g = env.get_state()
+        for key in ("q", "qd", "q0", "traj_start", "traj_end", "u0", "vbar", "fzbar", "fzprev", "dfz", "stiffness", "damping", "mu", "t", "has_touched", "episode", "ep_return", "status", "s", "sd"):
+            g[key] = st[key]
+        env.set_state(g)
+        obs, *_ = env.step(act.astype(np.float32))
+        errs[iters] = np.abs(obs[live, :3] - want).max(1)
+        env.close()
+    assert len(live) > 60 and np.abs(want).max() > 30
+    assert np.quantile(errs[30], 0.99) < 5e-3 and errs[30].max() < 2e-2, (np.quantile(errs[30], 0.99), errs[30].max())       # float32 kinematics: ~1e-3 N on forces of up to 100 N
+    assert 1e-3 < np.median(errs[4]) < 0.1 and np.quantile(errs[4], 0.99) < 1.5, (np.median(errs[4]), np.quantile(errs[4], 0.99))

@@ -310,6 +310,40 @@ def test_contact_solver_rests_at_the_optimum_of_the_convex_problem():
         assert np.abs(d.step(act1, auto_reset=False)[0][live1, :3] - want1).max() < bound, cfg
 
 
+def test_dual_optimum_satisfies_mujocos_primal_force_law():
+    """The same optimum seen from MuJoCo's side of the duality: MuJoCo's Newton solver works on the PRIMAL problem, where every contact's force is a closed-form
+    function of its constraint-space acceleration, f = f(J a - a_ref), with three zones of the elliptic cone in R-scaled coordinates (tests/cone_qp.py
+    primal_force).  At the oracle's converged contact forces f*, the accelerations they produce, y = A f* + b, must give back f* through that law, contact by
+    contact, and the three zones must all occur (sliding contacts dominate under random gains)."""
+    from cone_qp import dual_problem, primal_force
+    n, pre = 96, 8
+    o = Oracle(n, pgs_iters=60); o.reset()
+    for k in range(pre):
+        o.step(o.random_actions(k))
+    act = o.random_actions(pre)
+    zones = {"top": 0, "middle": 0, "bottom": 0}
+    worst = 0.0
+    for i in range(n):
+        P = dual_problem(o, i, act[i])
+        if P is None:
+            continue
+        dbg = np.zeros(8 * 8)
+        import ctypes as C
+        from oracle_lib import _ptr
+        o.lib.uso_debug_contacts.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        a = np.ascontiguousarray(act[i], dtype=np.float64)
+        nc = o.lib.uso_debug_contacts(o.h, i, _ptr(a), _ptr(dbg))
+        assert nc == P["nc"]
+        f = dbg.reshape(8, 8)[:nc, 5:8].reshape(-1)                   # the oracle's contact-frame forces (normal, t1, t2) of the same forward pass
+        y = P["A"] @ f + P["b"]
+        for c in range(nc):
+            fc, z = primal_force(y[3 * c:3 * c + 3], P["R"][3 * c:3 * c + 3], P["mu"])
+            zones[z] += 1
+            worst = max(worst, np.abs(fc - f[3 * c:3 * c + 3]).max())
+    assert worst < 1e-6, worst
+    assert zones["middle"] > 50 and zones["top"] > 5 and zones["bottom"] >= 1, zones
+
+
 def test_explicit_pair_of_coincident_contacts_against_the_merged_contact():
     """probe_geoms = 2 restates the two coincident contacts of a probe-element pair (mu 0.01 and 1.0) as ONE contact with half the normal regulariser and the mean
     friction coefficient.  The oracle can also solve them as two contacts (study switch pair_model = 1): the net contact force of the merged model stays within
