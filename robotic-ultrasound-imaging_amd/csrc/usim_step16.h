@@ -343,7 +343,12 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
 #define EB(off) lds[TB_WORDS + eb * GE_STRIDE + (off)]
 #define BK(slot, f) st[(size_t)io.bank_row0 * npad + ((size_t)ei * BANK_DEPTH + (slot)) * BANK_STRIDE + (f)]
 #define BKI(slot, f) (reinterpret_cast<int*>(st))[(size_t)io.bank_row0 * npad + ((size_t)ei * BANK_DEPTH + (slot)) * BANK_STRIDE + (f)]
-    float* const xl = (ROLE != 0) ? &lds[X2_BASE + eb * X2_STRIDE]
+    // The mailbox block sits beyond the 64 KB an LDS instruction's immediate offset reaches.  Left to itself the compiler forms one address register per mailbox WORD
+    // (block + constant, hoisted out of the step loop) and spills them around the contact solve: 74 registers, two scratch round trips per step in the resident
+    // kernel.  The block's offset is therefore made opaque: one address register, the words at immediate offsets from it.
+    int mbo = X2_BASE + eb * X2_STRIDE;
+    if constexpr (ROLE != 0) asm volatile("" : "+v"(mbo));
+    float* const xl = (ROLE != 0) ? &lds[mbo]
                                   : (TORSO ? &lds[TB_WORDS + eb * GE_STRIDE + GE_WS] : &lds[eb * X16_RIGID_STRIDE]);   // transpose scratch of this environment
     static_assert(GE_WS + X16_WORDS <= GE_STRIDE, "transpose scratch overlays the wrench records");
     // `fixed`-mode goal held across physics substeps: split kernel -- in the mailbox block; single wave, soft torso -- the last 12 words of the environment's
@@ -414,7 +419,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         for (int i = 0; i < NE; ++i) { const int e = gl + i * G; s_pre[i] = (e < N_TOP) ? EB(GE_S + e) : 0.f; }
     } else if constexpr (RES && ROLE == 2) {
         // resident launch, lattice side: the arm side reports a new episode (lattice at rest, its parameters, t = 0) through the mailbox
-        const float4 nx = *reinterpret_cast<const float4*>(&lds[X2_BASE + eb * X2_STRIDE + MB_W]);
+        const float4 nx = *reinterpret_cast<const float4*>(&lds[mbo + MB_W]);
         if (nx.w != 0.f) {
             kst = nx.x; kdmp = nx.y; mu = nx.z; t = 0;
 #pragma unroll
@@ -430,10 +435,12 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         float4* dst = reinterpret_cast<float4*>(lds);
         constexpr int NV = TB_WORDS / 4, PER = (NV + NT - 1) / NT;
         float4 tmp[PER];
+        int tix = threadIdx.x;
+        asm volatile("" : "+v"(tix));                                   // (keeps the copy's addresses from being formed ahead of the step loop and carried, spilled, through every step)
 #pragma unroll
-        for (int i = 0; i < PER; ++i) { int idx = threadIdx.x + i * NT; tmp[i] = (idx < NV) ? src[idx] : make_float4(0, 0, 0, 0); }
+        for (int i = 0; i < PER; ++i) { int idx = tix + i * NT; tmp[i] = (idx < NV) ? src[idx] : make_float4(0, 0, 0, 0); }
 #pragma unroll
-        for (int i = 0; i < PER; ++i) { int idx = threadIdx.x + i * NT; if (idx < NV) dst[idx] = tmp[i]; }
+        for (int i = 0; i < PER; ++i) { int idx = tix + i * NT; if (idx < NV) dst[idx] = tmp[i]; }
         USIM_BAR();
     }
     USIM_STAMP(dbg, 1);
@@ -451,10 +458,11 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
 #else
 #define RSTAMP(k) do { } while (0)
 #endif
+#define XSTAMP(k) RSTAMP(20 + (k))                                  /* lattice side only: dbg[50 ..] */
     if constexpr (ROLE == 2) {
         // ================= lattice / contact side of the split kernel =================
         RSTAMP(0);
-        float* const mb = &lds[X2_BASE + eb * X2_STRIDE];
+        float* const mb = &lds[mbo];
         const int* tb_shell = reinterpret_cast<const int*>(lds + TB_SHELL);
         const int tsim = tphys;
         float dz, vz, az;
@@ -531,12 +539,14 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         int overflow = 0;
         if (nc > MAXC) { overflow = 1; nc = MAXC; }
         if constexpr (!EARLY) group_sync();
+        XSTAMP(0);
         int ncmax = 0;
         if constexpr (EARLY) { nc = nc_early; overflow = overflow_early; ncmax = ncmax_early; }
         else {
 #pragma unroll
             for (int k = MAXC; k >= 1; --k) if (ncmax == 0 && __any(nc >= k)) ncmax = k;
         }
+        XSTAMP(1);
         float gf[MAXC], W[6] = {0, 0, 0, 0, 0, 0};
         int cel[MAXC];
 #pragma unroll
@@ -549,7 +559,9 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
 #pragma unroll
                 for (int b = 0; b <= a; ++b) Lp[PK(a, b)] = mb[MB_OP + a * 8 + b];
             }
+            XSTAMP(2);
             contact_solve<G, EARLY>(lds, eb, gl, M, C, nc, ncmax, cel, Lp, alpha, vs, mu, vz, P, W, gf, dbg);
+            XSTAMP(3);
         }
         if (gl == 0) {
             *reinterpret_cast<float4*>(&mb[MB_W]) = make_float4(W[0], W[1], W[2], W[3]);
@@ -1254,6 +1266,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
     USIM_STAMP(dbg, 16);
     if constexpr (ROLE == 1) RSTAMP(9);
 #undef RSTAMP
+#undef XSTAMP
 #undef LAT
 #undef EB
 #undef BK

@@ -223,7 +223,7 @@ class UltrasoundVecEnv:
                 prev = t[k]
         return out
 
-    def profile_step_raw(self, step, n=48):
+    def profile_step_raw(self, step, n=64):
         """Diagnostics (profiling build): the raw shader-clock stamps of one step (see usim_profile_step in csrc/usim_api.hip)."""
         ticks = (C.c_uint64 * n)()
         self._check(self.lib.usim_profile_step(self._handle, C.byref(self._io), int(step), ticks, n))

@@ -23,6 +23,9 @@ for base, names, title in ((20, names_a, "arm wave"), (30, names_b, "lattice wav
     for i, nm in enumerate(names):
         v = rows[:, base + i] - t0[:, 0]
         print(f"   {nm:36s} {np.median(v):9.0f}")
+print(f"   (contact_solve entered at {np.median(rows[:, 40] - t0[:, 0]):.0f}, left at {np.median(rows[:, 44] - t0[:, 0]):.0f}: median ticks since the step's start; ncmax of this quad varies)")
+for i, nm in enumerate(["list merged", "ncmax known", "before contact_solve", "after contact_solve"]):
+    print(f"   x{i} {nm:32s} {np.median(rows[:, 50 + i] - t0[:, 0]):9.0f}")
 print("== contact solve of the lattice wave (ticks since its start)")
 c0 = rows[:, 40:41]
 for i, nm in enumerate(["start", "contact rows done", "Delassus blocks done", "sweeps done", "wrench done"]):
