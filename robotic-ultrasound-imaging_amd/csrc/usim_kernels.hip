@@ -756,23 +756,25 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
                 // (2) friction on the disc |t| <= mu n0
                 const float lim = mu * n0;
                 const bool haslim = lim > 0.f;
-                const float ilim = haslim ? rcp_(lim) : 0.f;
                 const float q1 = r1 - fmaf(b12, n2, b11 * n1), q2 = r2 - fmaf(b22, n2, b12 * n1);
+                // In adjugate form, a = adj(B_tt + lambda I) r~ and t = -a / det: the Newton step (|t| / lim - 1) |t|^2 / (t'(B_tt + lambda I)^-1 t) is
+                // (|a| - det lim) |a|^2 / (lim a'adj a) -- no inverse determinant, two transcendentals instead of four -- and the clamped minimiser -a min(1 / det, lim / |a|).
                 float lam = lamc;
-                float m11 = b11 + lam, m22 = b22 + lam, idet = rcp_(fmaf(m11, m22, -(b12 * b12)));
-                float t1 = -fmaf(m22, q1, -(b12 * q2)) * idet, t2 = -fmaf(m11, q2, -(b12 * q1)) * idet;
+                float m11 = b11 + lam, m22 = b22 + lam, det = fmaf(m11, m22, -(b12 * b12));
+                float a1 = fmaf(m22, q1, -(b12 * q2)), a2 = fmaf(m11, q2, -(b12 * q1));
                 {
-                    const float tt = fmaf(t1, t1, t2 * t2);
-                    const float qd = fmaf(m11 * t2, t2, fmaf(m22 * t1, t1, -2.f * b12 * t1 * t2)) * idet;
-                    const float tn = tt * rsq_(fmaxf(tt, 1e-30f));
-                    lam = fmaxf(fmaf(fmaf(tn, ilim, -1.f) * tt, rcp_(fmaxf(qd, 1e-30f)), lam), 0.f);
+                    const float aa = fmaf(a1, a1, a2 * a2);
+                    const float aAa = fmaf(m11 * a2, a2, fmaf(m22 * a1, a1, -2.f * b12 * a1 * a2));
+                    const float an = aa * rsq_(fmaxf(aa, 1e-30f));
+                    lam = fmaxf(fmaf(fmaf(-det, lim, an) * aa, rcp_(fmaxf(lim * aAa, 1e-30f)), lam), 0.f);
                 }
-                m11 = b11 + lam; m22 = b22 + lam; idet = rcp_(fmaf(m11, m22, -(b12 * b12)));
-                t1 = -fmaf(m22, q1, -(b12 * q2)) * idet; t2 = -fmaf(m11, q2, -(b12 * q1)) * idet;
+                m11 = b11 + lam; m22 = b22 + lam; det = fmaf(m11, m22, -(b12 * b12));
+                a1 = fmaf(m22, q1, -(b12 * q2)); a2 = fmaf(m11, q2, -(b12 * q1));
+                float t1, t2;
                 {
-                    const float tt = fmaf(t1, t1, t2 * t2);
-                    const float sc = haslim ? fminf(lim * rsq_(tt), 1.0f) : 0.f;     // lim / |t| where that is below one (v_min keeps the number when tt = 0 makes the product inf or NaN)
-                    t1 *= sc; t2 *= sc;
+                    const float aa = fmaf(a1, a1, a2 * a2);
+                    const float sc = -fminf(lim * rsq_(aa), rcp_(det));     // (v_min keeps the number when aa = 0 makes the product inf or NaN)
+                    t1 = haslim ? a1 * sc : 0.f; t2 = haslim ? a2 * sc : 0.f;   // (no cone, no friction: lambda and a may be anything there)
                 }
                 const bool mine = gl == k;
                 float d0 = (mine && own) ? n0 - f[0] : 0.f, d1 = (mine && own) ? t1 - f[1] : 0.f, d2 = (mine && own) ? t2 - f[2] : 0.f;
