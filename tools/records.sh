@@ -5,19 +5,24 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 G=$ROOT/gpurun_out; mkdir -p "$G"
 cd "$ROOT"
 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -3 > "$G/${TAG}_gputests.txt"
+# counters first: bench.py quotes profiles/<tag>/traffic.json and issue.json in its roofline object, so they are made from this box's passes before any bench line is recorded
+tools/profile.sh ${TAG}_soft > /dev/null 2>&1
+tools/profile.sh ${TAG}_rigid --workload rigid > /dev/null 2>&1
+mkdir -p profiles/$TAG
+python3 tools/make_traffic.py $G/prof_${TAG}_soft $G/prof_${TAG}_rigid 64 profiles/$TAG/issue.json > profiles/$TAG/traffic.json
+cp profiles/$TAG/traffic.json "$G/${TAG}_traffic.json"; cp profiles/$TAG/issue.json "$G/${TAG}_issue.json"
 tools/bench_matrix.sh > /dev/null
 python3 bench.py > "$G/${TAG}_bench_soft.json" 2> /dev/null
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$G/${TAG}_bench_driver.json" 2> /dev/null
 python3 bench.py --workload rigid --no-cpu-baseline > "$G/${TAG}_bench_rigid.json" 2> /dev/null
 python3 bench.py --envs-per-gpu 8192 --randomize --steps 1000 --warmup 100 --no-cpu-baseline > "$G/${TAG}_bench_config5.json" 2> /dev/null
-tools/profile.sh ${TAG}_soft > /dev/null 2>&1
-tools/profile.sh ${TAG}_rigid --workload rigid > /dev/null 2>&1
 tools/stats_only.sh ${TAG}_config5 --envs-per-gpu 8192 --randomize > /dev/null 2>&1
 tools/stats_only.sh ${TAG}_soft_spl1 --steps-per-launch 1 > /dev/null 2>&1
 python3 tools/split_timeline.py 200 4096 32 > "$G/${TAG}_timeline.txt" 2>&1
 USIM_PROFILE_NSUB=16 python3 tools/split_timeline.py 200 4096 32 > "$G/${TAG}_timeline_multi.txt" 2>&1
 USIM_PROFILE_NSUB=16 python3 tools/split_timeline.py 200 8192 64 > "$G/${TAG}_timeline_g8.txt" 2>&1
 python3 tests/studies/gpu_parity_fullsize.py > "$G/${TAG}_parity_fullsize.txt" 2>&1
+{ python3 tests/studies/parity_report.py 256; python3 tests/studies/parity_report.py 4096 tracking,wrench; } 2>&1 | grep -v amdgpu.ids > "$G/${TAG}_parity_report.txt"
 for m in tracking variable_z wrench; do python3 tools/gpu_policy_replay.py $m 2>&1 | grep -v amdgpu.ids; done > "$G/${TAG}_policy_replay.txt"
 python3 tools/replay_medians.py 1024 3000 2>&1 | grep -v amdgpu.ids > "$G/${TAG}_replay_medians.txt"
 python3 tools/collector_probe.py 4096 128 5 2>&1 | grep -v amdgpu.ids > "$G/${TAG}_collector_probe.txt"

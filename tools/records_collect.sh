@@ -12,5 +12,5 @@ cp $G/${TAG}_timeline.txt $P/timeline_split_soft.txt; cp $G/${TAG}_timeline_mult
 cp $G/${TAG}_parity_fullsize.txt $P/parity_fullsize.txt; cp $G/${TAG}_parity_report.txt $P/parity_report.txt
 cp $G/${TAG}_policy_replay.txt $P/policy_replay.txt; cp $G/${TAG}_replay_medians.txt $P/replay_medians.txt; cp $G/${TAG}_collector_probe.txt $P/collector_probe.txt
 cp $G/${TAG}_prof_collector.txt $P/rocprofv3_fused_collector_4096_summary.txt; cp $G/${TAG}_ppo_fused.txt $P/ppo_demo_fused_collector.txt; cp $G/${TAG}_soak.txt $P/soak.txt
-python3 tools/make_traffic.py $G/prof_${TAG}_soft $G/prof_${TAG}_rigid 64 $P/issue.json > $P/traffic.json
+cp $G/${TAG}_traffic.json $P/traffic.json; cp $G/${TAG}_issue.json $P/issue.json      # made on the box by tools/records.sh, before the bench lines that quote them
 ls -la $P
