@@ -217,7 +217,13 @@ typedef struct usim_policy_net {               /* stable_baselines3 ActorCriticP
     const float *vf_w1, *vf_b1, *vf_w2, *vf_b2;        /* mlp_extractor.value_net */
     const float *val_w, *val_b;                        /* value_net: [1][128], [1] */
     const float* log_std;                              /* [A] */
+    const float* w2_packed;                            /* REQUIRED: USIM_POLICY_PACKED floats filled by usim_policy_pack from pi_w2 / vf_w2 as they are NOW -- the two layer-2
+                                                        * matrices in the order the matrix-core operands are consumed, every word split into two float16 (hi + lo: layer 2 runs
+                                                        * as three float16 products with float32 accumulation, 2^-22 relative).  Pack again after every change of the weights
+                                                        * (policy.FusedRollout: before every eager launch, and as the first policy node of a recorded rollout) */
 } usim_policy_net;
+#define USIM_POLICY_PACKED (2 * 128 * 256)
+int usim_policy_pack(const usim_policy_net* net, float* packed_dev, void* stream);
 
 typedef struct usim_norm_stats {               /* stable_baselines3 VecNormalize (src/rl.py:140,177-184): RunningMeanStd of observations and of discounted returns */
     double *obs_mean, *obs_var, *obs_count;            /* [19], [19], scalar -- updated in place when training */

@@ -13,6 +13,7 @@ LIB_PATH = PKG_DIR / "lib" / "libusim.so"
 OBS_DIM = 19
 MAXC = 8
 NSCALAR = 40
+POLICY_PACKED = 2 * 128 * 256      # USIM_POLICY_PACKED
 RESET_PARAMS = 13
 LOG_WIDTH = 53
 
@@ -42,7 +43,7 @@ class UsimStepIO(C.Structure):
 
 class UsimPolicyNet(C.Structure):
     """struct usim_policy_net (include/usim.h): device pointers to the MlpPolicy parameters"""
-    _fields_ = [(n, C.c_void_p) for n in ("pi_w1", "pi_b1", "pi_w2", "pi_b2", "act_w", "act_b", "vf_w1", "vf_b1", "vf_w2", "vf_b2", "val_w", "val_b", "log_std")]
+    _fields_ = [(n, C.c_void_p) for n in ("pi_w1", "pi_b1", "pi_w2", "pi_b2", "act_w", "act_b", "vf_w1", "vf_b1", "vf_w2", "vf_b2", "val_w", "val_b", "log_std", "w2_packed")]
 
 
 class UsimNormStats(C.Structure):
@@ -66,6 +67,7 @@ class UsimPolicyFused(C.Structure):
 SYMBOLS = {
     "usim_policy_step_fused": (C.c_int, [C.POINTER(UsimPolicyNet), C.POINTER(UsimNormStats), C.POINTER(UsimPolicyFused), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.POINTER(UsimPolicyOut), C.c_void_p]),
+    "usim_policy_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "usim_policy_step": (C.c_int, [C.POINTER(UsimPolicyNet), C.POINTER(UsimNormStats), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_uint64, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(UsimPolicyOut), C.c_void_p]),
     "usim_policy_reward": (C.c_int, [C.POINTER(UsimNormStats), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -29,6 +29,7 @@ struct PolicyNet {                                       // torch.nn.Linear layo
     const float *pi_w1, *pi_b1, *pi_w2, *pi_b2, *act_w, *act_b;      // policy_net (19 -> 256 -> 128, tanh), action_net (128 -> A)
     const float *vf_w1, *vf_b1, *vf_w2, *vf_b2, *val_w, *val_b;      // value_net_body, value_net (128 -> 1)
     const float* log_std;                                             // [A]
+    const float4* w2_packed;                                          // layer-2 weights of both networks in operand order (usim_policy_pack), or nullptr
 };
 struct NormStats {                                       // policy.DeviceVecNormalize: float64 tensors, updated in place
     double *obs_mean, *obs_var, *obs_count;              // [19], [19], scalar
@@ -119,6 +120,9 @@ __global__ __launch_bounds__(PL_ST) void usim_policy_obs_stats_kernel(const floa
 }
 
 typedef float v4f_ __attribute__((ext_vector_type(4)));
+typedef _Float16 v4h_ __attribute__((ext_vector_type(4)));
+// float32 as the sum of two float16 words (hi = round(x), lo = round(x - hi)): x = hi + lo to 2^-22 |x| (down to the float16 subnormal step, 6e-8, for small x)
+DI void split_h(const float x, _Float16& hi, _Float16& lo) { hi = (_Float16)x; lo = (_Float16)(x - (float)hi); }
 // tanh(x) = 1 - 2 / (exp(2x) + 1): v_exp_f32 + v_rcp_f32 (absolute error ~1e-7; saturates to +-1 through exp -> inf / 0), a tenth of the library routine
 DI float tanh_(float x) { const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f); return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f); }
 
@@ -140,6 +144,26 @@ DI float tanh_(float x) { const float e = __builtin_amdgcn_exp2f(x * 2.885390081
 // AFTER the wait, so nobody can read them half-updated.  The grid is at most 2 x 256 workgroups of which two fit a CU (LDS 76 KB, 4 waves): all are
 // resident, which the wait relies on; it is bounded all the same (a status word is raised and the kernel carries on with whatever rows it sees rather than
 // hang).  Measured alternative: every workgroup reducing the whole batch by itself (no wait) -- 256 x 311 KB through L2 cost 20-27 us per launch.
+// Layer-2 weights in operand order.  torch.nn.Linear stores weight[out][in]: the sixteen columns of a matrix-core operand are sixteen rows 1 KB apart, so a wave's
+// 16-byte operand reads touch sixteen cache lines per instruction (3 of the kernel's 16 us at 4096 environments: rocprofv3 with the reads cut out).  usim_policy_pack
+// rewrites the two matrices once per weight update as [network][wave][column tile][k step][lane] float4 -- the word lane (lr, lg) of wave w consumes at step s --
+// and the policy kernel then reads 1 KB contiguous per instruction.  The words are stored SPLIT, each float32 as two float16 (split_h): layer 2 then runs as three
+// float16 matrix-core products per tile -- hi hi + hi lo + lo hi, float32 accumulate, 2^-22 relative per product against 2^-24 -- at 8 cycles per 16 x 16 x 16
+// instead of four float32 instructions of 32 cycles each: 3.7 us of the launch become 0.8.
+DI int pl_packed_index(int net, int wave, int tile, int s, int lane) { return (((net * 4 + wave) * 2 + tile) * (PL_H1 / 16) + s) * 64 + lane; }
+__global__ __launch_bounds__(256) void usim_policy_pack_kernel(const float* __restrict__ pi_w2, const float* __restrict__ vf_w2, float4* __restrict__ packed) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;                    // one float4 per thread: 2 * 4 * 2 * 16 * 64 = 16384
+    if (idx >= 2 * 4 * 2 * (PL_H1 / 16) * 64) return;
+    const int lane = idx & 63, s = (idx >> 6) & 15, tile = (idx >> 10) & 1, wave = (idx >> 11) & 3, net = idx >> 13;
+    const int lr = lane & 15, lg = lane >> 4, col = (wave * 2 + tile) * 16 + lr, k = 16 * s + 4 * lg;
+    const float4 w = *reinterpret_cast<const float4*>(&(net ? vf_w2 : pi_w2)[col * PL_H1 + k]);
+    union { struct { v4h_ hi, lo; } h; float4 f; } u;                  // the four words' high parts, then their low parts: 16 bytes, as before
+    _Float16 a, b;
+    split_h(w.x, a, b); u.h.hi[0] = a; u.h.lo[0] = b; split_h(w.y, a, b); u.h.hi[1] = a; u.h.lo[1] = b;
+    split_h(w.z, a, b); u.h.hi[2] = a; u.h.lo[2] = b; split_h(w.w, a, b); u.h.hi[3] = a; u.h.lo[3] = b;
+    packed[idx] = u.f;
+}
+
 constexpr int PL_ROW = 48, PL_SG = 13;                          // doubles per workspace row (38 observation moments, 3 reward moments); segments of the final sum
 constexpr unsigned PL_SPIN = 1u << 17;                             // polls before a wait gives up (~0.1 s; a wait that succeeds takes 5-10 us)
 struct FusedArgs {
@@ -147,7 +171,7 @@ struct FusedArgs {
     double* work;                                                // [gridDim.x][PL_ROW] rows, then 2 gridDim.x arrival flags + a status word (32-bit words)
     int update_obs, have_prev, norm_reward;
 };
-struct FusedLds { double mean[PL_OBS], var[PL_OBS]; double scale; };             // (the raw observations sit where their normalised values go; the partial sums borrow h2)
+struct FusedLds { double mean[PL_OBS], var[PL_OBS], inv[PL_OBS]; double scale; };             // (the raw observations sit where their normalised values go; the partial sums borrow h2)
 struct FusedTab { double tab[2][PL_SG][PL_OBS]; double red[3][4]; };
 static_assert(sizeof(FusedTab) <= PL_TM * PL_H2S * sizeof(float), "partial sums fit the layer-2 output buffer");
 
@@ -160,7 +184,7 @@ __global__ __launch_bounds__(256) void usim_policy_act_kernel(PolicyNet P, NormS
                                                               float* __restrict__ start_out, FusedArgs F) {
     __shared__ FusedLds FL;
     __shared__ __attribute__((aligned(16))) float xs[PL_TM][PL_KPAD];
-    __shared__ __attribute__((aligned(16))) float h1[PL_TM][PL_H1S];
+    __shared__ __attribute__((aligned(16))) _Float16 h1h[PL_TM][PL_H1 + 8], h1l[PL_TM][PL_H1 + 8];      // layer-1 activations, split (split_h); row stride 528 bytes
     __shared__ __attribute__((aligned(16))) float h2[PL_TM][PL_H2S];
     __shared__ __attribute__((aligned(16))) float w1s[PL_H1 * PL_OBS];        // layer-1 weights [256][19] of this workgroup's network
     __shared__ __attribute__((aligned(16))) float whs[8 * PL_H2];             // head weights: action_net [A][128] or value_net [1][128]
@@ -172,13 +196,27 @@ __global__ __launch_bounds__(256) void usim_policy_act_kernel(PolicyNet P, NormS
     //      coalesced loads ----
     const int c0 = (wave * 2) * 16 + lr, c1 = c0 + 16;
     float4 wb0[PL_H1 / 16], wb1[PL_H1 / 16];
+    // ... and every small parameter a later phase needs (biases, log-std, action box): read where they are used, each of them exposes an L2 round trip behind a barrier
+    float4 pb1[4], pb2[2];
+    float ph[4] = {0.f, 0.f, 0.f, 0.f};
     auto prefetch = [&]() {
-        const float* W2 = net ? P.vf_w2 : P.pi_w2;
+        {
+            const float* B1 = net ? P.vf_b1 : P.pi_b1; const float* B2 = net ? P.vf_b2 : P.pi_b2;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) pb1[tt] = *reinterpret_cast<const float4*>(&B1[(wave * 4 + tt) * 16 + 4 * lg]);      // (this lane's four output features of the tile)
+            pb2[0] = *reinterpret_cast<const float4*>(&B2[(wave * 2) * 16 + 4 * lg]); pb2[1] = *reinterpret_cast<const float4*>(&B2[(wave * 2 + 1) * 16 + 4 * lg]);
+            const int o = tid & 7;
+            if (net == 0) { if (o < adim) { ph[0] = P.act_b[o]; ph[1] = P.log_std[o]; ph[2] = act_low[o]; ph[3] = act_high[o]; } }
+            else ph[0] = P.val_b[0];
+        }
 #pragma unroll
         for (int s = 0; s < PL_H1 / 16; ++s) {
             const int k = 16 * s + 4 * lg;
-            wb0[s] = *reinterpret_cast<const float4*>(&W2[c0 * PL_H1 + k]);
-            wb1[s] = *reinterpret_cast<const float4*>(&W2[c1 * PL_H1 + k]);
+#if defined(USIM_POLICY_NOLOAD)
+            wb0[s] = make_float4(0.001f * k, 0.f, 0.002f, 0.f); wb1[s] = make_float4(0.f, 0.001f * lr, 0.f, 0.003f);
+#else
+            wb0[s] = P.w2_packed[pl_packed_index(net, wave, 0, s, lane)]; wb1[s] = P.w2_packed[pl_packed_index(net, wave, 1, s, lane)];
+#endif
         }
         const float4* W1 = reinterpret_cast<const float4*>(net ? P.vf_w1 : P.pi_w1);
 #pragma unroll
@@ -286,7 +324,7 @@ __global__ __launch_bounds__(256) void usim_policy_act_kernel(PolicyNet P, NormS
                 om += delta * n / tot; ov = m2 / tot;
                 if (writer) { S.obs_mean[tid] = om; S.obs_var[tid] = ov; if (tid == 0) *S.obs_count = tot; }
             }
-            FL.mean[tid] = om; FL.var[tid] = ov;
+            FL.mean[tid] = om; FL.var[tid] = ov; FL.inv[tid] = 1.0 / sqrt(ov + S.epsilon);
         } else if (tid == 64) {
             double rmean = rmean0, rvar = rvar0, rcnt = rcnt0;
             if (F.have_prev) {
@@ -307,13 +345,28 @@ __global__ __launch_bounds__(256) void usim_policy_act_kernel(PolicyNet P, NormS
             F.nrew_prev[row0 + tid] = (float)v;
         }
     }
-    // ---- VecNormalize.normalize_obs: clip((obs - mean) / sqrt(var + eps)) in float64, stored as float32 ----
-    for (int t = tid; t < PL_TM * PL_KPAD; t += 256) {
+    // ---- VecNormalize.normalize_obs: clip((obs - mean) / sqrt(var + eps)) in float64, stored as float32 (the nineteen reciprocal deviations once per workgroup:
+    //      a float64 square root and a division per word were a microsecond of the launch) ----
+    constexpr int NX = (PL_TM * PL_KPAD + 255) / 256;
+    float xraw[NX];
+    if constexpr (!FUSED) {
+        // (the observation words are requested before the statistics are waited for: one round trip to L2, not two)
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int t = tid + 256 * j, r = t / PL_KPAD, c = t - r * PL_KPAD, env = row0 + r;
+            xraw[j] = (t < PL_TM * PL_KPAD && c < PL_OBS && env < n) ? obs[(size_t)env * PL_OBS + c] : 0.f;
+        }
+        if (tid < PL_OBS) { FL.mean[tid] = S.obs_mean[tid]; FL.inv[tid] = 1.0 / sqrt(S.obs_var[tid] + S.epsilon); }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        const int t = tid + 256 * j;
+        if (t >= PL_TM * PL_KPAD) break;
         const int r = t / PL_KPAD, c = t - r * PL_KPAD, env = row0 + r;
         float v = 0.f;
         if (c < PL_OBS && env < n) {
-            const double om = FUSED ? FL.mean[c] : S.obs_mean[c], ov = FUSED ? FL.var[c] : S.obs_var[c];
-            double x = ((double)(FUSED ? xs[r][c] : obs[(size_t)env * PL_OBS + c]) - om) / sqrt(ov + S.epsilon);
+            double x = ((double)(FUSED ? xs[r][c] : xraw[j]) - FL.mean[c]) * FL.inv[c];
             x = x < -S.clip_obs ? -S.clip_obs : (x > S.clip_obs ? S.clip_obs : x);
             v = (float)x;
             if (nobs_out && net == 0) nobs_out[(size_t)env * PL_OBS + c] = v;
@@ -321,7 +374,11 @@ __global__ __launch_bounds__(256) void usim_policy_act_kernel(PolicyNet P, NormS
         xs[r][c] = v;
     }
     __syncthreads();
-    // ---- layer 1 (19 -> 256, tanh): wave w owns column tiles 4 w .. 4 w + 3, both row tiles ----
+#if defined(USIM_POLICY_CUT) && USIM_POLICY_CUT == 1
+    if (value_out) { if (tid == 0) value_out[row0] = xs[0][0] + wb0[0].x + wb1[3].y; return; }
+#endif
+    // ---- layer 1 (19 -> 256, tanh): wave w owns feature tiles 4 w .. 4 w + 3, both environment tiles.  Transposed product (features x environments = W1 X'): the
+    //      four accumulator words of a lane are four CONSECUTIVE features of one environment -- one 8-byte store per split half instead of eight 2-byte ones ----
     {
         const float* W = w1s;
         const float* B = net ? P.vf_b1 : P.pi_b1;
@@ -333,15 +390,26 @@ __global__ __launch_bounds__(256) void usim_policy_act_kernel(PolicyNet P, NormS
             for (int s = 0; s < PL_KPAD / 4; ++s) {
                 const int k = 4 * s + lg;
                 const float b = (k < PL_OBS) ? W[col * PL_OBS + k] : 0.f;
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[lr][k], b, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[16 + lr][k], b, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, xs[lr][k], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, xs[16 + lr][k], acc1, 0, 0, 0);
             }
-            const float bias = B[col];
+            const float bias[4] = {pb1[tt].x, pb1[tt].y, pb1[tt].z, pb1[tt].w};
+            const int f0 = (wave * 4 + tt) * 16 + 4 * lg;
+            v4h_ h0, l0, h1v, l1;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { h1[4 * lg + r][col] = tanh_(acc0[r] + bias); h1[16 + 4 * lg + r][col] = tanh_(acc1[r] + bias); }
+            for (int r = 0; r < 4; ++r) {
+                _Float16 a, b2;
+                split_h(tanh_(acc0[r] + bias[r]), a, b2); h0[r] = a; l0[r] = b2;
+                split_h(tanh_(acc1[r] + bias[r]), a, b2); h1v[r] = a; l1[r] = b2;
+            }
+            *reinterpret_cast<v4h_*>(&h1h[lr][f0]) = h0; *reinterpret_cast<v4h_*>(&h1l[lr][f0]) = l0;
+            *reinterpret_cast<v4h_*>(&h1h[16 + lr][f0]) = h1v; *reinterpret_cast<v4h_*>(&h1l[16 + lr][f0]) = l1;
         }
     }
     __syncthreads();
+#if defined(USIM_POLICY_CUT) && USIM_POLICY_CUT == 2
+    if (value_out) { if (tid == 0) value_out[row0] = (float)h1h[0][0] + wb0[0].x + wb1[3].y; return; }
+#endif
     // ---- layer 2 (256 -> 128, tanh): wave w owns column tiles 2 w, 2 w + 1 for both row tiles; 16 k values per pass (one 16-byte read per operand,
     //      four instructions per accumulator): a weight word read once serves 32 environments ----
     {
@@ -350,21 +418,28 @@ __global__ __launch_bounds__(256) void usim_policy_act_kernel(PolicyNet P, NormS
 #pragma unroll
         for (int s = 0; s < PL_H1 / 16; ++s) {
             const int k = 16 * s + 4 * lg;
-            const float4 x0 = *reinterpret_cast<const float4*>(&h1[lr][k]), x1 = *reinterpret_cast<const float4*>(&h1[16 + lr][k]);
-            const float4 b0 = wb0[s], b1 = wb1[s];
-#define USIM_MM4(ACC, X, BB) ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(X.x, BB.x, ACC, 0, 0, 0); ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(X.y, BB.y, ACC, 0, 0, 0); \
-                             ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(X.z, BB.z, ACC, 0, 0, 0); ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(X.w, BB.w, ACC, 0, 0, 0);
-            USIM_MM4(a00, x0, b0) USIM_MM4(a01, x0, b1) USIM_MM4(a10, x1, b0) USIM_MM4(a11, x1, b1)
-#undef USIM_MM4
+            const v4h_ x0h = *reinterpret_cast<const v4h_*>(&h1h[lr][k]), x0l = *reinterpret_cast<const v4h_*>(&h1l[lr][k]);
+            const v4h_ x1h = *reinterpret_cast<const v4h_*>(&h1h[16 + lr][k]), x1l = *reinterpret_cast<const v4h_*>(&h1l[16 + lr][k]);
+            union W { float4 f; struct { v4h_ hi, lo; } h; };
+            W b0, b1; b0.f = wb0[s]; b1.f = wb1[s];
+            // three products per tile, the small ones first
+#define USIM_MM3(ACC, XH, XL, BB) ACC = __builtin_amdgcn_mfma_f32_16x16x16f16(BB.h.hi, XL, ACC, 0, 0, 0); ACC = __builtin_amdgcn_mfma_f32_16x16x16f16(BB.h.lo, XH, ACC, 0, 0, 0); \
+                                  ACC = __builtin_amdgcn_mfma_f32_16x16x16f16(BB.h.hi, XH, ACC, 0, 0, 0);          /* (outputs x environments: W2 H1') */
+            USIM_MM3(a00, x0h, x0l, b0) USIM_MM3(a01, x0h, x0l, b1) USIM_MM3(a10, x1h, x1l, b0) USIM_MM3(a11, x1h, x1l, b1)
+#undef USIM_MM3
         }
-        const float bias0 = B[c0], bias1 = B[c1];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            h2[4 * lg + r][c0] = tanh_(a00[r] + bias0); h2[4 * lg + r][c1] = tanh_(a01[r] + bias1);
-            h2[16 + 4 * lg + r][c0] = tanh_(a10[r] + bias0); h2[16 + 4 * lg + r][c1] = tanh_(a11[r] + bias1);
-        }
+        // (transposed as layer 1: a lane holds four consecutive outputs of one environment -- one 16-byte store per tile)
+        const int n0 = (wave * 2) * 16 + 4 * lg, n1 = n0 + 16;
+        const float4 bz0 = pb2[0], bz1 = pb2[1];
+        *reinterpret_cast<float4*>(&h2[lr][n0]) = make_float4(tanh_(a00[0] + bz0.x), tanh_(a00[1] + bz0.y), tanh_(a00[2] + bz0.z), tanh_(a00[3] + bz0.w));
+        *reinterpret_cast<float4*>(&h2[lr][n1]) = make_float4(tanh_(a01[0] + bz1.x), tanh_(a01[1] + bz1.y), tanh_(a01[2] + bz1.z), tanh_(a01[3] + bz1.w));
+        *reinterpret_cast<float4*>(&h2[16 + lr][n0]) = make_float4(tanh_(a10[0] + bz0.x), tanh_(a10[1] + bz0.y), tanh_(a10[2] + bz0.z), tanh_(a10[3] + bz0.w));
+        *reinterpret_cast<float4*>(&h2[16 + lr][n1]) = make_float4(tanh_(a11[0] + bz1.x), tanh_(a11[1] + bz1.y), tanh_(a11[2] + bz1.z), tanh_(a11[3] + bz1.w));
     }
     __syncthreads();
+#if defined(USIM_POLICY_CUT) && USIM_POLICY_CUT == 3
+    if (value_out) { if (tid == 0) value_out[row0] = h2[0][0]; return; }
+#endif
     // ---- head: eight lanes per environment.  Policy network: lane o < A forms the mean of action component o (128 -> A), then sampling and the
     //      log-probability; value network: the eight lanes split the 128 -> 1 dot product ----
     const int r = tid >> 3, o = tid & 7, env = row0 + r;
@@ -378,24 +453,24 @@ __global__ __launch_bounds__(256) void usim_policy_act_kernel(PolicyNet P, NormS
             const float4 w = *reinterpret_cast<const float4*>(&Wr[k]);
             acc = fmaf(h.x, w.x, acc); bcc = fmaf(h.y, w.y, bcc); acc = fmaf(h.z, w.z, acc); bcc = fmaf(h.w, w.w, bcc);
         }
-        const float mean = acc + bcc + P.act_b[is_act ? o : 0];
+        const float mean = acc + bcc + ph[0];
         // N(0, 1) for (environment, component): Box-Muller on one Philox block per pair of components
         float noise = 0.f;
         if (!deterministic && is_act) {
             const u4 rr = philox((uint32_t)(env_offset + env), ctr, (uint32_t)(o >> 1), 0x504f4c59u, key0, key1);
             const float u1 = ((float)(rr.a >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(rr.b >> 8) * (1.0f / 16777216.0f);
-            const float rad = sqrtf(-2.f * logf(u1)), ang = 2.f * PI_F * u2;
-            noise = (o & 1) ? rad * sinf(ang) : rad * cosf(ang);
+            const float rad = sqrtf(-2.f * __logf(u1)), ang = 2.f * PI_F * u2;        // (hardware log / sine / cosine: the draw is a sample, not a result to reproduce)
+            noise = (o & 1) ? rad * __sinf(ang) : rad * __cosf(ang);
         }
-        const float ls = is_act ? P.log_std[o] : 0.f;
-        const float a = mean + expf(ls) * noise;
+        const float ls = is_act ? ph[1] : 0.f;
+        const float a = mean + __expf(ls) * noise;
         // DiagGaussianDistribution.log_prob of the sample: sum over the components (the eight lanes of this environment)
         float lp = is_act ? (-0.5f * noise * noise - ls - 0.9189385332046727f) : 0.f;
         lp += __shfl_xor(lp, 1); lp += __shfl_xor(lp, 2); lp += __shfl_xor(lp, 4);
         if (env < n) {
             if (is_act) {
                 if (act_out) act_out[(size_t)env * adim + o] = a;
-                act_env[(size_t)env * adim + o] = fminf(fmaxf(a, act_low[o]), act_high[o]);
+                act_env[(size_t)env * adim + o] = fminf(fmaxf(a, ph[2]), ph[3]);
             }
             if (o == 0) {
                 if (logp_out) logp_out[env] = lp;
@@ -411,7 +486,7 @@ __global__ __launch_bounds__(256) void usim_policy_act_kernel(PolicyNet P, NormS
             acc = fmaf(h.x, w.x, acc); acc = fmaf(h.y, w.y, acc); acc = fmaf(h.z, w.z, acc); acc = fmaf(h.w, w.w, acc);
         }
         acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
-        if (env < n && o == 0 && value_out) value_out[env] = acc + P.val_b[0];
+        if (env < n && o == 0 && value_out) value_out[env] = acc + ph[0];
     }
 }
 
@@ -488,13 +563,19 @@ __global__ void usim_policy_gae_kernel(const float* __restrict__ rewards, const 
 
 extern "C" {
 
+int usim_policy_pack(const usim_policy_net* net, float* packed_dev, void* stream) {
+    if (!net || !net->pi_w2 || !net->vf_w2 || !packed_dev || (reinterpret_cast<uintptr_t>(packed_dev) & 15)) return USIM_ERR_INVALID;
+    hipLaunchKernelGGL(usim_policy_pack_kernel, dim3(USIM_POLICY_PACKED / 4 / 256), dim3(256), 0, (hipStream_t)stream, net->pi_w2, net->vf_w2, reinterpret_cast<float4*>(packed_dev));
+    return hipGetLastError() == hipSuccess ? USIM_OK : USIM_ERR_HIP;
+}
+
 int usim_policy_step(const usim_policy_net* net, const usim_norm_stats* st, const float* obs_dev, const uint8_t* prev_done_dev, int n, int act_dim,
                      const float* act_low_dev, const float* act_high_dev, uint64_t seed, uint32_t counter, const uint32_t* counter_base_dev, int env_offset,
                      int training, int deterministic, const usim_policy_out* out, void* stream) {
     using namespace usim;
-    if (!net || !st || !obs_dev || !out || !out->act_env_dev || n <= 0 || act_dim < 1 || act_dim > 7 || !act_low_dev || !act_high_dev) return USIM_ERR_INVALID;
+    if (!net || !st || !obs_dev || !out || !out->act_env_dev || n <= 0 || act_dim < 1 || act_dim > 7 || !act_low_dev || !act_high_dev || !net->w2_packed) return USIM_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    PolicyNet P{net->pi_w1, net->pi_b1, net->pi_w2, net->pi_b2, net->act_w, net->act_b, net->vf_w1, net->vf_b1, net->vf_w2, net->vf_b2, net->val_w, net->val_b, net->log_std};
+    PolicyNet P{net->pi_w1, net->pi_b1, net->pi_w2, net->pi_b2, net->act_w, net->act_b, net->vf_w1, net->vf_b1, net->vf_w2, net->vf_b2, net->val_w, net->val_b, net->log_std, reinterpret_cast<const float4*>(net->w2_packed)};
     NormStats S{st->obs_mean, st->obs_var, st->obs_count, st->ret_mean, st->ret_var, st->ret_count, st->returns, st->clip_obs, st->clip_reward, st->gamma, st->epsilon};
     if (training == 1) {
         if (!st->scratch) return USIM_ERR_INVALID;
@@ -511,7 +592,7 @@ int usim_policy_step_fused(const usim_policy_net* net, const usim_norm_stats* st
                            int act_dim, const float* act_low_dev, const float* act_high_dev, uint64_t seed, uint32_t counter, const uint32_t* counter_base_dev,
                            int env_offset, int deterministic, const usim_policy_out* out, void* stream) {
     using namespace usim;
-    if (!net || !st || !f || !obs_dev || !out || !out->act_env_dev || n <= 0 || act_dim < 1 || act_dim > 7 || !act_low_dev || !act_high_dev) return USIM_ERR_INVALID;
+    if (!net || !st || !f || !obs_dev || !out || !out->act_env_dev || n <= 0 || act_dim < 1 || act_dim > 7 || !act_low_dev || !act_high_dev || !net->w2_packed) return USIM_ERR_INVALID;
     if (!f->work_dev || (f->have_prev && (!f->rew_prev_dev || !f->done_prev_dev || !f->nrew_prev_dev))) return USIM_ERR_INVALID;
     if (n > USIM_POLICY_FUSED_MAX_ENVS) return USIM_ERR_UNSUPPORTED;          // every workgroup must be resident (see the kernel)
     {
@@ -528,7 +609,7 @@ int usim_policy_step_fused(const usim_policy_net* net, const usim_norm_stats* st
         }
         if (2 * ((n + PL_TM - 1) / PL_TM) > capacity[dev]) return USIM_ERR_UNSUPPORTED;
     }
-    PolicyNet P{net->pi_w1, net->pi_b1, net->pi_w2, net->pi_b2, net->act_w, net->act_b, net->vf_w1, net->vf_b1, net->vf_w2, net->vf_b2, net->val_w, net->val_b, net->log_std};
+    PolicyNet P{net->pi_w1, net->pi_b1, net->pi_w2, net->pi_b2, net->act_w, net->act_b, net->vf_w1, net->vf_b1, net->vf_w2, net->vf_b2, net->val_w, net->val_b, net->log_std, reinterpret_cast<const float4*>(net->w2_packed)};
     NormStats S{st->obs_mean, st->obs_var, st->obs_count, st->ret_mean, st->ret_var, st->ret_count, st->returns, st->clip_obs, st->clip_reward, st->gamma, st->epsilon};
     FusedArgs F{f->rew_prev_dev, f->done_prev_dev, f->nrew_prev_dev, f->raw_sum_dev, f->work_dev, f->update_obs, f->have_prev, f->norm_reward};
     hipLaunchKernelGGL(usim_policy_act_kernel<true>, dim3((n + PL_TM - 1) / PL_TM, 2), dim3(256), 0, (hipStream_t)stream, P, S, obs_dev, prev_done_dev, n,

@@ -515,7 +515,11 @@ class FusedRollout:
         pn, vb = policy.policy_net, policy.value_net_body
         self._net = _lib.UsimPolicyNet(ptr(pn[0].weight), ptr(pn[0].bias), ptr(pn[2].weight), ptr(pn[2].bias), ptr(policy.action_net.weight), ptr(policy.action_net.bias),
                                        ptr(vb[0].weight), ptr(vb[0].bias), ptr(vb[2].weight), ptr(vb[2].bias), ptr(policy.value_net.weight), ptr(policy.value_net.bias),
-                                       ptr(policy.log_std))
+                                       ptr(policy.log_std), None)
+        # layer-2 weights of both networks in the order the matrix-core operands consume them (usim_policy_pack; include/usim.h): packed again before every eager
+        # launch and as the first policy node of a recorded rollout, so a parameter update between rollouts is seen as before
+        self._w2_packed = torch.zeros(_lib.POLICY_PACKED, dtype=torch.float32, device=dev)
+        self._net.w2_packed = self._w2_packed.data_ptr()
         vn = vecnorm
         self._scratch = torch.zeros(1280, dtype=torch.float64, device=dev)                  # USIM_POLICY_SCRATCH (include/usim.h)
         self._stats = _lib.UsimNormStats(ptr(vn.obs_mean), ptr(vn.obs_var), ptr(vn._obs_count), ptr(vn.ret_mean), ptr(vn.ret_var), ptr(vn._ret_count), ptr(vn.returns),
@@ -550,10 +554,16 @@ class FusedRollout:
         from . import _lib
         _lib.check(self.lib, rc, None)
 
-    def act(self, obs, prev_done, counter, training=None, deterministic=False, t=None):
+    def pack(self):
+        """usim_policy_pack: the layer-2 weights as they are now, in operand order (a launch of 64 workgroups)"""
+        self._check(self.lib.usim_policy_pack(C.byref(self._net), self._w2_packed.data_ptr(), self.env._stream()))
+
+    def act(self, obs, prev_done, counter, training=None, deterministic=False, t=None, pack=True):
         """usim_policy_step on raw observations [n, 19]: returns (clipped action for the env, value); with t, the buffer slices of step t are written"""
         from . import _lib
         env, b = self.env, self.buffer
+        if pack:
+            self.pack()
         training = self.vecnorm.training if training is None else training
         ptr = lambda x: None if x is None else x.data_ptr()
         out = _lib.UsimPolicyOut(ptr(self._act_env), None if t is None else ptr(b.observations[t]), None if t is None else ptr(b.actions[t]),
@@ -570,11 +580,13 @@ class FusedRollout:
         return _lib.UsimPolicyFused(self._work.data_ptr(), env._rew.data_ptr() if prev else None, env._done.data_ptr() if prev else None,
                                     rewards_out.data_ptr() if prev else None, self.raw_reward_sum.data_ptr(), int(prev), int(prev), int(bool(vn.norm_reward)), 0)
 
-    def act_fused(self, obs, prev_done, counter, rewards_out=None, deterministic=False, t=None):
+    def act_fused(self, obs, prev_done, counter, rewards_out=None, deterministic=False, t=None, pack=True):
         """usim_policy_step_fused: as act(), with RunningMeanStd.update(obs) and the reward side of the step before (normalised into rewards_out) in the same
         launch when counter > 0"""
         from . import _lib
         env, b = self.env, self.buffer
+        if pack:
+            self.pack()
         ptr = lambda x: None if x is None else x.data_ptr()
         out = _lib.UsimPolicyOut(ptr(self._act_env), None if t is None else ptr(b.observations[t]), None if t is None else ptr(b.actions[t]),
                                  ptr(self._value) if t is None else ptr(b.values[t]), None if t is None else ptr(b.log_probs[t]), None if t is None else ptr(b.episode_starts[t]))
@@ -594,10 +606,11 @@ class FusedRollout:
         T, n = b.buffer_size, env.num_envs
         env.refill_bank()                      # first node of the recorded sequence as well: a replay is valid whatever ran on the env since the last one
         self.raw_reward_sum.zero_()
+        self.pack()                            # the weights of this rollout (they do not change inside it)
         for t in range(T):
-            self.act_fused(self.obs, self._prev_done, counter=t, rewards_out=b.rewards[t - 1] if t else None, t=t)
+            self.act_fused(self.obs, self._prev_done, counter=t, rewards_out=b.rewards[t - 1] if t else None, t=t, pack=False)
             env.step_tensor(self._act_env)
-        self.act_fused(self.obs, self._prev_done, counter=T, rewards_out=b.rewards[T - 1], deterministic=True)      # bootstrap value + the last step's reward side
+        self.act_fused(self.obs, self._prev_done, counter=T, rewards_out=b.rewards[T - 1], deterministic=True, pack=False)      # bootstrap value + the last step's reward side
         self._check(self.lib.usim_policy_gae(b.rewards.data_ptr(), b.values.data_ptr(), b.episode_starts.data_ptr(), self._value.data_ptr(), self._prev_done.data_ptr(),
                                              T, n, b.gamma, b.gae_lambda, b.advantages.data_ptr(), b.returns.data_ptr(), env._stream()))
         self._ctr.add_(T + 1)
@@ -615,12 +628,13 @@ class FusedRollout:
         # The observation statistics follow VecNormalize's timing: RunningMeanStd.update(obs) when the environment RETURNS the observation (reset: once, in
         # __init__; step: in the launch that also does the reward side), so the policy kernel only normalises (training = 2) and the bootstrap value sees
         # statistics that include the last observation, as SB3's `_last_obs` does.
+        self.pack()                            # the weights of this rollout (they do not change inside it)
         for t in range(T):
-            self.act(self.obs, self._prev_done, counter=t, training=2 if vn.training else 0, t=t)
+            self.act(self.obs, self._prev_done, counter=t, training=2 if vn.training else 0, t=t, pack=False)
             o, rew, done = env.step_tensor(self._act_env)
             self._check(self.lib.usim_policy_reward(C.byref(self._stats), rew.data_ptr(), done.data_ptr(), n, int(bool(vn.training)), int(bool(vn.norm_reward)),
                                                     b.rewards[t].data_ptr(), self.raw_reward_sum.data_ptr(), o.data_ptr() if vn.training else None, env._stream()))
-        self.act(self.obs, self._prev_done, counter=T, training=0, deterministic=True)
+        self.act(self.obs, self._prev_done, counter=T, training=0, deterministic=True, pack=False)
         self._check(self.lib.usim_policy_gae(b.rewards.data_ptr(), b.values.data_ptr(), b.episode_starts.data_ptr(), self._value.data_ptr(), self._prev_done.data_ptr(),
                                              T, n, b.gamma, b.gae_lambda, b.advantages.data_ptr(), b.returns.data_ptr(), env._stream()))
         self._ctr.add_(T + 1)
