@@ -175,6 +175,8 @@ struct FusedLds { double mean[PL_OBS], var[PL_OBS], inv[PL_OBS]; double scale; }
 struct FusedTab { double tab[2][PL_SG][PL_OBS]; double red[3][4]; };
 static_assert(sizeof(FusedTab) <= PL_TM * PL_H2S * sizeof(float), "partial sums fit the layer-2 output buffer");
 
+// Diagnostics (never in the shipped library): -DUSIM_POLICY_CUT=1 / 2 / 3 ends the kernel before layer 1 / before layer 2 / before the heads, -DUSIM_POLICY_NOLOAD replaces the
+// layer-2 weight reads by constants -- the kernel's time by phase under rocprofv3.
 template <bool FUSED>
 __global__ __launch_bounds__(256) void usim_policy_act_kernel(PolicyNet P, NormStats S, const float* __restrict__ obs,
                                                               const uint8_t* __restrict__ prev_done, int n, int adim, const float* __restrict__ act_low,
