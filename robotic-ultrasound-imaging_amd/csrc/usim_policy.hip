@@ -178,7 +178,7 @@ static_assert(sizeof(FusedTab) <= PL_TM * PL_H2S * sizeof(float), "partial sums 
 // Diagnostics (never in the shipped library): -DUSIM_POLICY_CUT=1 / 2 / 3 ends the kernel before layer 1 / before layer 2 / before the heads, -DUSIM_POLICY_NOLOAD replaces the
 // layer-2 weight reads by constants -- the kernel's time by phase under rocprofv3.
 template <bool FUSED>
-__global__ __launch_bounds__(256) void usim_policy_act_kernel(PolicyNet P, NormStats S, const float* __restrict__ obs,
+__global__ __launch_bounds__(256, 2) void usim_policy_act_kernel(PolicyNet P, NormStats S, const float* __restrict__ obs,
                                                               const uint8_t* __restrict__ prev_done, int n, int adim, const float* __restrict__ act_low,
                                                               const float* __restrict__ act_high, uint32_t key0, uint32_t key1, uint32_t ctr0, const uint32_t* __restrict__ ctr_base, int env_offset,
                                                               int deterministic, float* __restrict__ nobs_out, float* __restrict__ act_out,

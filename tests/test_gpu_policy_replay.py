@@ -376,6 +376,22 @@ def test_fused_rollout_noise_is_keyed_on_the_global_environment_id(usim):
     assert not torch.equal(lo[0], hi[0])                                 # (and the shards do not repeat each other)
 
 
+def test_fused_statistics_launch_holds_8192_environments(usim):
+    """The in-launch statistics exchange needs its whole grid resident: 2 x 256 workgroups at the library's limit of 8192 environments = two per CU, i.e. the policy
+    kernel has to stay within 256 registers per lane and 80 KB of LDS per workgroup (a rework of its matrix products once took it to 271 registers: USIM_ERR_UNSUPPORTED)."""
+    pol = importlib.import_module("robotic-ultrasound-imaging_amd.policy")
+    dev, n, T = torch.device("cuda:0"), 8192, 3
+    torch.manual_seed(0)
+    env = usim.UltrasoundVecEnv(n, device="cuda:0", seed=4, **usim.default_robosuite_kwargs())
+    policy = pol.MlpActorCritic(19, env.action_dim).to(dev)
+    vn = pol.DeviceVecNormalize(n, 19, device=dev, training=True, norm_reward=True)
+    buf = pol.DeviceRolloutBuffer(T, n, 19, env.action_dim, device=dev)
+    fr = pol.FusedRollout(env, policy, vn, buf, seed=9, graph=False, fused_stats=True)
+    fr.collect(); torch.cuda.synchronize()
+    assert fr.fused_stats and not fr.wait_ran_out and vn.obs_count > n * (T + 1) and torch.isfinite(buf.advantages).all() and buf.full
+    env.close()
+
+
 def test_fused_statistics_launch_refuses_what_it_cannot_run(usim):
     """usim_policy_step_fused: more environments than can be resident -> USIM_ERR_UNSUPPORTED (-5); no workspace / no reward buffers with have_prev -> USIM_ERR_INVALID
     (-1); FusedRollout then picks the three-launch sequence by itself"""
