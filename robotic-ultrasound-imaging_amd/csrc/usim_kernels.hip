@@ -745,8 +745,8 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
                 // (1) ray
                 const bool pos = f[0] > 0.f;
                 const float rt2 = fmaf(r1, r1, r2 * r2);
-                const float irt = rsq_(rt2), rtn = rt2 * irt;
-                const float sl = (rt2 > 0.f && r0 < mu * rtn) ? -mu * irt : 0.f;
+                const float irt = rsq_(fmaxf(rt2, 1e-30f)), rtn = rt2 * irt;
+                const float sl = (int(rt2 > 0.f) & int(r0 < mu * rtn)) ? -mu * irt : 0.f;      // (no short circuit: the compiler otherwise branches around the square root, and a lane without force is in every visit)
                 const float v0 = pos ? f[0] : 1.f, v1 = pos ? f[1] : sl * r1, v2 = pos ? f[2] : sl * r2;
                 const float Bv0 = fmaf(b02, v2, fmaf(b01, v1, b00 * v0)), Bv1 = fmaf(b12, v2, fmaf(b11, v1, b01 * v0)), Bv2 = fmaf(b22, v2, fmaf(b12, v1, b02 * v0));
                 const float vr = fmaf(v2, r2, fmaf(v1, r1, v0 * r0)), vBv = fmaf(v2, Bv2, fmaf(v1, Bv1, v0 * Bv0));
