@@ -499,7 +499,7 @@ DI void contact_rows(float* lds, const int eb, const int gl, const DevModel& M, 
         float kk = dimp * (1.0f / (SI_DMAX * SI_DMAX * SR_TC * SR_TC));
         float Rn = (1.f - dimp) * rcp_(dimp) * M.invw;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) if (c < nc) P.Km[c] = lds[TB_LINV + e * LROW + cel[c]] * (1.0f / ELEM_MASS);
+        for (int c = 0; c < MAXC; ++c) { const float t = lds[TB_LINV + e * LROW + cel[c]] * (1.0f / ELEM_MASS); P.Km[c] = (c < nc) ? t : 0.f; }
         P.ae0 = EB(GE_A + e);
         P.kdist = kk * dist;
 #pragma unroll
@@ -588,7 +588,7 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
         float kk = dimp * (1.0f / (SI_DMAX * SI_DMAX * SR_TC * SR_TC));
         float Rn = (1.f - dimp) * rcp_(dimp) * M.invw;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) if (c < nc) Km[c] = lds[TB_LINV + e * LROW + cel[c]] * (1.0f / ELEM_MASS);
+        for (int c = 0; c < MAXC; ++c) { const float t = lds[TB_LINV + e * LROW + cel[c]] * (1.0f / ELEM_MASS); Km[c] = (c < nc) ? t : 0.f; }   // (cel[c] = 0 beyond the count: the read is always in range, and a select costs less than a branch around it)
         const float ae0 = EB(GE_A + e);
 #pragma unroll
         for (int d = 0; d < 3; ++d) {

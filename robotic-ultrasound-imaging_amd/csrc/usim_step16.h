@@ -488,7 +488,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
                 const int eraw = i * G + gl, e = eraw < N_TOP ? eraw : N_TOP - 1;
                 const bool cand = (eraw < N_TOP) && collide_cull(lds, e, M, C, s_pre[i], dz, xs, sxc, sz);
                 const unsigned gm = (unsigned)(__ballot(cand) >> gbase) & GMASK;
-                if (cand) mb[MB_Q + nq + __popc(gm & ((1u << gl) - 1u))] = __int_as_float(e);
+                mb[MB_Q + (cand ? nq + __popc(gm & ((1u << gl) - 1u)) : 99)] = __int_as_float(e);       // (as on the arm side: the spare last word takes the non-candidates)
                 nq += __popc(gm);
             }
             group_sync();
@@ -550,7 +550,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
         float gf[MAXC], W[6] = {0, 0, 0, 0, 0, 0};
         int cel[MAXC];
 #pragma unroll
-        for (int k = 0; k < MAXC; ++k) { gf[k] = 0.f; cel[k] = EARLY ? cel_early[k] : ((k < nc) ? __float_as_int(EB(GE_CG + k * CG_WORDS + 6)) : 0); }
+        for (int k = 0; k < MAXC; ++k) { const int ek = __float_as_int(EB(GE_CG + k * CG_WORDS + 6)); gf[k] = 0.f; cel[k] = EARLY ? cel_early[k] : ((k < nc) ? ek : 0); }      // (read, then select: no branch per slot)
         if (ncmax > 0) {
             float alpha[6], vs[6], Lp[21];
 #pragma unroll
@@ -567,7 +567,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
             *reinterpret_cast<float4*>(&mb[MB_W]) = make_float4(W[0], W[1], W[2], W[3]);
             *reinterpret_cast<float4*>(&mb[MB_W + 4]) = make_float4(W[4], W[5], __int_as_float(nc), __int_as_float(overflow));
 #pragma unroll
-            for (int k = 0; k < MAXC; ++k) mb[MB_W + 8 + k] = __int_as_float((k < nc) ? tb_shell[cel[k]] : -1);
+            for (int k = 0; k < MAXC; ++k) { const int sh = tb_shell[cel[k]]; mb[MB_W + 8 + k] = __int_as_float((k < nc) ? sh : -1); }
         }
         RSTAMP(5);
         USIM_BAR();                                                 // (3) contact wrench and contact list published
@@ -709,7 +709,7 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
                 if (i >= arm_cull_rounds<G>()) continue;
                 const bool cand = (eraw < N_TOP) && collide_cull(lds, e, M, C, s_pre[i], dz_, xs, sxc, sz);
                 const unsigned gm = (unsigned)(__ballot(cand) >> gbase) & GMASK;
-                if (cand) xl[MB_Q + nq + __popc(gm & ((1u << gl) - 1u))] = __int_as_float(e);
+                xl[MB_Q + (cand ? nq + __popc(gm & ((1u << gl) - 1u)) : 99)] = __int_as_float(e);     // (a lane without a candidate writes the queue's spare last word -- 99 elements at most are queued --: a store, not a branch)
                 nq += __popc(gm);
             }
             if (gl == 0) xl[MB_POSE + 10] = __int_as_float(nq);
@@ -741,7 +741,10 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
             const bool sgn = (C.mode == 1) || (C.mode == 3) || (C.mode == 2 && a == 6);
             act[a] = sgn ? 2.f * u - 1.f : u;
             if (C.mode == 3) act[a] *= WRENCH_MAX;
-            if (io.act_out && store && a < C.adim) io.act_out[(size_t)ei * C.adim + a] = act[a];
+        }
+        if (io.act_out && store) {                                      // (one predicated region for the seven stores)
+#pragma unroll
+            for (int a = 0; a < 7; ++a) if (a < C.adim) io.act_out[(size_t)ei * C.adim + a] = act[a];
         }
     } else {
 #pragma unroll
