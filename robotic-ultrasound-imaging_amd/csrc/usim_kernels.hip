@@ -823,7 +823,7 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
                 W[a] += group_bcast<G>(v, 7);
             }
 #pragma unroll
-            for (int k = 0; k < MAXC; ++k) if (k < ncmax) gf[k] = group_bcast<G>(gfo, k);
+            for (int k = 0; k < MAXC; ++k) gf[k] = group_bcast<G>(gfo, k);          // (no test per slot: a lane without a contact holds zeros)
         }
     }
     USIM_CSTAMP(dbg, 4);

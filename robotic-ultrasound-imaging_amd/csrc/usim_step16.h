@@ -577,13 +577,12 @@ DI void step16_one(float* lds, const DevModel& M, const DevCfg& C, float* __rest
 #pragma unroll
             for (int i = 0; i < NE; ++i) { const int e = gl + i * G; acc_e[i] = (e < N_TOP) ? EB(GE_A + e) : 0.f; }
 #pragma unroll
-            for (int k = 0; k < MAXC; ++k) {
-                if (k < ncmax) {
+            for (int k = 0; k < MAXC; ++k) {                              // (every slot, no test against the wave's contact count: slots beyond an environment's count carry gf = 0
+                                                                         //  and element 0, and eight uniform branches cost more than the multiply-adds they skip)
 #pragma unroll
-                    for (int i = 0; i < NE; ++i) {
-                        const int e = (gl + i * G < N_TOP) ? gl + i * G : N_TOP - 1;
-                        acc_e[i] = fmaf(lds[TB_LINV + e * LROW + cel[k]], gf[k], acc_e[i]);
-                    }
+                for (int i = 0; i < NE; ++i) {
+                    const int e = (gl + i * G < N_TOP) ? gl + i * G : N_TOP - 1;
+                    acc_e[i] = fmaf(lds[TB_LINV + e * LROW + cel[k]], gf[k], acc_e[i]);
                 }
             }
 #pragma unroll
