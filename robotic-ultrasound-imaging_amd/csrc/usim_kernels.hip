@@ -667,13 +667,14 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (j < ncr) {
 #pragma unroll
-                for (int d = 0; d < 3; ++d)
+            for (int d = 0; d < 3; ++d)
 #pragma unroll
-                    for (int dd = 0; dd < 3; ++dd) B[j][d][dd] = X[j][d][dd];
-            }
-            if (4 + j < ncr) {
+                for (int dd = 0; dd < 3; ++dd) B[j][d][dd] = X[j][d][dd];          // (a renaming: slots beyond ncr hold whatever X held and are never read)
+        }
+        if (ncr > 4) {                                                   // one test for the four rotations instead of one each
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
 #pragma unroll
@@ -682,7 +683,7 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
         }
 #pragma unroll
         for (int k = 0; k < MAXC; ++k) {
-            if (k < ncr && gl == k && own) {
+            if (gl == k && own) {                                        // (own: k < nc <= ncr)
 #pragma unroll
                 for (int d = 0; d < 3; ++d) B[k][d][d] += Rd[d];
             }
