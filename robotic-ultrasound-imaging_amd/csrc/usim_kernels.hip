@@ -620,7 +620,7 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
     //      Lane k publishes Lambda^-1 w^k (18 words) and g^k (3) once in the environment's LDS block (the right-hand-side / staging area is
     //      free by now); every lane then reads contact k's record with six 16-byte broadcast reads -- a quarter of the issue slots the 21 DPP
     //      broadcasts took --, the reads of contact k + 1 in flight while the block of contact k is formed.
-    const int ncr = ncmax == 5 ? 6 : (ncmax == 7 ? 8 : ncmax);     // the sweeps run the code of 6 / 8 contacts for 5 / 7 (below): those blocks are formed too (from the zero rows of a lane without a contact)
+    const int ncr = ncmax;                                        // (the sweeps run exactly the wave's largest contact count)
     float B[MAXC][3][3];            // B[k] is written and read only under k < ncr
     static_assert(MAXC * 24 <= GE_SD, "Delassus records overlay the rhs / staging area");
     if (gl < MAXC) {
@@ -787,13 +787,16 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
             }
         }
     };
-    // (counts 5 and 7 run the code of 6 and 8: a visit of a slot without a contact shares zeros; two instantiations less of a 150-instruction visit)
+    // (one straight-line instantiation per count: rounds 5 -> 6 and 7 -> 8 cost the environments that decide when a launch ends a visit per sweep; before the kernel's
+    //  branches were thinned out the two extra instantiations cost more in instruction fetch than they saved)
     switch (ncr) {
         case 1: sweeps(std::integral_constant<int, 1>{}); break;
         case 2: sweeps(std::integral_constant<int, 2>{}); break;
         case 3: sweeps(std::integral_constant<int, 3>{}); break;
         case 4: sweeps(std::integral_constant<int, 4>{}); break;
-        case 5: case 6: sweeps(std::integral_constant<int, 6>{}); break;
+        case 5: sweeps(std::integral_constant<int, 5>{}); break;
+        case 6: sweeps(std::integral_constant<int, 6>{}); break;
+        case 7: sweeps(std::integral_constant<int, 7>{}); break;
         default: sweeps(std::integral_constant<int, 8>{}); break;
     }
     USIM_STAMP(dbg, 10);
