@@ -77,21 +77,21 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks of this node (default: WORLD_SIZE of the launcher, else 1).  N > 1 without a launcher "
                     "around it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` itself")
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=2048)
+    ap.add_argument("--warmup", type=int, default=256)        # (one refill period of the reset bank: the timed launches are then all full 256-step launches)
     ap.add_argument("--presteps", type=int, default=0, help="studies only: untimed steps between the synchronous reset and the warm-up (after one horizon the episodes of "
                     "the batch are de-synchronised; right after the reset every probe has just been pressed in and the first ~100 steps carry a third more contacts).  "
                     "Default 0: the run starts from the reset, as the W warm-up steps of the contract imply")
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--workload", choices=["soft", "rigid"], default="soft")
-    ap.add_argument("--block", type=int, default=128, help="rollout block length T (steps per all-gather)")
+    ap.add_argument("--block", type=int, default=256, help="rollout block length T (steps per all-gather)")
     ap.add_argument("--randomize", action="store_true", help="BASELINE configs[4]: per-env randomised stiffness/damping + probe friction")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--gather", choices=["rccl", "p2p"], default="rccl", help="N > 1: RCCL all-gather (resident workgroups on the CUs) or peer-to-peer copies "
                     "of the packed block (copy engines, no CUs; distributed.P2PRolloutGather)")
     ap.add_argument("--pgs-iters", type=int, default=0, help="studies only: sweeps of the contact solver (default: the library's, usim_config.pgs_iters)")
-    ap.add_argument("--steps-per-launch", type=int, default=0, help="consecutive steps per kernel launch of the rollout (1 .. 64; default: the library's, 64)")
+    ap.add_argument("--steps-per-launch", type=int, default=0, help="consecutive steps per kernel launch of the rollout (1 .. 256; default: the library's, 256)")
     ap.add_argument("--lanes-per-env", type=int, default=0, choices=[0, 1, 8, 16, 32, 64], help="kernel mapping: 16 lanes per environment (automatic), 8 (soft torso) or 1 (rigid torso)")
     args = ap.parse_args()
 

@@ -178,9 +178,11 @@ int usim_rollout_random(usim_handle* h, int64_t first_step, int nsteps, const us
  * recompiles the model, ultrasound.py:416-478). */
 int usim_refill_bank(usim_handle* h, void* stream);
 
-/* usim_rollout_random enqueues its steps in launches of up to `steps` consecutive steps each (1 .. 64, default 64; the 16- and 32-lane
- * mappings -- the others always launch step by step): inside a launch the lattice tables stay in LDS and launch latency is paid once, every
- * step still reads and writes its state and its slice of the rollout block in HBM.  The results do not depend on the value (bit for bit). */
+/* usim_rollout_random enqueues its steps in launches of up to `steps` consecutive steps each (1 .. 256, default 256 = the refill period of the reset
+ * bank, which a launch never crosses; the 16- and 32-lane mappings -- the others always launch step by step): inside a launch the lattice tables stay in LDS and launch
+ * latency is paid once, every step still writes its state and its slice of the rollout block to HBM.  A launch lasts as long as its slowest workgroup -- the one whose
+ * environments had the most contacts --, so long launches also average that out: 4096 envs, us per step: 32 steps per launch 15.6, 64 14.7, 128 14.1, 256 13.6.  The
+ * results do not depend on the value (bit for bit). */
 int usim_set_steps_per_launch(usim_handle* h, int steps);
 
 /* Device time spent so far in the reset-bank refill launches of this handle (one every 256 steps with auto-reset: the initial-pose IK and

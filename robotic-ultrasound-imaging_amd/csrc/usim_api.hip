@@ -39,7 +39,7 @@ struct usim_handle {
     int2* d_items = nullptr;          // refill work list, capacity 2 * n * BANK_DEPTH
     int* d_count = nullptr;           // [0] items, [1] finished workgroups of the running refill
     long long steps_since_refill = 0;
-    int steps_per_launch = 64;      // usim_rollout_random: consecutive steps per launch of the 16-lane kernels (USIM_STEPS_PER_LAUNCH overrides, 1 .. 64)
+    int steps_per_launch = 256;      // usim_rollout_random: consecutive steps per launch of the 16-lane kernels (USIM_STEPS_PER_LAUNCH overrides, 1 .. 64)
     int bank_row0 = 0;
     size_t lds_bytes = 0, lds16_bytes = 0, lds32_bytes = 0, lds64_bytes = 0;
     std::string hip_err;

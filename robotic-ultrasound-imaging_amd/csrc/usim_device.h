@@ -105,7 +105,7 @@ enum BankField : int { BQ0 = 0, BTS = 7, BTE = 10, BU0 = 13, BKST = 14, BKDMP = 
 constexpr int BANK_DEPTH = 256;                       // = the refill period in steps (an environment consumes at most one slot per step).  64 -> 256: the refill launch is a
                                                       // latency-bound pass (~40 us whatever the number of finished episodes), so a quarter as many of them: 14.27 ->
                                                       // 13.70 us per step at 4096 envs (128: 14.00), 20.7 -> 19.6 at 8192; 168 MB of bank at 4096 envs
-constexpr int MAX_STEPS_PER_LAUNCH = 64;
+constexpr int MAX_STEPS_PER_LAUNCH = 256;
 constexpr int BANK_STRIDE = 40;                       // words per slot (BANK_WORDS rounded up to 16 bytes)
 constexpr int BANK_ROWS = BANK_DEPTH * BANK_STRIDE;   // the bank is environment-major too: env i owns BANK_ROWS words, slot s at s * BANK_STRIDE
 

@@ -57,7 +57,7 @@ class UltrasoundVecEnv:
         self._report_truncation = bool(report_truncation)
         self._env_offset = int(env_offset)
         self._handle = C.c_void_p()
-        self.steps_per_launch = 64                   # usim_set_steps_per_launch default (csrc/usim_api.hip)
+        self.steps_per_launch = 256                  # usim_set_steps_per_launch default (csrc/usim_api.hip)
         self._create(seed)
         lo, hi = _ACTION_BOX[self.cfg.mode]
         self.action_space = Box(np.array(lo), np.array(hi))
@@ -164,7 +164,7 @@ class UltrasoundVecEnv:
         self._check(self.lib.usim_refill_bank(self._handle, self._stream()))
 
     def set_steps_per_launch(self, steps):
-        """rollout_random / time_steps: consecutive steps per kernel launch (1 .. 64, default 64; include/usim.h usim_set_steps_per_launch)"""
+        """rollout_random / time_steps: consecutive steps per kernel launch (1 .. 256, default 256; include/usim.h usim_set_steps_per_launch)"""
         self._check(self.lib.usim_set_steps_per_launch(self._handle, int(steps)))
         self.steps_per_launch = int(steps)
 

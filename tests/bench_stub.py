@@ -5,7 +5,7 @@ import torch
 
 
 class StubEnv:
-    steps_per_launch = 64
+    steps_per_launch = 256
 
     def __init__(self, n, env_offset=0):
         self.num_envs, self.env_offset, self.action_dim = int(n), int(env_offset), 6

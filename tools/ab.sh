@@ -8,10 +8,10 @@ d = json.loads(sys.stdin.read())
 print('%-18s %-30s %8.1f M env-steps/s  %7.2f us/step  kernel %7.2f us' % ('$lib', '$label', d['value'] / 1e6, d['ms_per_step'] * 1e3, d['roofline']['avg_kernel_us']))" | tee -a "$OUT"; }
 for rep in 1 2; do
 for lib in "$@"; do
-run $lib "soft 4096"            --steps 2000 --warmup 100
-run $lib "config5 8192"         --steps 1000 --warmup 100 --envs-per-gpu 8192 --randomize
+run $lib "soft 4096"            --steps 2048 --warmup 256
+run $lib "config5 8192"         --steps 1024 --warmup 256 --envs-per-gpu 8192 --randomize
 [ -n "$QUICK" ] && continue
 run $lib "soft 4096 20/5"       --steps 20 --warmup 5
-run $lib "rigid 4096"           --steps 2000 --warmup 100 --workload rigid
-run $lib "soft 4096 lanes16"    --steps 2000 --warmup 100 --lanes-per-env 16
+run $lib "rigid 4096"           --steps 2048 --warmup 256 --workload rigid
+run $lib "soft 4096 lanes16"    --steps 2048 --warmup 256 --lanes-per-env 16
 done; done

@@ -7,18 +7,18 @@ run() { label=$1; shift; python3 "$ROOT/bench.py" --no-cpu-baseline "$@" 2>/dev/
 import sys, json
 d = json.loads(sys.stdin.read())
 print('%-34s %8.1f M env-steps/s  %7.2f us/step  kernel %7.2f us  frac %.4f  lanes %s  spl %s' % ('$label', d['value'] / 1e6, d['ms_per_step'] * 1e3, d['roofline']['avg_kernel_us'], d['roofline']['frac'], d['config']['lanes_per_env'], d['config']['steps_per_launch']))" | tee -a "$OUT"; }
-run "configs[2] soft 4096"            --steps 2000 --warmup 100
-run "configs[2] soft 4096 spl 1"      --steps 2000 --warmup 100 --steps-per-launch 1
+run "configs[2] soft 4096"            --steps 2048 --warmup 256
+run "configs[2] soft 4096 spl 1"      --steps 2048 --warmup 256 --steps-per-launch 1
 run "configs[2] driver-style 20/5"    --steps 20 --warmup 5
-run "configs[2] 20/5 after 1000 steps" --steps 20 --warmup 5 --presteps 1000
-run "configs[2] lanes 16"             --steps 2000 --warmup 100 --lanes-per-env 16
-run "configs[1] rigid 4096"           --steps 2000 --warmup 100 --workload rigid
-run "configs[4] 8192 randomised auto" --steps 1000 --warmup 100 --envs-per-gpu 8192 --randomize
-run "configs[4] after 1000 steps"      --steps 1000 --warmup 100 --envs-per-gpu 8192 --randomize --presteps 1000
-run "configs[4] 8192 randomised l32"  --steps 1000 --warmup 100 --envs-per-gpu 8192 --randomize --lanes-per-env 32
-run "configs[4] 8192 randomised l64"  --steps 1000 --warmup 100 --envs-per-gpu 8192 --randomize --lanes-per-env 64
-run "configs[4] 8192 randomised l8"   --steps 1000 --warmup 100 --envs-per-gpu 8192 --randomize --lanes-per-env 8
-run "soft 16384 auto"                 --steps 500 --warmup 100 --envs-per-gpu 16384
-run "soft 16384 l64"                  --steps 500 --warmup 100 --envs-per-gpu 16384 --lanes-per-env 64
-run "configs[2] soft 4096 l64"        --steps 2000 --warmup 100 --lanes-per-env 64
-run "soft 16384 l32"                  --steps 500 --warmup 100 --envs-per-gpu 16384 --lanes-per-env 32
+run "configs[2] 20/5 after 1000 steps" --steps 20 --warmup 5 --presteps 1024
+run "configs[2] lanes 16"             --steps 2048 --warmup 256 --lanes-per-env 16
+run "configs[1] rigid 4096"           --steps 2048 --warmup 256 --workload rigid
+run "configs[4] 8192 randomised auto" --steps 1024 --warmup 256 --envs-per-gpu 8192 --randomize
+run "configs[4] after 1000 steps"      --steps 1024 --warmup 256 --envs-per-gpu 8192 --randomize --presteps 1024
+run "configs[4] 8192 randomised l32"  --steps 1024 --warmup 256 --envs-per-gpu 8192 --randomize --lanes-per-env 32
+run "configs[4] 8192 randomised l64"  --steps 1024 --warmup 256 --envs-per-gpu 8192 --randomize --lanes-per-env 64
+run "configs[4] 8192 randomised l8"   --steps 1024 --warmup 256 --envs-per-gpu 8192 --randomize --lanes-per-env 8
+run "soft 16384 auto"                 --steps 512 --warmup 256 --envs-per-gpu 16384
+run "soft 16384 l64"                  --steps 512 --warmup 256 --envs-per-gpu 16384 --lanes-per-env 64
+run "configs[2] soft 4096 l64"        --steps 2048 --warmup 256 --lanes-per-env 64
+run "soft 16384 l32"                  --steps 512 --warmup 256 --envs-per-gpu 16384 --lanes-per-env 32

@@ -1,4 +1,4 @@
-"""Long soak through the multi-step launches (64 steps per launch, state resident in registers between them): every randomisation on, random actions, checks per
+"""Long soak through the multi-step launches (up to 256 steps per launch, state resident in registers between them): every randomisation on, random actions, checks per
 128-step block: non-finite outputs, status bits, episode statistics.   usage: python tools/gpu_soak_blocks.py [n_envs] [steps] [mode] [control_freq]"""
 import importlib, sys, time
 from pathlib import Path

@@ -21,14 +21,14 @@ def mean_kb(root, sub, counter, steps_per_launch):
     sel = [v for v in vals if 0.5 * med < v < 2.0 * med]
     return sum(sel) / len(sel) / steps_per_launch, len(sel)
 
-spl = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+spl = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 out = {}
 for tag, root in (("soft", sys.argv[1]), ("rigid", sys.argv[2])):
     f, nf = mean_kb(root, "pmc_fetch", "FETCH_SIZE", spl)
     w, nw = mean_kb(root, "pmc_write", "WRITE_SIZE", spl)
     out[tag] = {"fetch_kb": f, "fetch_kb_x2": None if f is None else 2 * f, "fetch_kb_launches": nf, "write_kb": w, "write_kb_launches": nw, "steps_per_launch": spl}
 out["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KB), separate passes (tools/profile.sh), mean over the full step launches of "
-               "`bench.py --steps 1024 --warmup 128` at 4096 envs, divided by the steps per launch: KB per step of all environments. "
+               "`bench.py --steps 2048 --warmup 256` at 4096 envs, divided by the steps per launch: KB per step of all environments. "
                "fetch_kb is the raw counter; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of 16 B/lane streaming reads. Since round 2 "
                "the state is environment-major and the scalar words are read as 16-byte quads, the lattice words 4 bytes per lane over 64-byte runs: "
                "the correction applies to the former, is uncalibrated for the latter -- fetch_kb_x2 is the upper bound, and the figure to compare "

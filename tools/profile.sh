@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 1024 --warmup 128 --no-cpu-baseline $*"      # 18 launches of 64 steps (usim_set_steps_per_launch default); pass --steps-per-launch 1 for per-step launches
+ARGS="--steps 2048 --warmup 256 --no-cpu-baseline $*"      # 8 launches of 256 steps (usim_set_steps_per_launch default; the warm-up ends on a refill boundary); pass --steps-per-launch 1 for per-step launches
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats" -o stats -- python3 "$ROOT/bench.py" $ARGS > "$OUT/stats.log" 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY -d "$OUT/pmc_sq1" -o pmc -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_sq1.log" 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT -d "$OUT/pmc_sq2" -o pmc -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_sq2.log" 2>&1

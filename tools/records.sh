@@ -9,13 +9,13 @@ python3 -m pytest tests -m gpu -x -q 2>&1 | tail -3 > "$G/${TAG}_gputests.txt"
 tools/profile.sh ${TAG}_soft > /dev/null 2>&1
 tools/profile.sh ${TAG}_rigid --workload rigid > /dev/null 2>&1
 mkdir -p profiles/$TAG
-python3 tools/make_traffic.py $G/prof_${TAG}_soft $G/prof_${TAG}_rigid 64 profiles/$TAG/issue.json > profiles/$TAG/traffic.json
+python3 tools/make_traffic.py $G/prof_${TAG}_soft $G/prof_${TAG}_rigid 256 profiles/$TAG/issue.json > profiles/$TAG/traffic.json
 cp profiles/$TAG/traffic.json "$G/${TAG}_traffic.json"; cp profiles/$TAG/issue.json "$G/${TAG}_issue.json"
 tools/bench_matrix.sh > /dev/null
 python3 bench.py > "$G/${TAG}_bench_soft.json" 2> /dev/null
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$G/${TAG}_bench_driver.json" 2> /dev/null
 python3 bench.py --workload rigid --no-cpu-baseline > "$G/${TAG}_bench_rigid.json" 2> /dev/null
-python3 bench.py --envs-per-gpu 8192 --randomize --steps 1000 --warmup 100 --no-cpu-baseline > "$G/${TAG}_bench_config5.json" 2> /dev/null
+python3 bench.py --envs-per-gpu 8192 --randomize --steps 1024 --warmup 256 --no-cpu-baseline > "$G/${TAG}_bench_config5.json" 2> /dev/null
 tools/stats_only.sh ${TAG}_config5 --envs-per-gpu 8192 --randomize > /dev/null 2>&1
 tools/stats_only.sh ${TAG}_soft_spl1 --steps-per-launch 1 > /dev/null 2>&1
 python3 tools/split_timeline.py 200 4096 32 > "$G/${TAG}_timeline.txt" 2>&1
