@@ -1,5 +1,5 @@
 """Long soak through the multi-step launches (up to 256 steps per launch, state resident in registers between them): every randomisation on, random actions, checks per
-128-step block: non-finite outputs, status bits, episode statistics.   usage: python tools/gpu_soak_blocks.py [n_envs] [steps] [mode] [control_freq]"""
+256-step block: non-finite outputs, status bits, episode statistics.   usage: python tools/gpu_soak_blocks.py [n_envs] [steps] [mode] [control_freq]"""
 import importlib, sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -15,7 +15,7 @@ kw["controller_configs"] = dict(kw["controller_configs"], impedance_mode=mode)
 kw.update(deterministic_trajectory=False, torso_solref_randomization=True, initial_probe_pos_randomization=True, control_freq=freq)
 env = usim.UltrasoundVecEnv(n, torso="soft", friction_randomization=True, seed=20211002, **kw)
 env.reset_tensor()
-T = 128
+T = 256
 blk = env.alloc_block(T)
 dev = env.device
 bad = torch.zeros((), dtype=torch.int64, device=dev); dones = torch.zeros_like(bad); rsum = torch.zeros((), dtype=torch.float64, device=dev)
