@@ -50,11 +50,13 @@ def test_lane_independence_and_env_offset_sharding(usim):
 
 
 def test_rollout_random_equals_explicit_actions(usim):
+    """one launch of many steps (up to 256 since round 4; the rollout below is cut at the reset bank's refill period: 256 + 44) == the same steps one launch each"""
     a, b = _env(usim, 512), _env(usim, 512)
     a.reset_tensor(); b.reset_tensor()
-    blk = a.alloc_block(30)
-    a.rollout_random(0, 30, blk)
-    for k in range(30):
+    blk = a.alloc_block(300)
+    a.rollout_random(0, 300, blk)
+    assert int(blk["done"].sum()) > 100                                  # (episodes end and restart inside the launches)
+    for k in range(300):
         act = b.random_actions_tensor(k)
         obs, rew, done = b.step_tensor(act)
         torch.cuda.synchronize()
