@@ -27,15 +27,16 @@ def dual_problem(o, i, act):
     G = np.zeros((3 * nc, nc))
     for c in range(nc):
         G[3 * c:3 * c + 3, c] = g[3 * c:3 * c + 3]
-    A = W @ Li @ W.T + G @ Lm @ G.T
+    Aarm, Alat = W @ Li @ W.T, G @ Lm @ G.T                      # the arm's part (rank <= 6, couples every pair) and the lattice's (element to element)
+    A = Aarm + Alat
     if o.cfg.probe_geoms == 2 and o.cfg.pair_model:
         # the two coincident contacts of every probe-element pair (ultrasound_probe_gripper.xml:8-9) as two contacts: the same rows twice, each with a single
         # contact's regulariser; virtual contact v < nc is contact A of pair v (cone mu_A = the environment's friction word), v >= nc contact B of pair v - nc
         muB = max(o.cfg.probe_friction2, o.cfg.elem_friction)
         A2, R2 = np.block([[A, A], [A, A]]), np.concatenate([R, R])
         return {"nc": 2 * nc, "pairs": nc, "mu": np.concatenate([np.full(nc, out[1]), np.full(nc, muB)]), "W": np.vstack([W, W]), "A": A2, "R": R2,
-                "Q": A2 + np.diag(R2), "b": np.concatenate([b, b])}
-    return {"nc": nc, "pairs": 0, "mu": np.full(nc, out[1]), "W": W, "A": A, "R": R, "Q": A + np.diag(R), "b": b}
+                "Q": A2 + np.diag(R2), "b": np.concatenate([b, b]), "Aarm": Aarm, "Alat": Alat, "Li": Li, "W1": W}
+    return {"nc": nc, "pairs": 0, "mu": np.full(nc, out[1]), "W": W, "A": A, "R": R, "Q": A + np.diag(R), "b": b, "Aarm": Aarm, "Alat": Alat, "Li": Li, "W1": W}
 
 
 def project_cone(f, mus):
