@@ -138,8 +138,9 @@ typedef struct usim_step_io {
     float* ep_return_dev;      /* [n]      SB3 Monitor infos[i]["episode"]["r"]; written where done */
     int32_t* ep_length_dev;    /* [n]      SB3 Monitor infos[i]["episode"]["l"]; written where done */
     float* act_out_dev;        /* [n][A]   usim_rollout_random only: the actions drawn in-kernel (completes the transition) */
-    int32_t* status_dev;       /* [n]      per-environment status word after this step (bits stay set until the episode ends): bit 0 = more than USIM_MAXC simultaneous contacts, bit 2 =
-                                *          numerical fault (non-finite / run-away state; the episode is ended and, with auto_reset, restarted) */
+    int32_t* status_dev;       /* [n]      per-environment status word after this step (bits stay set until the episode ends): bit 0 = more than USIM_MAXC simultaneous probe contacts, bit 1 =
+                                *          (USIM_TORSO_FULL only) more element-table contacts than the kernel keeps (120), bit 2 = numerical fault (non-finite / run-away state of the
+                                *          arm or -- USIM_TORSO_FULL -- of the free torso body or a slider; the episode is ended and, with auto_reset, restarted) */
     float* log_dev;            /* [n][USIM_LOG_WIDTH] per-step episode record, the channels of the reference's save_data CSV dump
                                 *          (ultrasound.py:552-614): ee_pos3 goal_pos3 ee_vel3 goal_vel vbar ee_quat4 goal_quat4 quat_dist Fz goal_Fz
                                 *          Fz_mean dFz goal_dFz is_contact q7 torques7 time% pos/ori/vel/force/dforce reward action7 */

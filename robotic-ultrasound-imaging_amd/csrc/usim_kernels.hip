@@ -1312,6 +1312,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT, (TORSO == 2) ? 2 : 1) void usim_s
             joint_friction(D.M, Lm, idm, qd, C.frictionloss, qs);
 
             float W[6] = {0, 0, 0, 0, 0, 0};          // site-space wrench of the contact forces
+            float full_chk = 0.f;                     // full torso: |free body| + sum |sliders| after the integration, for the numerical fault guard
             if constexpr (TORSO == 2) {
                 // ---------------- full torso (usim_full.h): 270 sliders on the free body, probe and table contacts ----------------
                 float alpha[6], vs[6];
@@ -1322,7 +1323,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT, (TORSO == 2) ? 2 : 1) void usim_s
                     for (int j = 0; j < NJ; ++j) { s = fmaf(J[a][j], qs[j], s); u = fmaf(J[a][j], qd[j], u); }
                     alpha[a] = s; vs[a] = u;
                 }
-                float acc_e[FE], ab[6];
+                float acc_e[FE], ab[6], lat_chk = 0.f;
                 int cel[MAXC], nc = 0, ovf = 0;
                 // (the contact solve starts from the forces of the previous physics step, kept in the environment's lattice block; a reset pass starts cold and leaves none)
                 float* const latp = &LAT(0);
@@ -1355,6 +1356,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT, (TORSO == 2) ? 2 : 1) void usim_s
                     float sdn = 0.f, sn = 0.f;
                     if (pass == 0) { sdn = fmaf(dt, acc_e[i], sd_pre[i]); sn = fmaf(dt, sdn, s_pre[i]); }
                     if (valid && e < NSH && (pass == 0 || !refill)) { LAT(LATF_SD + e) = sdn; LAT(LATF_S + e) = sn; }
+                    if (e < NSH) lat_chk += fabsf(sn) + 1e-3f * fabsf(sdn);
                 }
                 if (pass == 0) {
                     const float qw = body.q[0], qx = body.q[1], qy = body.q[2], qz = body.q[3];
@@ -1372,6 +1374,10 @@ __global__ __launch_bounds__(GroupGeom<G>::NT, (TORSO == 2) ? 2 : 1) void usim_s
                     const float n2 = qw * dy - qx * dz2 + qy * chh + qz * dx, n3 = qw * dz2 + qx * dy - qy * dx + qz * chh;
                     const float irn = rsq_(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
                     body.q[0] = n0 * irn; body.q[1] = n1 * irn; body.q[2] = n2 * irn; body.q[3] = n3 * irn;
+                    // what the numerical fault guard below sees of the torso: the free body's 13 words and every slider (a non-finite word makes the sum non-finite; without
+                    // this a torso gone NaN fails every comparison of full_forward, its contacts vanish silently and the arm -- all the guard used to look at -- stays finite)
+                    full_chk = wave_sum(lat_chk) + fabsf(body.p.x) + fabsf(body.p.y) + fabsf(body.p.z) + fabsf(body.q[0]) + fabsf(body.q[1]) + fabsf(body.q[2]) + fabsf(body.q[3])
+                             + 1e-3f * (fabsf(body.v.x) + fabsf(body.v.y) + fabsf(body.v.z) + fabsf(body.w.x) + fabsf(body.w.y) + fabsf(body.w.z));
                 }
                 if (store && (pass == 0 || !refill)) {
                     const float bw[13] = {body.p.x, body.p.y, body.p.z, body.q[0], body.q[1], body.q[2], body.q[3], body.v.x, body.v.y, body.v.z, body.w.x, body.w.y, body.w.z};
@@ -1583,7 +1589,7 @@ __global__ __launch_bounds__(GroupGeom<G>::NT, (TORSO == 2) ? 2 : 1) void usim_s
                     if (R.overflow) status |= (TORSO == 2) ? (R.overflow & 3) : 1;      // (full torso: bit 1 = more element-table contacts than the kernel keeps)
                     {
                         // numerical fault guard: a non-finite or run-away state ends the episode and is flagged
-                        float chk = 0.f;
+                        float chk = (TORSO == 2) ? full_chk : 0.f;
 #pragma unroll
                         for (int i = 0; i < NJ; ++i) chk += fabsf(q[i]) + 1e-3f * fabsf(qd[i]);
                         if (!(chk < 1.0e3f)) { status |= 4; done = true; epret -= reward; reward = 0.f; if (!(epret == epret)) epret = 0.f; }

@@ -255,7 +255,7 @@ class UltrasoundVecEnv:
 
     @property
     def status(self):
-        """int32 [n] status word of the last step (bit 0: contact-slot overflow, bit 2: numerical fault -> episode ended)"""
+        """int32 [n] status word of the last step (bit 0: contact-slot overflow, bit 1: full torso, element-table contact overflow, bit 2: numerical fault -> episode ended)"""
         return self._status
 
     @property

@@ -52,6 +52,23 @@ def _razor_edge(inf, i):
 
 TABLE_EDGE = 5e-7          # m: full torso -- an element's end sphere this close to the table plane (eight float32 ulps of its 0.8 m coordinates) may touch a step apart in float32 and float64
 
+def _float32_oracle_tail(n, steps, torso, mode, so64, alive, extra):
+    """per-environment distance of the oracle's FLOAT32 build from its float64 build after the same rollout (same seed, same actions), per state field, relative to
+    the field's scale among the live environments -- float32's own tail, measured where it is needed (only when some environment misses the state bar)"""
+    import os
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 64)))
+    kw = {k: v for k, v in extra.items() if k not in ("gpu_extra", "ora_extra", "omp", "precision")}
+    kw.update(extra.get("ora_extra") or {})
+    kw.setdefault("seed", 3); kw.setdefault("robot", "Panda")            # (_mk's defaults)
+    o32 = Oracle(n, precision="f32", omp=True, mode=mode, torso={"soft": "top", "full": "full"}.get(torso, "none"), **kw)
+    o32.reset()
+    for k in range(steps):
+        o32.step(o32.random_actions(k))
+    s32 = o32.get_state()
+    return {key: np.abs(np.asarray(s32[key], dtype=np.float64) - so64[key]).reshape(n, -1).max(1) / max(np.abs(so64[key][alive]).max(), 1e-12)
+            for key in ("q", "qd", "s", "sd") if np.asarray(so64[key]).size}
+
+
 REPORT = None                # a study script sets this to a dict to collect the per-environment state errors instead of asserting the state bars
 
 
@@ -147,6 +164,7 @@ def _run_parity(usim, n, steps, torso, mode, state_rtol=STATE_RTOL, **extra):
             assert np.all(table_edge[over] < TABLE_EDGE), (key, per_env[over], table_edge[over])
             explained += int(over.sum())
             alive &= ~over
+    f32_tail = None
     for key in ("q", "qd", "s", "sd"):
         if np.asarray(sg[key]).size:
             # per environment: largest difference over the field's components, relative to the largest magnitude of the field in the batch
@@ -155,10 +173,18 @@ def _run_parity(usim, n, steps, torso, mode, state_rtol=STATE_RTOL, **extra):
             if REPORT is not None:
                 REPORT[key] = per_env; REPORT[key + "_scale"] = np.abs(b_).max()
                 continue
-            # every environment up to 1024 of them; beyond, float32 itself has a tail -- the oracle's float32 build against its float64 build at 4096 environments x 200
-            # steps leaves 1 (Panda) to 3 (UR5e) environments between 1e-4 and 2.3e-4 on the lattice fields since the arm joints carry rotor inertia and dry friction
-            # (tests/studies/float32_tail.py, profiles/r05/float32_tail.txt) -- : at most one environment per 1024 beyond the bar, none beyond three times it
-            assert int((per_env >= state_rtol).sum()) <= n // 1024 and per_env.max() < 3 * state_rtol, (key, per_env.max(), int((per_env > state_rtol).sum()))
+            # THE BAR, for every environment at every size: north_star's 1e-4.  Float32 itself has a tail at full size since the arm joints carry rotor inertia and dry
+            # friction (a stiff damper around zero joint speed: DESIGN.md section 6) -- an environment beyond the bar is accepted only if float32 ALONE explains it: the
+            # oracle's own float32 build, run here on the same seed and actions, leaves its float64 build by at least half the bar on the same field of the SAME
+            # environment.  At most one such environment per 1024 (one in a smaller batch), none beyond three times the bar.
+            over = np.nonzero(per_env >= state_rtol)[0]
+            if len(over):
+                if f32_tail is None:
+                    f32_tail = _float32_oracle_tail(n, steps, torso, mode, so, alive, extra)
+                idx = np.nonzero(alive)[0][over]
+                assert np.all(f32_tail[key][idx] >= 0.5 * state_rtol) and len(over) <= max(1, n // 1024) and per_env.max() < 3 * state_rtol, \
+                    (key, idx, per_env[over], f32_tail[key][idx])
+                explained += len(over)
     for key in ("t", "episode", "has_touched"):
         assert np.array_equal(np.asarray(sg[key])[alive].astype(int), so[key][alive].astype(int)), key
     if torso == "full":
@@ -303,9 +329,9 @@ def test_every_kernel_mapping_holds_the_full_parity_bars(usim, mapping):
     16-lane kernel in both register budgets, the split kernel with 8-lane groups (two environments per DPP row; automatic beyond 4096
     envs/GPU) -- through the same check as the default split kernel: 200 steps, done flags and contact indices bit-exact, every
     observation channel and the state within the oracle bars (they share the lattice / contact phases, not the arm mathematics)."""
-    # (the 8-lane kernel: 1.5e-4 on the state -- one environment of 256 at 1.17e-4 on the element velocities since the joints carry dry friction; the float32 build of the
-    #  ORACLE leaves its float64 build by 0.9e-4 on that field in this batch, tests/studies/parity_report.py)
-    _run_parity(usim, 256, 200, "soft", "tracking", gpu_extra=mapping, **({"state_rtol": 1.5 * STATE_RTOL} if mapping.get("lanes_per_env") == 8 else {}))
+    # (the 8-lane kernel leaves one environment of 256 at 1.17e-4 on the element velocities since the joints carry dry friction: accepted by _run_parity's rule -- the
+    #  float32 build of the ORACLE leaves its float64 build by 0.9e-4 on that field of that environment -- not by a wider bar)
+    _run_parity(usim, 256, 200, "soft", "tracking", gpu_extra=mapping)
 
 
 def test_residual_is_precision_not_logic(usim):

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Every record of profiles/<round>/ from ONE box and one gpurun call: tools/records.sh <round tag, e.g. r03>   (then tools/records_collect.sh <tag> here)
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 G=$ROOT/gpurun_out; mkdir -p "$G"
 cd "$ROOT"
 python3 -m pytest tests -m gpu -q --tb=line 2>&1 | tail -15 > "$G/${TAG}_gputests.txt"
-"$ROOT/tools/micro/two_wave" > "$G/${TAG}_micro_two_wave.txt" 2>&1
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o "$ROOT/tools/micro/two_wave" "$ROOT/tools/micro/two_wave.hip" && "$ROOT/tools/micro/two_wave" > "$G/${TAG}_micro_two_wave.txt" 2>&1      # (always rebuilt from its source: a stale binary must not write a record)
 # counters first: bench.py quotes profiles/<tag>/traffic.json and issue.json in its roofline object, so they are made from this box's passes before any bench line is recorded
 tools/profile.sh ${TAG}_soft > /dev/null 2>&1
 tools/profile.sh ${TAG}_rigid --workload rigid > /dev/null 2>&1
