@@ -472,6 +472,44 @@ DI float group_allsum(float x) {
     return x;
 }
 
+// Two floats per lane, handled by the packed float32 instructions of the part (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32: both halves in one issue slot): with 8-lane
+// groups a lane carries BOTH contacts of a probe-element pair, and their visits are the same instruction sequence on different data.  Every operation below is the
+// scalar one per component (IEEE fma / mul / add; v_rcp, v_rsq, min, max and the selects run once per half), so a pair visited in one lane has the bits of a pair
+// visited in lanes k and 8 + k of a 16-lane group.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct b2 { bool x, y; };
+template <class T> struct LaneVec;
+template <> struct LaneVec<float> {
+    typedef bool mask;
+    static DI float splat(float a) { return a; }
+    static DI float fma(float a, float b, float c) { return fmaf(a, b, c); }
+    static DI float rcp(float a) { return rcp_(a); }
+    static DI float rsq(float a) { return rsq_(a); }
+    static DI float max(float a, float b) { return fmaxf(a, b); }
+    static DI float min(float a, float b) { return fminf(a, b); }
+    static DI bool gt(float a, float b) { return a > b; }
+    static DI bool lt(float a, float b) { return a < b; }
+    static DI bool both(bool a, bool b) { return bool(int(a) & int(b)); }
+    static DI float sel(bool c, float a, float b) { return c ? a : b; }
+    static DI float hsum(float a) { return a; }                       // sum over the lane's virtual contacts, in their order
+    static DI float nsum(float a) { return -a; }                      // minus that sum, as the scalar code accumulates it: (-a0) - a1
+};
+template <> struct LaneVec<v2f> {
+    typedef b2 mask;
+    static DI v2f splat(float a) { return (v2f)(a); }
+    static DI v2f fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+    static DI v2f rcp(v2f a) { v2f r; r.x = rcp_(a.x); r.y = rcp_(a.y); return r; }
+    static DI v2f rsq(v2f a) { v2f r; r.x = rsq_(a.x); r.y = rsq_(a.y); return r; }
+    static DI v2f max(v2f a, v2f b) { v2f r; r.x = fmaxf(a.x, b.x); r.y = fmaxf(a.y, b.y); return r; }
+    static DI v2f min(v2f a, v2f b) { v2f r; r.x = fminf(a.x, b.x); r.y = fminf(a.y, b.y); return r; }
+    static DI b2 gt(v2f a, v2f b) { return b2{a.x > b.x, a.y > b.y}; }
+    static DI b2 lt(v2f a, v2f b) { return b2{a.x < b.x, a.y < b.y}; }
+    static DI b2 both(b2 a, b2 b) { return b2{bool(int(a.x) & int(b.x)), bool(int(a.y) & int(b.y))}; }
+    static DI v2f sel(b2 c, v2f a, v2f b) { v2f r; r.x = c.x ? a.x : b.x; r.y = c.y ? a.y : b.y; return r; }
+    static DI float hsum(v2f a) { return a.x + a.y; }
+    static DI float nsum(v2f a) { return -a.x - a.y; }
+};
+
 // One contact's block of the Jacobi iteration (oracle: cone_local_solve): from the force f, the residual r of its three rows and its block B (regulariser included),
 // a better force h of the cone |h_t| <= mu h_n for the block's own problem.
 //   (1) ray: exact line minimisation along the current force, f <- (1 + x) f, x >= -1;
@@ -480,43 +518,46 @@ DI float group_allsum(float x) {
 //       function of its inputs (no switch that float32 and float64 could take differently);
 //   (3) friction with the normal fixed: the minimiser of the tangential 2 x 2 problem on the disc |t| <= mu n, t = -(B_tt + lambda I)^-1 r~ in adjugate form, one
 //       Newton step on the secular equation from the contact's lambda of the iteration before, radial clamp.
+// T = float: one contact per lane; T = v2f: the two contacts of a pair (same block, own residual, force, cone and multiplier) in the two halves.
 // Returns whether the contact has a friction disc (lambda is meaningful).
-DI bool cone_local(const float b00, const float b01, const float b02, const float b11, const float b12, const float b22, float r0, float r1, float r2,
-                   const float f0, const float f1, const float f2, const float mu, float& lam, float& h0, float& h1, float& h2) {
-    const float Bf0 = fmaf(b02, f2, fmaf(b01, f1, b00 * f0)), Bf1 = fmaf(b12, f2, fmaf(b11, f1, b01 * f0)), Bf2 = fmaf(b22, f2, fmaf(b12, f1, b02 * f0));
-    const float vr = fmaf(f2, r2, fmaf(f1, r1, f0 * r0)), vBv = fmaf(f2, Bf2, fmaf(f1, Bf1, f0 * Bf0));
+template <class T>
+DI typename LaneVec<T>::mask cone_local(const T b00, const T b01, const T b02, const T b11, const T b12, const T b22, T r0, T r1, T r2,
+                                        const T f0, const T f1, const T f2, const T mu, T& lam, T& h0, T& h1, T& h2) {
+    typedef LaneVec<T> V;
+    const T Bf0 = V::fma(b02, f2, V::fma(b01, f1, b00 * f0)), Bf1 = V::fma(b12, f2, V::fma(b11, f1, b01 * f0)), Bf2 = V::fma(b22, f2, V::fma(b12, f1, b02 * f0));
+    const T vr = V::fma(f2, r2, V::fma(f1, r1, f0 * r0)), vBv = V::fma(f2, Bf2, V::fma(f1, Bf1, f0 * Bf0));
     // (a force below 1e-10 N is left to the second ray: the damped steps of the iteration shrink a force that has to vanish geometrically, and once f0^2 underflows in
     //  float32 the quotient is inf -- oracle: same threshold)
-    const float x = (f0 > 1e-10f) ? fmaxf(-vr * rcp_(vBv), -1.f) : 0.f;
-    r0 = fmaf(x, Bf0, r0); r1 = fmaf(x, Bf1, r1); r2 = fmaf(x, Bf2, r2);
-    float n0 = fmaf(x, f0, f0), n1 = fmaf(x, f1, f1), n2 = fmaf(x, f2, f2);
-    const float rt2 = fmaf(r1, r1, r2 * r2);
-    const float irt = rsq_(fmaxf(rt2, 1e-30f)), rtn = rt2 * irt;
-    const float sl = (int(rt2 > 0.f) & int(r0 < mu * rtn)) ? -mu * irt : 0.f;
-    const float u1 = sl * r1, u2 = sl * r2;                                        // second direction (1, u1, u2)
-    const float Bu0 = fmaf(b02, u2, fmaf(b01, u1, b00)), Bu1 = fmaf(b12, u2, fmaf(b11, u1, b01)), Bu2 = fmaf(b22, u2, fmaf(b12, u1, b02));
-    const float ur = fmaf(u2, r2, fmaf(u1, r1, r0)), uBu = fmaf(u2, Bu2, fmaf(u1, Bu1, Bu0));
-    const float x2 = fmaxf(-ur * rcp_(uBu), 0.f);
-    n0 += x2; n1 = fmaf(x2, u1, n1); n2 = fmaf(x2, u2, n2);
-    r1 = fmaf(x2, Bu1, r1); r2 = fmaf(x2, Bu2, r2);
+    const T x = V::sel(V::gt(f0, V::splat(1e-10f)), V::max(-vr * V::rcp(vBv), V::splat(-1.f)), V::splat(0.f));
+    r0 = V::fma(x, Bf0, r0); r1 = V::fma(x, Bf1, r1); r2 = V::fma(x, Bf2, r2);
+    T n0 = V::fma(x, f0, f0), n1 = V::fma(x, f1, f1), n2 = V::fma(x, f2, f2);
+    const T rt2 = V::fma(r1, r1, r2 * r2);
+    const T irt = V::rsq(V::max(rt2, V::splat(1e-30f))), rtn = rt2 * irt;
+    const T sl = V::sel(V::both(V::gt(rt2, V::splat(0.f)), V::lt(r0, mu * rtn)), -mu * irt, V::splat(0.f));
+    const T u1 = sl * r1, u2 = sl * r2;                                            // second direction (1, u1, u2)
+    const T Bu0 = V::fma(b02, u2, V::fma(b01, u1, b00)), Bu1 = V::fma(b12, u2, V::fma(b11, u1, b01)), Bu2 = V::fma(b22, u2, V::fma(b12, u1, b02));
+    const T ur = V::fma(u2, r2, V::fma(u1, r1, r0)), uBu = V::fma(u2, Bu2, V::fma(u1, Bu1, Bu0));
+    const T x2 = V::max(-ur * V::rcp(uBu), V::splat(0.f));
+    n0 += x2; n1 = V::fma(x2, u1, n1); n2 = V::fma(x2, u2, n2);
+    r1 = V::fma(x2, Bu1, r1); r2 = V::fma(x2, Bu2, r2);
     // friction on the disc |t| <= mu n0
-    const float lim = mu * n0;
+    const T lim = mu * n0;
     // (a friction disc below 1e-7 N is no friction: the multiplier of such a disc is ~ |r~| / lim, and beyond 1e10 the squares below leave float32 -- oracle: same threshold)
-    const bool haslim = lim > 1e-7f;
-    const float q1 = r1 - fmaf(b12, n2, b11 * n1), q2 = r2 - fmaf(b22, n2, b12 * n1);
-    float m11 = b11 + lam, m22 = b22 + lam, det = fmaf(m11, m22, -(b12 * b12));
-    float a1 = fmaf(m22, q1, -(b12 * q2)), a2 = fmaf(m11, q2, -(b12 * q1));
+    const typename V::mask haslim = V::gt(lim, V::splat(1e-7f));
+    const T q1 = r1 - V::fma(b12, n2, b11 * n1), q2 = r2 - V::fma(b22, n2, b12 * n1);
+    T m11 = b11 + lam, m22 = b22 + lam, det = V::fma(m11, m22, -(b12 * b12));
+    T a1 = V::fma(m22, q1, -(b12 * q2)), a2 = V::fma(m11, q2, -(b12 * q1));
     {
-        const float aa = fmaf(a1, a1, a2 * a2);
-        const float aAa = fmaf(m11 * a2, a2, fmaf(m22 * a1, a1, -2.f * b12 * a1 * a2));
-        const float an = aa * rsq_(fmaxf(aa, 1e-30f));
-        lam = fmaxf(fmaf(fmaf(-det, lim, an) * aa, rcp_(fmaxf(lim * aAa, 1e-30f)), lam), 0.f);
+        const T aa = V::fma(a1, a1, a2 * a2);
+        const T aAa = V::fma(m11 * a2, a2, V::fma(m22 * a1, a1, -2.f * b12 * a1 * a2));
+        const T an = aa * V::rsq(V::max(aa, V::splat(1e-30f)));
+        lam = V::max(V::fma(V::fma(-det, lim, an) * aa, V::rcp(V::max(lim * aAa, V::splat(1e-30f))), lam), V::splat(0.f));
     }
-    m11 = b11 + lam; m22 = b22 + lam; det = fmaf(m11, m22, -(b12 * b12));
-    a1 = fmaf(m22, q1, -(b12 * q2)); a2 = fmaf(m11, q2, -(b12 * q1));
-    const float aa = fmaf(a1, a1, a2 * a2);
-    const float sc = -fminf(lim * rsq_(aa), rcp_(det));                            // (v_min keeps the number when aa = 0 makes the product inf or NaN)
-    h0 = n0; h1 = haslim ? a1 * sc : 0.f; h2 = haslim ? a2 * sc : 0.f;
+    m11 = b11 + lam; m22 = b22 + lam; det = V::fma(m11, m22, -(b12 * b12));
+    a1 = V::fma(m22, q1, -(b12 * q2)); a2 = V::fma(m11, q2, -(b12 * q1));
+    const T aa = V::fma(a1, a1, a2 * a2);
+    const T sc = -V::min(lim * V::rsq(aa), V::rcp(det));                           // (v_min keeps the number when aa = 0 makes the product inf or NaN)
+    h0 = n0; h1 = V::sel(haslim, a1 * sc, V::splat(0.f)); h2 = V::sel(haslim, a2 * sc, V::splat(0.f));
     return haslim;
 }
 
@@ -788,14 +829,16 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
     //      (cone_local: ray update with an immediate restart from zero, friction QCQP with one Newton step on the carried multiplier).  The step along d = f^ - f is
     //      t = (sum_v d_v'B_v d_v) / (d'Qd) <= 1 (the exact minimiser of the quadratic when every block is solved exactly, never longer) -- a convex combination of feasible points, no projection --; the shared residual moves by t A D,
     //      D_k = d_Ak + d_Bk (three row broadcasts and nine multiply-adds per pair: the only part that grows with the contact count).  pgs_iters iterations, cold start.
-    constexpr int NVL = CLONE ? 1 : 2;                           // virtual contacts per lane
+    // Virtual contacts per lane: one (16-lane groups: contact A of pair k in lane k, contact B in lane 8 + k) or two (8-lane groups: both in lane k, in the two halves
+    // of packed registers -- one visit for the pair at the issue cost of ~1.2 instead of two: round 6).
+    typedef typename std::conditional<CLONE, float, v2f>::type VT;
+    typedef LaneVec<VT> V;
     const bool pairB = C.pair != 0;
     const float muB = fmaxf(C.probe_fric2, C.elem_fric);
-    bool ownv[NVL]; float muv[NVL], fv[NVL][3], lamv[NVL];
-    if constexpr (CLONE) { ownv[0] = own && (gl < 8 || pairB); muv[0] = (gl < 8) ? mu : muB; }
-    else { ownv[0] = own; ownv[1] = own && pairB; muv[0] = mu; muv[1] = muB; }
-#pragma unroll
-    for (int v = 0; v < NVL; ++v) { fv[v][0] = fv[v][1] = fv[v][2] = 0.f; lamv[v] = 0.f; }
+    typename V::mask ownv; VT muv, fv[3], lamv = V::splat(0.f);
+    if constexpr (CLONE) { ownv = own && (gl < 8 || pairB); muv = (gl < 8) ? mu : muB; }
+    else { ownv = b2{own, own && pairB}; muv.x = mu; muv.y = muB; }
+    fv[0] = fv[1] = fv[2] = V::splat(0.f);
     // the lane's own diagonal block, regulariser included
     float b00 = 0.f, b01 = 0.f, b02 = 0.f, b11 = 0.f, b12 = 0.f, b22 = 0.f;
 #pragma unroll
@@ -809,24 +852,23 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
     b00 += Rd[0]; b11 += Rd[1]; b22 += Rd[2];
     auto iterations = [&](auto NCM_) {
         constexpr int NCM = decltype(NCM_)::value;
+        const VT vb00 = V::splat(b00), vb01 = V::splat(b01), vb02 = V::splat(b02), vb11 = V::splat(b11), vb12 = V::splat(b12), vb22 = V::splat(b22);
+        const VT vR0 = V::splat(Rd[0]), vR1 = V::splat(Rd[1]), vR2 = V::splat(Rd[2]);
         for (int it = 0; it < C.pgs_iters; ++it) {
-            float dv[NVL][3], num, D0, D1, D2;
-#pragma unroll
-            for (int v = 0; v < NVL; ++v) {
-                const float r0 = fmaf(Rd[0], fv[v][0], cres[0]), r1 = fmaf(Rd[1], fv[v][1], cres[1]), r2 = fmaf(Rd[2], fv[v][2], cres[2]);
-                float h0, h1, h2, lam = lamv[v];
-                const bool haslim = cone_local(b00, b01, b02, b11, b12, b22, r0, r1, r2, fv[v][0], fv[v][1], fv[v][2], muv[v], lam, h0, h1, h2);
-                lamv[v] = (ownv[v] && haslim) ? lam : lamv[v];
-                dv[v][0] = ownv[v] ? h0 - fv[v][0] : 0.f; dv[v][1] = ownv[v] ? h1 - fv[v][1] : 0.f; dv[v][2] = ownv[v] ? h2 - fv[v][2] : 0.f;
+            VT dv[3];
+            float num, D0, D1, D2;
+            {
+                const VT r0 = V::fma(vR0, fv[0], V::splat(cres[0])), r1 = V::fma(vR1, fv[1], V::splat(cres[1])), r2 = V::fma(vR2, fv[2], V::splat(cres[2]));
+                VT h0, h1, h2, lam = lamv;
+                const typename V::mask haslim = cone_local<VT>(vb00, vb01, vb02, vb11, vb12, vb22, r0, r1, r2, fv[0], fv[1], fv[2], muv, lam, h0, h1, h2);
+                lamv = V::sel(V::both(ownv, haslim), lam, lamv);
+                dv[0] = V::sel(ownv, h0 - fv[0], V::splat(0.f)); dv[1] = V::sel(ownv, h1 - fv[1], V::splat(0.f)); dv[2] = V::sel(ownv, h2 - fv[2], V::splat(0.f));
                 // slope of the cost along d, block by block: -d'B d (for the minimiser of a block r.d <= -d'B d, with equality inside the cone) -- a sum of squares
                 // instead of r.d, whose products cancel to second order for a sliding contact and are float32 noise once |d| < 5e-3 N (oracle: same lines)
-                {
-                    const float e0 = dv[v][0], e1 = dv[v][1], e2 = dv[v][2];
-                    const float Be0 = fmaf(b02, e2, fmaf(b01, e1, b00 * e0)), Be1 = fmaf(b12, e2, fmaf(b11, e1, b01 * e0)), Be2 = fmaf(b22, e2, fmaf(b12, e1, b02 * e0));
-                    const float eBe = fmaf(e2, Be2, fmaf(e1, Be1, e0 * Be0));
-                    num = (v == 0) ? -eBe : num - eBe;            // (no 0 + x: the compiler may not fold it -- signed zeros -- and an instruction here is paid 24 times per step)
-                }
-                D0 = (v == 0) ? dv[v][0] : D0 + dv[v][0]; D1 = (v == 0) ? dv[v][1] : D1 + dv[v][1]; D2 = (v == 0) ? dv[v][2] : D2 + dv[v][2];
+                const VT e0 = dv[0], e1 = dv[1], e2 = dv[2];
+                const VT Be0 = V::fma(vb02, e2, V::fma(vb01, e1, vb00 * e0)), Be1 = V::fma(vb12, e2, V::fma(vb11, e1, vb01 * e0)), Be2 = V::fma(vb22, e2, V::fma(vb12, e1, vb02 * e0));
+                num = V::nsum(V::fma(e2, Be2, V::fma(e1, Be1, e0 * Be0)));          // (no 0 + x: the compiler may not fold it -- signed zeros -- and an instruction here is paid 24 times per step)
+                D0 = V::hsum(dv[0]); D1 = V::hsum(dv[1]); D2 = V::hsum(dv[2]);
             }
             if constexpr (CLONE) {                                       // D_k = d_Ak + d_Bk in both halves
                 D0 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(D0), 0x128, 0xf, 0xf, true));
@@ -841,16 +883,10 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
                 q1 = fmaf(B[k][1][2], e2, fmaf(B[k][1][1], e1, fmaf(B[k][1][0], e0, q1)));
                 q2 = fmaf(B[k][2][2], e2, fmaf(B[k][2][1], e1, fmaf(B[k][2][0], e0, q2)));
             }
-            float den;
-#pragma unroll
-            for (int v = 0; v < NVL; ++v) {
-                const float dQd = fmaf(dv[v][2], fmaf(Rd[2], dv[v][2], q2), fmaf(dv[v][1], fmaf(Rd[1], dv[v][1], q1), dv[v][0] * fmaf(Rd[0], dv[v][0], q0)));
-                den = (v == 0) ? dQd : den + dQd;
-            }
+            float den = V::hsum(V::fma(dv[2], V::fma(vR2, dv[2], V::splat(q2)), V::fma(dv[1], V::fma(vR1, dv[1], V::splat(q1)), dv[0] * V::fma(vR0, dv[0], V::splat(q0)))));
             num = group_allsum<G>(num); den = group_allsum<G>(den);
             const float t = (den > 0.f) ? fminf(-num * rcp_(den), 1.f) : 0.f;
-#pragma unroll
-            for (int v = 0; v < NVL; ++v) { fv[v][0] = fmaf(t, dv[v][0], fv[v][0]); fv[v][1] = fmaf(t, dv[v][1], fv[v][1]); fv[v][2] = fmaf(t, dv[v][2], fv[v][2]); }
+            fv[0] = V::fma(V::splat(t), dv[0], fv[0]); fv[1] = V::fma(V::splat(t), dv[1], fv[1]); fv[2] = V::fma(V::splat(t), dv[2], fv[2]);
             cres[0] = fmaf(t, q0, cres[0]); cres[1] = fmaf(t, q1, cres[1]); cres[2] = fmaf(t, q2, cres[2]);
         }
     };
@@ -868,10 +904,10 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
     // the pair's total force (lanes 0-7 of a 16-lane group: contact A's own force plus contact B's from lane 8 + k)
     if constexpr (CLONE) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) f[d] = fv[0][d] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(fv[0][d]), 0x128, 0xf, 0xf, true));
+        for (int d = 0; d < 3; ++d) f[d] = fv[d] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(fv[d]), 0x128, 0xf, 0xf, true));
     } else {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) f[d] = fv[0][d] + fv[1][d];
+        for (int d = 0; d < 3; ++d) f[d] = V::hsum(fv[d]);
     }
     USIM_STAMP(dbg, 10);
     USIM_CSTAMP(dbg, 3);
