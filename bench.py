@@ -247,7 +247,7 @@ def main():
     achieved_gbs = ALGO_BYTES[args.workload] * n / avg_kernel_s / 1e9
 
     traffic_step = None
-    tfile = next((f for f in (ROOT / "profiles" / r / "traffic.json" for r in ("r05", "r04", "r03", "r02", "r01")) if f.exists()), ROOT / "profiles" / "r05" / "traffic.json")
+    tfile = next((f for f in (ROOT / "profiles" / r / "traffic.json" for r in ("r06", "r05", "r04", "r03", "r02", "r01")) if f.exists()), ROOT / "profiles" / "r06" / "traffic.json")
     if tfile.exists() and n == 4096:
         try:
             tj = json.loads(tfile.read_text()).get(args.workload)

@@ -191,6 +191,17 @@ def test_full_torso_checkpoint_determinism_and_auto_reset(usim):
     e.close()
 
 
+def test_full_torso_rejects_the_configurations_it_does_not_run(usim):
+    """torso="full" runs the Panda at control_freq 500 (the reference's callers: rl_config.yaml:26, robots Panda); the UR5e (ultrasound.py:137) and control_freq below
+    500 (ultrasound.py:119: physics substeps) are refused at creation with USIM_ERR_UNSUPPORTED and a message, not run as something else; the top-face model runs both."""
+    kw = usim.default_robosuite_kwargs()
+    for bad in (dict(robots="UR5e"), dict(control_freq=20), dict(control_freq=100)):
+        with pytest.raises(RuntimeError, match="(?i)unsupported.*USIM_TORSO_FULL|USIM_TORSO_FULL.*Panda"):
+            usim.UltrasoundVecEnv(32, device="cuda:0", seed=1, torso="full", **dict(kw, **bad))
+        usim.UltrasoundVecEnv(32, device="cuda:0", seed=1, torso="soft", **dict(kw, **bad)).close()
+    usim.UltrasoundVecEnv(32, device="cuda:0", seed=1, torso="full", **kw).close()
+
+
 def test_full_torso_numerical_fault_guard(usim):
     """The fault guard sees the torso: a non-finite word in the free body's state or in a slider ends the episode with status bit 2 and the environment restarts clean
     (free body at the spawn pose, sliders at rest, no warm start), its neighbours untouched.  (Until round 6 the guard looked at the arm only: a torso gone NaN fails

@@ -2,7 +2,7 @@
 # rocprofv3 runs of the FULL-torso workload (bench.py --workload full) for profiles/: kernel-trace stats + two PMC passes (run on the GPU box via gpurun)
 # usage: tools/profile_full.sh <tag>
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_full_$TAG
 mkdir -p "$OUT"

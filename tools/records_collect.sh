@@ -1,6 +1,6 @@
 #!/bin/bash
 # copies what tools/records.sh left in gpurun_out/ into profiles/<tag>/ under the names the documents cite
-TAG=${1:-r05}; cd "$(dirname "$0")/.."; G=gpurun_out; P=profiles/$TAG; mkdir -p $P
+TAG=${1:-r06}; cd "$(dirname "$0")/.."; G=gpurun_out; P=profiles/$TAG; mkdir -p $P
 cp $G/bench_matrix.txt $P/bench_matrix.txt
 cp $G/${TAG}_bench_soft.json $P/bench_soft.json; cp $G/${TAG}_bench_driver.json $P/bench_soft_driver_style.json
 cp $G/${TAG}_bench_rigid.json $P/bench_rigid.json; cp $G/${TAG}_bench_config5.json $P/bench_config5_8192_randomised.json
