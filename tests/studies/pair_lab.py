@@ -15,6 +15,8 @@ against the independent optimum (tests/cone_qp.py):
                                                                                            against R_t = 0.09 /kg; the review's bars (99 % / worst) are reached at 11 - 12 passes of >= 2 visits: no gain
   arm      model blocks with the arm's part scaled by the number of pairs                   -> worse
   momentum Nesterov / constant extrapolation of the point the visits are evaluated at       -> worse (the exact line search already is the one-dimensional Krylov step)
+  cheap    a cheaper visit: the friction step without the multiplier's Newton step (unconstrained tangential minimiser, radial clamp), or without the first ray
+                                                                                        -> rests 0.5 - 10 N from the optimum: the visit's fixed point is the optimum only with both
   newton   MuJoCo's own road: Newton on the primal (6 site + nc element accelerations), exact line search -> 5 - 6 iterations to 1e-3 / 4e-2 N, each a (6 + nc)^2 Hessian assembly,
                                                                                            a factorisation and a piecewise line search: ~4 Jacobi iterations of instructions apiece on one wave
 Conclusion: no visit of comparable cost reaches the bars in <= 12 iterations; block Jacobi + line search at one visit per pass stays.
@@ -52,7 +54,26 @@ def load_sets():
     return pickle.loads(CACHE.read_bytes()) if CACHE.exists() else build_sets()
 
 
-def jacobi(P, iters, K=None, arm_scale=0.0, beta=0.0, trace=None, history=False):
+def local_solve_cheap(B, r, f, mu, lam, ray1=True):
+    """solver_lab.local_solve with pieces left out (what does a visit need for its fixed point to be the optimum?): the friction step is the unconstrained tangential
+    minimiser clamped radially (no multiplier); ray1 = False also drops the ray along the current force"""
+    fc = f.copy()
+    if ray1 and f[0] > 1e-10:
+        Bf = B @ f; x = max(-1.0, -(f @ r) / (f @ Bf)); fc = f + x * f; r = r + x * Bf
+    rtn = np.hypot(r[1], r[2])
+    v = np.array([1.0, -mu * r[1] / rtn, -mu * r[2] / rtn]) if (rtn > 0 and r[0] < mu * rtn) else np.array([1.0, 0.0, 0.0])
+    Bv = B @ v; x = -(v @ r) / (v @ Bv); x = max(0.0, x) if ray1 else max(x, -fc[0])
+    fc = fc + x * v; r = r + x * Bv
+    lim = mu * fc[0]; t = np.zeros(2)
+    if lim > 1e-7:
+        Btt = B[1:, 1:]; q = r[1:] - Btt @ fc[1:]
+        t = -np.linalg.solve(Btt, q); tn = np.hypot(*t)
+        if tn > lim:
+            t = t * lim / tn
+    return np.array([fc[0], t[0], t[1]]), lam
+
+
+def jacobi(P, iters, K=None, arm_scale=0.0, beta=0.0, trace=None, history=False, visit=None):
     """round 5's iteration; K (3 x 3 weights on A_cc) / arm_scale give the visits a MODEL block, beta extrapolates the point the visits are evaluated at"""
     Q, b, mu, nv, R, nc = P["Q"], P["b"], P["mu"], P["nc"], P["R"], P["pairs"]
     f = np.zeros(3 * nv); lam = np.zeros(nv); p = np.zeros(3 * nv); hist = []
@@ -66,7 +87,7 @@ def jacobi(P, iters, K=None, arm_scale=0.0, beta=0.0, trace=None, history=False)
         r = Q @ y + b; fh = f.copy()
         for v in range(nv):
             i = slice(3 * v, 3 * v + 3)
-            fh[i], lam[v] = local_solve(Bm[v], r[i] + Bm[v] @ (f[i] - y[i]), f[i], mu[v], lam[v])
+            fh[i], lam[v] = (visit or local_solve)(Bm[v], r[i] + Bm[v] @ (f[i] - y[i]), f[i], mu[v], lam[v])
         d = fh - f; den = d @ Q @ d
         num = (Q @ f + b) @ d if beta else -sum(d[3 * v:3 * v + 3] @ Bm[v] @ d[3 * v:3 * v + 3] for v in range(nv))
         t = max(0.0, min(1.0, -num / den)) if den > 0 else 0.0
@@ -191,6 +212,8 @@ if __name__ == "__main__":
         cands += [(f"arm part x (1 + {s} (pairs - 1)), {k}", lambda p, k=k, s=s: jacobi(p, k, arm_scale=s)) for s in (0.3, 1.0) for k in (12, 16)]
         cands += [(f"extrapolated by {bt}, {k}", lambda p, k=k, bt=bt: jacobi(p, k, beta=bt)) for bt in (0.2, 0.4) for k in (12, 16)]
         cands += [(f"gs inside the pair, {k}", lambda p, k=k: pair_block(p, k, 1)) for k in (8, 10, 12)]
+        cands += [(f"cheap visit: friction step clamped, no multiplier, {k}", lambda p, k=k: jacobi(p, k, visit=local_solve_cheap)) for k in (16, 24)]
+        cands += [(f"cheap visit: no first ray, {k}", lambda p, k=k: jacobi(p, k, visit=lambda *a: local_solve_cheap(*a, ray1=False))) for k in (16, 24)]
         for name, fn in cands:
             print(f"  {name:44s} " + errs(sets, fn), flush=True)
     if what in ("pair", "all"):
