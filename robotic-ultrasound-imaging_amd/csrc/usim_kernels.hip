@@ -97,6 +97,20 @@ DI float group_bcast(float v, int k) {
     return __int_as_float(iv);
 }
 #undef USIM_BCAST_CASE
+// 16-lane groups: lanes 0-7 of the row receive the value of lane J, lanes 8-15 that of lane 4 + J (J = 0..3, a compile-time constant after unrolling): two bank-masked
+// v_mov_b32_dpp row_newbcast
+DI float half_bcast(float v, int J) {
+    const int iv = __float_as_int(v);
+    int r = iv;
+    switch (J) {
+        case 0: { const int t = __builtin_amdgcn_mov_dpp(iv, 0x150 + 0, 0xf, 0x3, false); r = __builtin_amdgcn_update_dpp(t, iv, 0x150 + 4, 0xf, 0xc, false); } break;
+        case 1: { const int t = __builtin_amdgcn_mov_dpp(iv, 0x150 + 1, 0xf, 0x3, false); r = __builtin_amdgcn_update_dpp(t, iv, 0x150 + 5, 0xf, 0xc, false); } break;
+        case 2: { const int t = __builtin_amdgcn_mov_dpp(iv, 0x150 + 2, 0xf, 0x3, false); r = __builtin_amdgcn_update_dpp(t, iv, 0x150 + 6, 0xf, 0xc, false); } break;
+        case 3: { const int t = __builtin_amdgcn_mov_dpp(iv, 0x150 + 3, 0xf, 0x3, false); r = __builtin_amdgcn_update_dpp(t, iv, 0x150 + 7, 0xf, 0xc, false); } break;
+        default: break;
+    }
+    return __int_as_float(r);
+}
 
 // phase timeline probe (diagnostics only; profiling build): wave 0 of workgroup 0 stamps the shader clock when a buffer is given
 #if !defined(USIM_TSTAMP) && !defined(USIM_TSTAMP_NOWAIT)
@@ -724,7 +738,12 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
     //      free by now); every lane then reads contact k's record with six 16-byte broadcast reads -- a quarter of the issue slots the 21 DPP
     //      broadcasts took --, the reads of contact k + 1 in flight while the block of contact k is formed.
     const int ncr = ncmax;                                        // (the iterations run exactly the wave's largest contact count)
-    float B[MAXC][3][3];            // B[k] = d(residual of this lane's rows) / d(force on contact k), WITHOUT the regulariser; written and read only under k < ncr
+    // B[k] = d(residual of this lane's rows) / d(force on contact k), WITHOUT the regulariser; written and read only under k < ncr.  16-lane groups keep FOUR blocks per
+    // lane (round 6): those of contacts 0-3 in both halves while the wave has at most four contacts, those of contacts 0-3 in lanes 0-7 and of contacts 4-7 in lanes 8-15
+    // beyond -- each half then sums its own four products of an iteration and one rotation adds the halves (below).
+    constexpr int NB = CLONE ? 4 : MAXC;
+    float B[NB][3][3];
+    float b00 = 0.f, b01 = 0.f, b02 = 0.f, b11 = 0.f, b12 = 0.f, b22 = 0.f;      // the lane's own diagonal block (regulariser added below)
     static_assert(MAXC * 24 <= GE_SD, "Delassus records overlay the rhs / staging area");
     if (gl < MAXC) {
         float4* pub = reinterpret_cast<float4*>(&EB(gl * 24));
@@ -734,13 +753,13 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
     }
     group_sync();
     if constexpr (CLONE) {
-        // Both halves of the group need every block (lane k carries contact A of pair k, lane 8 + k contact B: the same rows).  Up to four contacts in the wave: both
-        // halves form blocks 0-3 (the same instructions: no cost).  More: lanes 0-7 form the blocks of contacts 0-3, lanes 8-15 those of contacts 4-7, and one rotation
-        // of the DPP row by eight lanes per word brings each half the other's.  Same multiply-adds per block in the same order either way: the same bits.
+        // Lane k carries contact A of pair k, lane 8 + k contact B: the same rows.  Up to four contacts in the wave: both halves form blocks 0-3 (the same instructions:
+        // no cost).  More: lanes 0-7 form the blocks of contacts 0-3, lanes 8-15 those of contacts 4-7 -- and keep them (rounds 3-5 rotated every block to the other half:
+        // 36 rotations, 72 selects and 36 more registers per lane; the iteration below no longer needs them).  A slot beyond an environment's count holds zeros (its lane
+        // published zero rows), so its block is exactly zero.
         const bool hi = gl >= 8;
         const bool wide = ncr > 4;                                       // (wave-uniform)
         const int k0 = (hi && wide) ? 4 : 0;
-        float X[4][3][3];
         float4 rk[6];
         {
             const float4* src = reinterpret_cast<const float4*>(&EB(k0 * 24));
@@ -765,29 +784,20 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
                     for (int d = 0; d < 3; ++d) {
                         float r1 = fmaf(w[d][4], Lk[dd][4], fmaf(w[d][2], Lk[dd][2], w[d][0] * Lk[dd][0]));
                         float r2 = fmaf(w[d][5], Lk[dd][5], fmaf(w[d][3], Lk[dd][3], w[d][1] * Lk[dd][1]));
-                        X[j][d][dd] = fmaf(g[d], gk[dd], r1 + r2);
+                        B[j][d][dd] = fmaf(g[d], gk[dd], r1 + r2);
                     }
                 }
+                // the lane's own diagonal block, if this half formed it (cl - k0 == j); otherwise the partner lane (the other half, same cl) did: one rotation below
+                const bool me = (cl - k0) == j;
+                b00 = me ? B[j][0][0] : b00; b01 = me ? B[j][0][1] : b01; b02 = me ? B[j][0][2] : b02;
+                b11 = me ? B[j][1][1] : b11; b12 = me ? B[j][1][2] : b12; b22 = me ? B[j][2][2] : b22;
             }
         }
-        if (!wide) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int d = 0; d < 3; ++d)
-#pragma unroll
-                    for (int dd = 0; dd < 3; ++dd) B[j][d][dd] = X[j][d][dd];      // (a renaming: slots beyond ncr hold whatever X held and are never read)
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int d = 0; d < 3; ++d)
-#pragma unroll
-                    for (int dd = 0; dd < 3; ++dd) {
-                        const float rot = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X[j][d][dd]), 0x128, 0xf, 0xf, true));   // row_ror:8
-                        B[j][d][dd] = hi ? rot : X[j][d][dd];
-                        B[4 + j][d][dd] = hi ? X[j][d][dd] : rot;
-                    }
+        if (wide) {
+            // (exactly one lane of a pair holds the block, the other holds zeros: x + 0)
+            b00 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b00), 0x128, 0xf, 0xf, true)); b01 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b01), 0x128, 0xf, 0xf, true));
+            b02 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b02), 0x128, 0xf, 0xf, true)); b11 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b11), 0x128, 0xf, 0xf, true));
+            b12 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b12), 0x128, 0xf, 0xf, true)); b22 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b22), 0x128, 0xf, 0xf, true));
         }
     } else {
     float4 rk[6];
@@ -840,13 +850,14 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
     else { ownv = b2{own, own && pairB}; muv.x = mu; muv.y = muB; }
     fv[0] = fv[1] = fv[2] = V::splat(0.f);
     // the lane's own diagonal block, regulariser included
-    float b00 = 0.f, b01 = 0.f, b02 = 0.f, b11 = 0.f, b12 = 0.f, b22 = 0.f;
+    if constexpr (!CLONE) {
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
-        if (k < ncr) {
-            const bool me = cl == k;
-            b00 = me ? B[k][0][0] : b00; b01 = me ? B[k][0][1] : b01; b02 = me ? B[k][0][2] : b02;
-            b11 = me ? B[k][1][1] : b11; b12 = me ? B[k][1][2] : b12; b22 = me ? B[k][2][2] : b22;
+        for (int k = 0; k < MAXC; ++k) {
+            if (k < ncr) {
+                const bool me = cl == k;
+                b00 = me ? B[k][0][0] : b00; b01 = me ? B[k][0][1] : b01; b02 = me ? B[k][0][2] : b02;
+                b11 = me ? B[k][1][1] : b11; b12 = me ? B[k][1][2] : b12; b22 = me ? B[k][2][2] : b22;
+            }
         }
     }
     b00 += Rd[0]; b11 += Rd[1]; b22 += Rd[2];
@@ -875,13 +886,41 @@ DI void contact_solve(float* lds, const int eb, const int gl, const DevModel& M,
                 D1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(D1), 0x128, 0xf, 0xf, true));
                 D2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(D2), 0x128, 0xf, 0xf, true));
             }
+            // q = A D.  Up to four contacts: one running sum over them.  More: the sum over contacts 0-3 plus the sum over contacts 4-7 -- in that association in EVERY mapping
+            // (an environment's bits must not depend on its wave's neighbours: for one with at most four contacts the second sum is exact zeros) -- which a 16-lane group
+            // evaluates in its two halves at once: lanes 0-7 take D_j, lanes 8-15 D_(4+j) from the same row (two bank-masked broadcasts per word), each half multiplies with
+            // the four blocks it formed, one rotation by eight lanes adds the halves.  Eight contacts: 63 instructions instead of 96 (round 5), six: 63 / 72.
             float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+            if constexpr (NCM <= 4) {
 #pragma unroll
-            for (int k = 0; k < NCM; ++k) {
-                const float e0 = group_bcast<G>(D0, k), e1 = group_bcast<G>(D1, k), e2 = group_bcast<G>(D2, k);
-                q0 = fmaf(B[k][0][2], e2, fmaf(B[k][0][1], e1, fmaf(B[k][0][0], e0, q0)));
-                q1 = fmaf(B[k][1][2], e2, fmaf(B[k][1][1], e1, fmaf(B[k][1][0], e0, q1)));
-                q2 = fmaf(B[k][2][2], e2, fmaf(B[k][2][1], e1, fmaf(B[k][2][0], e0, q2)));
+                for (int k = 0; k < NCM; ++k) {
+                    const float e0 = group_bcast<G>(D0, k), e1 = group_bcast<G>(D1, k), e2 = group_bcast<G>(D2, k);
+                    q0 = fmaf(B[k][0][2], e2, fmaf(B[k][0][1], e1, fmaf(B[k][0][0], e0, q0)));
+                    q1 = fmaf(B[k][1][2], e2, fmaf(B[k][1][1], e1, fmaf(B[k][1][0], e0, q1)));
+                    q2 = fmaf(B[k][2][2], e2, fmaf(B[k][2][1], e1, fmaf(B[k][2][0], e0, q2)));
+                }
+            } else if constexpr (CLONE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float e0 = half_bcast(D0, j), e1 = half_bcast(D1, j), e2 = half_bcast(D2, j);
+                    q0 = fmaf(B[j][0][2], e2, fmaf(B[j][0][1], e1, fmaf(B[j][0][0], e0, q0)));
+                    q1 = fmaf(B[j][1][2], e2, fmaf(B[j][1][1], e1, fmaf(B[j][1][0], e0, q1)));
+                    q2 = fmaf(B[j][2][2], e2, fmaf(B[j][2][1], e1, fmaf(B[j][2][0], e0, q2)));
+                }
+                q0 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q0), 0x128, 0xf, 0xf, true));
+                q1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q1), 0x128, 0xf, 0xf, true));
+                q2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q2), 0x128, 0xf, 0xf, true));
+            } else {
+                float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < NCM; ++k) {
+                    const float e0 = group_bcast<G>(D0, k), e1 = group_bcast<G>(D1, k), e2 = group_bcast<G>(D2, k);
+                    float& a0 = (k < 4) ? q0 : h0; float& a1 = (k < 4) ? q1 : h1; float& a2 = (k < 4) ? q2 : h2;
+                    a0 = fmaf(B[k][0][2], e2, fmaf(B[k][0][1], e1, fmaf(B[k][0][0], e0, a0)));
+                    a1 = fmaf(B[k][1][2], e2, fmaf(B[k][1][1], e1, fmaf(B[k][1][0], e0, a1)));
+                    a2 = fmaf(B[k][2][2], e2, fmaf(B[k][2][1], e1, fmaf(B[k][2][0], e0, a2)));
+                }
+                q0 += h0; q1 += h1; q2 += h2;
             }
             float den = V::hsum(V::fma(dv[2], V::fma(vR2, dv[2], V::splat(q2)), V::fma(dv[1], V::fma(vR1, dv[1], V::splat(q1)), dv[0] * V::fma(vR0, dv[0], V::splat(q0)))));
             num = group_allsum<G>(num); den = group_allsum<G>(den);
