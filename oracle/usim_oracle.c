@@ -834,6 +834,10 @@ static real solimp_d(real r) {
  * [0] nc, [1] mu, [2..37] Lam^-1 = J M^-1 J^T (6x6), then per row r = 3 c + d (USO_MAXC * 3 rows): w[6], g, R, b (residual at zero force), element index,
  * then the (USO_MAXC x USO_MAXC) block of L^-1 / m between the contacts' elements */
 static double* g_dual_dump = 0;
+/* study hook (uso_debug_full): when set, constrained_forward_full writes its dual problem here: [0] nv2 (virtual contacts), [1] nc (probe pairs), [2] table contacts, then
+ * Q (3 nv2 x 3 nv2, regulariser on the diagonal), b (residual at zero force), mu (nv2), the warm start (3 nv2 forces, nv2 multipliers), and per row the 12 rigid coordinates
+ * it acts on: the torso body's 6 (jt) and the arm's site 6 (w; zero for a table contact) */
+static double* g_full_dump = 0; static long g_full_cap = 0;
 #define DUAL_ROW 10
 #define DUAL_SIZE (2 + 36 + USO_MAXC * 3 * DUAL_ROW + USO_MAXC * USO_MAXC)
 
@@ -1542,6 +1546,21 @@ static void constrained_forward_full(const Sim* S, const Env* E, const KinDyn* k
                     }
                 }
             }
+            if (g_full_dump && 3 + (long)nr2 * nr2 + (long)nr2 * 14 + 2L * nv2 <= g_full_cap) {
+                double* D = g_full_dump; long o = 3;
+                D[0] = nv2; D[1] = nc; D[2] = nt_c;
+                for (long i = 0; i < (long)nr2 * nr2; i++) D[o + i] = (double)Q2[i];
+                o += (long)nr2 * nr2;
+                for (int i = 0; i < nr2; i++) D[o + i] = (double)res2[i];
+                o += nr2;
+                for (int v = 0; v < nv2; v++) D[o + v] = (double)mu2[v];
+                o += nv2;
+                for (int i = 0; i < nr2; i++) D[o + i] = (double)f2[i / 3][i % 3];
+                o += nr2;
+                for (int v = 0; v < nv2; v++) D[o + v] = (double)lam2[v];
+                o += nv2;
+                for (int i2 = 0; i2 < nr2; i2++) { const int i = i2 < nr ? i2 : i2 - nr; for (int a = 0; a < 6; a++) { D[o + (long)i2 * 12 + a] = (double)jt[i][a]; D[o + (long)i2 * 12 + 6 + a] = (double)w[i][a]; } }
+            }
             for (int i2 = 0; i2 < nr2; i2++) { real sacc = 0; for (int j2 = 0; j2 < nr2; j2++) sacc += Q2[(size_t)i2 * nr2 + j2] * f2[j2 / 3][j2 % 3]; res2[i2] += sacc; }
             cone_pgs_dense(nv2, Q2, nr2, res2, mu2, S->cfg.pgs_iters, f2, lam2);
             for (int v = 0; v < nv; v++) for (int d = 0; d < 3; d++) fv[v][d] = f2[v][d] + ((pairs && v < nc) ? f2[nv + v][d] : 0);
@@ -2071,6 +2090,20 @@ int uso_debug_dual(void* h, int env, const double* act_d, double* out) {
     Pass P; forward_pass(S, &T, act, act_d ? 0 : 1, &P);
     g_dual_dump = 0;
     return P.f.ncon;
+}
+/* study hook: the full torso's dual problem at the CURRENT state of `env` under the action `act` (layout at g_full_dump; out holds cap doubles); returns the number of
+ * virtual contacts, 0 if the buffer is too small.  Not thread-safe. */
+int uso_debug_full(void* h, int env, const double* act_d, double* out, long cap) {
+    Sim* S = (Sim*)h; Env* E = &S->env[env];
+    if (S->cfg.torso != USO_TORSO_FULL) return -1;
+    real act[8] = {0};
+    for (int a = 0; a < S->adim; a++) act[a] = (real)act_d[a];
+    Env T = *E; T.t += 1;
+    out[0] = 0;
+    g_full_dump = out; g_full_cap = cap;
+    Pass P; forward_pass(S, &T, act, 0, &P);
+    g_full_dump = 0;
+    return (int)out[0];
 }
 int uso_element_distances(void* h, int env, double* dist_out, int32_t* contacts_out) {
     Sim* S = (Sim*)h; Env* E = &S->env[env];
