@@ -139,6 +139,11 @@ int uso_debug_forward(void* h, int env, double* out);
  * pass keeps (count + element indices, not shell ids); returns the overflow flag */
 int uso_debug_contacts(void* h, int env, const double* act, double* out /* [USO_MAXC][8] */);
 int uso_element_distances(void* h, int env, double* dist_out, int32_t* contacts_out);
+/* study hooks (tests/cone_qp.py, tests/studies/pair_lab.py, full_torso_lab.py): the dual contact problem of the forward pass at the current state of `env` under the
+ * action `act` -- the top-face model's (layout at g_dual_dump in usim_oracle.c; returns the number of pairs) and the full torso's (layout at g_full_dump; `cap` doubles
+ * available; returns the number of virtual contacts, 0 if the buffer is too small).  One global pointer each: not thread-safe. */
+int uso_debug_dual(void* h, int env, const double* act, double* out);
+int uso_debug_full(void* h, int env, const double* act, double* out, long cap);
 /* signed distance of a point (site frame) from the probe stand-in and the direction the collision uses there (unit vector) */
 double uso_probe_sdf(void* h, const double* p_site, double* grad_out);
 
