@@ -69,6 +69,7 @@ def _float32_oracle_tail(n, steps, torso, mode, so64, alive, extra):
             for key in ("q", "qd", "s", "sd") if np.asarray(so64[key]).size}
 
 
+LAST = {}                    # what the last _run_parity call found beyond its return value: {"f32_explained": environments beyond the state bar that float32's own tail explained}
 REPORT = None                # a study script sets this to a dict to collect the per-environment state errors instead of asserting the state bars
 
 
@@ -165,6 +166,7 @@ def _run_parity(usim, n, steps, torso, mode, state_rtol=STATE_RTOL, **extra):
             explained += int(over.sum())
             alive &= ~over
     f32_tail = None
+    LAST["f32_explained"] = 0
     for key in ("q", "qd", "s", "sd"):
         if np.asarray(sg[key]).size:
             # per environment: largest difference over the field's components, relative to the largest magnitude of the field in the batch
@@ -185,6 +187,7 @@ def _run_parity(usim, n, steps, torso, mode, state_rtol=STATE_RTOL, **extra):
                 assert np.all(f32_tail[key][idx] >= 0.5 * state_rtol) and len(over) <= max(1, n // 1024) and per_env.max() < 3 * state_rtol, \
                     (key, idx, per_env[over], f32_tail[key][idx])
                 explained += len(over)
+                LAST["f32_explained"] += len(over)
     for key in ("t", "episode", "has_touched"):
         assert np.array_equal(np.asarray(sg[key])[alive].astype(int), so[key][alive].astype(int)), key
     if torso == "full":
